@@ -1,0 +1,1177 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported by the product path (linearham_amd/).
+
+CPU restatement (numpy, dense, single-threaded) of the reference's phylo-HMM log-likelihood path,
+function by function.  Citations are file:line into matsengrp/linearham (mounted read-only at
+/root/reference in the build container).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.
+
+Parity status: PINNED.  `tests/test_oracle_goldens.py` checks this module against every literal
+of the reference's own Catch tests (tests/golden/reference_goldens.json, transcribed from
+test/test.cpp): parameter parsing, state space, dense transition matrices, xMSA + index arrays,
+xmsa_emission (1e-5), the five log-likelihood goldens and the seed-0 sampled paths.
+
+The Felsenstein-pruning arithmetic of the reference lives in a third-party dependency that is NOT
+vendored in /root/reference (matsengrp/libptpll wrapping xflouris/libpll-2, version unpinned in the
+snapshot -- lib/libptpll is an empty submodule directory).  Its published algorithm is restated
+here (GTR with rates ordered AC,AG,AT,CG,CT,GT, Q normalised to mean rate 1, discrete-Gamma
+category MEANS with equal weights, N tips = all-ones CLV) and anchored on the reference's own
+golden vectors for the call sites src/PhyloHMM.cpp:224-226,360,368-370.
+"""
+import math
+import os
+import re
+
+import numpy as np
+import yaml
+
+EPS = 1e-6                      # src/utils.hpp:20
+SCALE_FACTOR = 2.0 ** 256       # src/utils.hpp:22
+SCALE_THRESHOLD = 1.0 / SCALE_FACTOR  # src/utils.hpp:24
+LOG_SCALE_FACTOR = math.log(SCALE_FACTOR)
+
+
+# --------------------------------------------------------------------------------------------
+# utils  (src/utils.cpp)
+# --------------------------------------------------------------------------------------------
+
+def scale_matrix(m):
+    """src/utils.cpp:135-144 -- in place; returns the number of multiplications."""
+    n = 0
+    while np.any((0 < m) & (m < SCALE_THRESHOLD)):
+        m *= SCALE_FACTOR
+        n += 1
+    return n
+
+
+def parse_string_prob_map(node):
+    """src/utils.cpp:20-35"""
+    names = list(node.keys())
+    probs = np.array([float(node[k]) for k in names])
+    assert abs(probs.sum() - 1) <= EPS, (names, probs)
+    return names, probs
+
+
+def get_alphabet(root):
+    """src/utils.cpp:43-51"""
+    return "".join(sorted(str(c) for c in root["tracks"]["nukes"]))
+
+
+def find_germline_start_end(root, gname):
+    """src/utils.cpp:110-125"""
+    states = root["states"]
+    gstart, gend = 0, len(states) - 1
+    while gname not in states[gstart]["name"]:
+        gstart += 1
+    while gname not in states[gend]["name"]:
+        gend -= 1
+    return gstart, gend
+
+
+def fix_gene_name(name):
+    return name.replace("_star_", "*").replace("_slash_", "/")
+
+
+def convert_seq_to_ints(seq, alphabet):
+    """src/utils.cpp:155-164"""
+    return np.array([alphabet.index(c) for c in seq], dtype=np.int32)
+
+
+# --------------------------------------------------------------------------------------------
+# Germline / NTInsertion / NPadding  (src/Germline.cpp, src/NTInsertion.cpp, src/NPadding.cpp)
+# --------------------------------------------------------------------------------------------
+
+class GermlineGene:
+    """One allele: Germline fields always; NTInsertion fields for D/J; NPadding fields for V/J
+    (src/VDJGermline.hpp:20-66)."""
+
+    def __init__(self, root, gtype):
+        self.type = gtype
+        self._parse_germline(root)
+        if gtype in ("D", "J"):
+            self._parse_nti(root)
+        if gtype in ("V", "J"):
+            self._parse_npadding(root)
+
+    # src/Germline.cpp:20-115
+    def _parse_germline(self, root):
+        self.alphabet = get_alphabet(root)
+        name = root["name"]
+        grgx = re.compile("^" + re.escape(name) + "_([0-9]+)$")
+        gstart, gend = find_germline_start_end(root, name)
+        nstates = len(root["states"])
+        assert gstart == 2 or gstart == len(self.alphabet) + 1
+        assert gend == nstates - 1 or gend == nstates - 2
+        gcount = gend - gstart + 1
+        self.name = fix_gene_name(name)
+        self.landing_in = np.zeros(gcount)
+        self.landing_out = np.zeros(gcount)
+        self.transition = np.zeros(gcount - 1)
+        self.emission = np.zeros((len(self.alphabet), gcount))
+        self.bases = np.zeros(gcount, dtype=np.int32)
+        self.gene_prob = float(root["extras"]["gene_prob"])
+        self.length = gcount
+        init = root["states"][0]
+        assert init["name"] == "init"
+        names, probs = parse_string_prob_map(init["transitions"])
+        for nm, p in zip(names, probs):
+            m = grgx.match(nm)
+            if m:
+                self.landing_in[int(m.group(1))] = p
+            else:
+                assert "insert_left_" in nm
+        for i in range(gstart, gend + 1):
+            st = root["states"][i]
+            m = grgx.match(st["name"])
+            assert m
+            gindex = int(m.group(1))
+            assert gindex == i - gstart
+            names, probs = parse_string_prob_map(st["transitions"])
+            for nm, p in zip(names, probs):
+                m = grgx.match(nm)
+                if m:
+                    assert int(m.group(1)) == gindex + 1
+                    self.transition[gindex] = p
+                elif nm == "end":
+                    self.landing_out[gindex] = p
+                else:
+                    assert nm == "insert_right_N"
+            names, probs = parse_string_prob_map(st["emissions"]["probs"])
+            assert st["emissions"]["track"] == "nukes"
+            for nm, p in zip(names, probs):
+                self.emission[self.alphabet.index(nm[0]), gindex] = p
+            self.bases[gindex] = self.alphabet.index(str(st["extras"]["germline"]))
+
+    # src/NTInsertion.cpp:21-104
+    def _parse_nti(self, root):
+        alphabet = get_alphabet(root)
+        gname = root["name"]
+        grgx = re.compile("^" + re.escape(gname) + "_([0-9]+)$")
+        nti_rgx = re.compile("^insert_left_([" + alphabet + "])$")
+        gstart, gend = find_germline_start_end(root, gname)
+        assert gstart == len(alphabet) + 1
+        gcount = gend - gstart + 1
+        na = len(alphabet)
+        self.nti_landing_in = np.zeros(na)
+        self.nti_landing_out = np.zeros((na, gcount))
+        self.nti_transition = np.zeros((na, na))
+        self.nti_emission = np.zeros((na, na))
+        init = root["states"][0]
+        names, probs = parse_string_prob_map(init["transitions"])
+        for nm, p in zip(names, probs):
+            m = nti_rgx.match(nm)
+            if m:
+                self.nti_landing_in[alphabet.index(m.group(1))] = p
+            else:
+                assert grgx.match(nm)
+        for i in range(1, na + 1):
+            st = root["states"][i]
+            m = nti_rgx.match(st["name"])
+            assert m
+            nti_base = alphabet.index(m.group(1))
+            names, probs = parse_string_prob_map(st["transitions"])
+            for nm, p in zip(names, probs):
+                m = grgx.match(nm)
+                if m:
+                    self.nti_landing_out[nti_base, int(m.group(1))] = p
+                else:
+                    m = nti_rgx.match(nm)
+                    assert m
+                    self.nti_transition[nti_base, alphabet.index(m.group(1))] = p
+            names, probs = parse_string_prob_map(st["emissions"]["probs"])
+            for nm, p in zip(names, probs):
+                self.nti_emission[alphabet.index(nm[0]), nti_base] = p
+
+    # src/NPadding.cpp:22-109
+    def _parse_npadding(self, root):
+        alphabet = get_alphabet(root)
+        gname = root["name"]
+        gstart, gend = find_germline_start_end(root, gname)
+        nstates = len(root["states"])
+        assert gstart == 2 or gend == nstates - 2
+        if gstart == 2:
+            n_index, n_check_index, n_name, next_name = gstart - 1, gstart - 2, "insert_left_N", gname + "_0"
+        else:
+            n_index, n_check_index, n_name, next_name = gend + 1, gend, "insert_right_N", "end"
+        n_state = root["states"][n_index]
+        n_check = root["states"][n_check_index]
+        assert n_state["name"] == n_name
+        t = {k: float(v) for k, v in n_state["transitions"].items()}
+        tc = {k: float(v) for k, v in n_check["transitions"].items()}
+        assert len(t) == len(tc)
+        for (k, v), (kc, vc) in zip(sorted(t.items()), sorted(tc.items())):
+            assert k == kc and abs(v - vc) <= EPS
+            if k == n_name:
+                self.n_transition = v
+            else:
+                assert k == next_name
+        names, probs = parse_string_prob_map(n_state["emissions"]["probs"])
+        self.n_emission = np.zeros(len(alphabet))
+        for nm, p in zip(names, probs):
+            assert p == 0.25
+            self.n_emission[alphabet.index(nm[0])] = p
+
+
+def create_germline_gene_map(hmm_param_dir):
+    """src/VDJGermline.cpp:46-108"""
+    if not os.path.isdir(hmm_param_dir):
+        raise RuntimeError('--hmm-param-dir "%s" does not exist' % hmm_param_dir)
+    rgx = re.compile(r"^(IG([HKL])([VDJ]).*_star_.*)\.yaml$")
+    ggenes = {}
+    for fn in sorted(os.listdir(hmm_param_dir)):
+        m = rgx.match(fn)
+        if not m:
+            continue
+        if m.group(3) == "D" and m.group(2) in "KL":
+            continue
+        with open(os.path.join(hmm_param_dir, fn)) as f:
+            root = yaml.safe_load(f)
+        ggenes[fix_gene_name(m.group(1))] = GermlineGene(root, m.group(3))
+    return ggenes
+
+
+# --------------------------------------------------------------------------------------------
+# libstdc++ RNG semantics used by sampling (src/HMM.cpp:56,325-329; bits/random.tcc)
+# --------------------------------------------------------------------------------------------
+
+class MT19937:
+    """std::mt19937 seeded with seed(value) (init_genrand)."""
+
+    def __init__(self, seed):
+        self.mt = [0] * 624
+        self.mt[0] = seed & 0xFFFFFFFF
+        for i in range(1, 624):
+            self.mt[i] = (1812433253 * (self.mt[i - 1] ^ (self.mt[i - 1] >> 30)) + i) & 0xFFFFFFFF
+        self.idx = 624
+
+    def __call__(self):
+        if self.idx >= 624:
+            mt = self.mt
+            for k in range(624):
+                y = (mt[k] & 0x80000000) | (mt[(k + 1) % 624] & 0x7FFFFFFF)
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0)
+            self.idx = 0
+        y = self.mt[self.idx]
+        self.idx += 1
+        y ^= y >> 11
+        y ^= (y << 7) & 0x9D2C5680
+        y ^= (y << 15) & 0xEFC60000
+        y ^= y >> 18
+        return y & 0xFFFFFFFF
+
+
+def generate_canonical(rng):
+    """std::generate_canonical<double,53> over mt19937: two draws (bits/random.tcc:3348-3380)."""
+    s = float(rng()) * 1.0
+    s += float(rng()) * 4294967296.0
+    r = s / 18446744073709551616.0
+    if r >= 1.0:
+        r = math.nextafter(1.0, 0.0)
+    return r
+
+
+def discrete_distribution_draw(weights, rng):
+    """std::discrete_distribution<int>::operator() (bits/random.tcc:2656-2713)."""
+    w = [float(x) for x in weights]
+    if len(w) < 2:
+        return 0  # no RNG draw
+    total = 0.0
+    for x in w:
+        total += x
+    cp = []
+    acc = 0.0
+    for x in w:
+        acc += x / total
+        cp.append(acc)
+    cp[-1] = 1.0
+    p = generate_canonical(rng)
+    lo, hi = 0, len(cp)
+    while lo < hi:  # std::lower_bound
+        mid = (lo + hi) // 2
+        if cp[mid] < p:
+            lo = mid + 1
+        else:
+            hi = mid
+    return lo
+
+
+# --------------------------------------------------------------------------------------------
+# HMM base class  (src/HMM.cpp)
+# --------------------------------------------------------------------------------------------
+
+class Region:
+    """Bag of per-region state-space vectors (src/HMM.hpp:56-110)."""
+
+    def __init__(self):
+        self.state_strs = []
+        self.left_del = []
+        self.right_del = []
+        self.dels = []
+        self.ggene_types = []
+        self.ggene_ranges = {}   # name -> (start, end); iterate with sorted() == std::map order
+        self.naive_bases = []
+        self.germ_inds = []
+        self.site_inds = []
+
+
+class HMM:
+    def __init__(self, yaml_path, cluster_ind, hmm_param_dir, seed):
+        # src/HMM.cpp:27-63
+        with open(yaml_path) as f:
+            root = yaml.safe_load(f)
+        self.locus = root["germline-info"]["locus"]
+        self.cluster_data = root["events"][cluster_ind]
+        li = self.cluster_data["linearham-info"]
+        self.flexbounds = {k: (int(v[0]), int(v[1])) for k, v in li["flexbounds"].items()}
+        self.relpos = {k: int(v) for k, v in li["relpos"].items()}
+        self.ggenes = create_germline_gene_map(hmm_param_dir)
+        self.alphabet = next(iter(self.ggenes.values())).alphabet + "N"
+        self._initialize_msa()
+        self.rng = MT19937(seed)
+        self._initialize_state_space()
+        self._initialize_transition()
+        self.cache_forward = False
+
+    # src/HMM.cpp:71-83
+    def _initialize_msa(self):
+        cd = self.cluster_data
+        n, L = len(cd["unique_ids"]), len(cd["naive_seq"])
+        self.msa = np.full((n, L), -1, dtype=np.int32)
+        for i in range(n):
+            key = "indel_reversed_seqs" if cd["has_shm_indels"][i] else "input_seqs"
+            self.msa[i] = convert_seq_to_ints(cd[key][i], self.alphabet)
+
+    # src/HMM.cpp:94-185
+    def _initialize_state_space(self):
+        self.vpadding, self.vgerm, self.vd_junction = Region(), Region(), Region()
+        self.dgerm, self.dj_junction, self.jgerm, self.jpadding = Region(), Region(), Region(), Region()
+        fb = self.flexbounds
+        igh = self.locus == "igh"
+        for gname in sorted(self.relpos):   # std::map iteration order
+            relpos = self.relpos[gname]
+            gg = self.ggenes[gname]
+            if gg.type == "V":
+                cache_padding_states(gg, fb["v_l"], relpos, True, self.vpadding)
+                cache_germline_states(gg, fb["v_l"], fb["v_r"], relpos, True, False, self.vgerm)
+                cache_junction_states(gg, fb["v_r"], fb["d_l"] if igh else fb["j_l"], relpos, False,
+                                      self.vd_junction)
+            elif gg.type == "D":
+                cache_junction_states(gg, fb["v_r"], fb["d_l"], relpos, True, self.vd_junction)
+                cache_germline_states(gg, fb["d_l"], fb["d_r"], relpos, False, False, self.dgerm)
+                cache_junction_states(gg, fb["d_r"], fb["j_l"], relpos, False, self.dj_junction)
+            else:
+                assert gg.type == "J"
+                if igh:
+                    cache_junction_states(gg, fb["d_r"], fb["j_l"], relpos, True, self.dj_junction)
+                else:
+                    cache_junction_states(gg, fb["v_r"], fb["j_l"], relpos, True, self.vd_junction)
+                cache_germline_states(gg, fb["j_l"], fb["j_r"], relpos, False, True, self.jgerm)
+                cache_padding_states(gg, fb["j_r"], relpos, False, self.jpadding)
+
+    # src/HMM.cpp:190-246
+    def _initialize_transition(self):
+        g = self.ggenes
+        self.vpadding_transition = compute_padding_transition(self.vpadding, g)
+        if self.locus == "igh":
+            self.vgerm_vd_junction_transition = compute_germline_junction_transition(
+                self.vgerm, self.vd_junction, "V", "D", g)
+            self.vd_junction_transition = compute_junction_transition(self.vd_junction, "V", "D", g)
+            self.vd_junction_dgerm_transition = compute_junction_germline_transition(
+                self.vd_junction, self.dgerm, "V", "D", g)
+            self.dgerm_dj_junction_transition = compute_germline_junction_transition(
+                self.dgerm, self.dj_junction, "D", "J", g)
+            self.dj_junction_transition = compute_junction_transition(self.dj_junction, "D", "J", g)
+            self.dj_junction_jgerm_transition = compute_junction_germline_transition(
+                self.dj_junction, self.jgerm, "D", "J", g)
+        else:
+            assert self.locus in ("igk", "igl")
+            self.vgerm_vd_junction_transition = compute_germline_junction_transition(
+                self.vgerm, self.vd_junction, "V", "J", g)
+            self.vd_junction_transition = compute_junction_transition(self.vd_junction, "V", "J", g)
+            self.vd_junction_dgerm_transition = compute_junction_germline_transition(
+                self.vd_junction, self.jgerm, "V", "J", g)
+        self.jpadding_transition = compute_padding_transition(self.jpadding, g)
+
+    # src/HMM.cpp:254-287
+    def run_forward_algorithm(self):
+        self._compute_initial_forward_probabilities()
+        if self.locus == "igh":
+            self.vd_junction_forward, self.vd_junction_scaler_counts = compute_junction_forward(
+                self.vgerm_forward, self.vgerm_scaler_count, self.vgerm_vd_junction_transition,
+                self.vd_junction_transition, self.vd_junction_emission)
+            nd = len(self.dgerm.state_strs)
+            self.dgerm_forward, self.dgerm_scaler_count = compute_germline_forward(
+                self.vd_junction_forward, self.vd_junction_scaler_counts,
+                self.vd_junction_dgerm_transition, self.dgerm_emission, np.ones(nd), np.ones(nd),
+                self.dgerm_scaler_count)
+            self.dj_junction_forward, self.dj_junction_scaler_counts = compute_junction_forward(
+                self.dgerm_forward, self.dgerm_scaler_count, self.dgerm_dj_junction_transition,
+                self.dj_junction_transition, self.dj_junction_emission)
+            self.jgerm_forward, self.jgerm_scaler_count = compute_germline_forward(
+                self.dj_junction_forward, self.dj_junction_scaler_counts,
+                self.dj_junction_jgerm_transition, self.jgerm_emission, self.jpadding_transition,
+                self.jpadding_emission, self.jgerm_scaler_count)
+        else:
+            self.vd_junction_forward, self.vd_junction_scaler_counts = compute_junction_forward(
+                self.vgerm_forward, self.vgerm_scaler_count, self.vgerm_vd_junction_transition,
+                self.vd_junction_transition, self.vd_junction_emission)
+            self.jgerm_forward, self.jgerm_scaler_count = compute_germline_forward(
+                self.vd_junction_forward, self.vd_junction_scaler_counts,
+                self.vd_junction_dgerm_transition, self.jgerm_emission, self.jpadding_transition,
+                self.jpadding_emission, self.jgerm_scaler_count)
+
+    # src/HMM.cpp:291-319
+    def _compute_initial_forward_probabilities(self):
+        n = len(self.vgerm.state_strs)
+        f = np.zeros(n)
+        for i, gname in enumerate(sorted(self.vgerm.ggene_ranges)):
+            rs, re_ = self.vgerm.ggene_ranges[gname]
+            gg = self.ggenes[gname]
+            gis = self.vgerm.germ_inds[rs]
+            v = gg.gene_prob
+            v *= self.vpadding_transition[i]
+            v *= self.vpadding_emission[i]
+            v *= np.prod(gg.transition[gis:gis + (re_ - rs - 1)])
+            v *= self.vgerm_emission[i]
+            f[i] = v
+        self.vgerm_scaler_count += scale_matrix(f)
+        self.vgerm_forward = f
+
+    # src/HMM.cpp:345-354
+    def log_likelihood(self):
+        if self.cache_forward:
+            self.run_forward_algorithm()
+            self.cache_forward = False
+        with np.errstate(divide="ignore"):
+            return float(np.log(self.jgerm_forward.sum()) - self.jgerm_scaler_count * LOG_SCALE_FACTOR)
+
+    # src/HMM.cpp:358-431 (+323-341, 1222-1353)
+    def sample_naive_sequence(self):
+        if self.cache_forward:
+            self.run_forward_algorithm()
+            self.cache_forward = False
+        L = self.msa.shape[1]
+        s = ["N"] * L
+        out = {}
+        # SampleInitialState
+        j = discrete_distribution_draw(self.jgerm_forward, self.rng)
+        out["jgerm_state_ind_samp"] = j
+        out["jgerm_state_str_samp"] = self.jgerm.state_strs[j]
+        out["jgerm_left_del_samp"] = self.jgerm.left_del[j]
+        out["jgerm_right_del_samp"] = self.jgerm.right_del[j]
+        rs, re_ = self.jgerm.ggene_ranges[self.jgerm.state_strs[j]]
+        for i in range(rs, re_):
+            s[self.jgerm.site_inds[i]] = self.alphabet[self.jgerm.naive_bases[i]]
+        if self.locus == "igh":
+            r = sample_junction_states(j, self.dj_junction_jgerm_transition, self.dj_junction,
+                                       self.dj_junction_transition, self.dj_junction_forward, "D", "J",
+                                       self.flexbounds["d_r"], self.alphabet, self.rng, s,
+                                       out["jgerm_left_del_samp"])
+            (out["jgerm_left_del_samp"], out["dj_junction_state_str_samps"],
+             out["dj_junction_state_ind_samps"], out["dj_junction_insertion_samp"], d_right_del) = r
+            r = sample_germline_state(out["dj_junction_state_ind_samps"],
+                                      self.dgerm_dj_junction_transition, self.dgerm, self.dgerm_forward,
+                                      self.alphabet, self.rng, s, d_right_del)
+            (out["dgerm_state_str_samp"], out["dgerm_state_ind_samp"], out["dgerm_left_del_samp"],
+             out["dgerm_right_del_samp"]) = r
+            r = sample_junction_states(out["dgerm_state_ind_samp"], self.vd_junction_dgerm_transition,
+                                       self.vd_junction, self.vd_junction_transition,
+                                       self.vd_junction_forward, "V", "D", self.flexbounds["v_r"],
+                                       self.alphabet, self.rng, s, out["dgerm_left_del_samp"])
+            (out["dgerm_left_del_samp"], out["vd_junction_state_str_samps"],
+             out["vd_junction_state_ind_samps"], out["vd_junction_insertion_samp"], v_right_del) = r
+        else:
+            r = sample_junction_states(j, self.vd_junction_dgerm_transition, self.vd_junction,
+                                       self.vd_junction_transition, self.vd_junction_forward, "V", "J",
+                                       self.flexbounds["v_r"], self.alphabet, self.rng, s,
+                                       out["jgerm_left_del_samp"])
+            (out["jgerm_left_del_samp"], out["vd_junction_state_str_samps"],
+             out["vd_junction_state_ind_samps"], out["vd_junction_insertion_samp"], v_right_del) = r
+        r = sample_germline_state(out["vd_junction_state_ind_samps"], self.vgerm_vd_junction_transition,
+                                  self.vgerm, self.vgerm_forward, self.alphabet, self.rng, s, v_right_del)
+        (out["vgerm_state_str_samp"], out["vgerm_state_ind_samp"], out["vgerm_left_del_samp"],
+         out["vgerm_right_del_samp"]) = r
+        seq = "".join(s)
+        m = re.match("^(N*)[" + self.alphabet[:-1] + "]+(N*)$", seq)
+        out["vgerm_left_insertion_samp"] = m.group(1) if m else ""
+        out["jgerm_right_insertion_samp"] = m.group(2) if m else ""
+        out["naive_seq_samp"] = seq
+        self.sample = out
+        return seq
+
+
+# src/HMM.cpp:466-498
+def cache_germline_states(gg, left_fb, right_fb, relpos, left_end, right_end, R):
+    site_start = max(relpos, left_fb[0]) if left_end else left_fb[1]
+    site_end = min(relpos + gg.length, right_fb[1]) if right_end else right_fb[0]
+    rs = len(R.naive_bases)
+    R.ggene_ranges[gg.name] = (rs, rs + (site_end - site_start))
+    R.state_strs.append(gg.name)
+    R.left_del.append(site_start - relpos)
+    R.right_del.append(relpos + gg.length - site_end)
+    for i in range(site_start, site_end):
+        R.naive_bases.append(int(gg.bases[i - relpos]))
+        R.germ_inds.append(i - relpos)
+        R.site_inds.append(i)
+
+
+# src/HMM.cpp:528-576
+def cache_junction_states(gg, left_fb, right_fb, relpos, left_end, R):
+    site_start = max(relpos, left_fb[0]) if left_end else left_fb[0]
+    site_end = right_fb[1] if left_end else min(relpos + gg.length, right_fb[1])
+    rs = len(R.naive_bases)
+    re_ = rs + (site_end - site_start)
+    na = len(gg.alphabet)
+    if left_end:
+        re_ += na
+    R.ggene_ranges[gg.name] = (rs, re_)
+    if left_end:
+        for i in range(na):
+            R.state_strs.append(gg.name + ":N_" + gg.alphabet[i])
+            R.dels.append(-1)
+            R.ggene_types.append(gg.type)
+            R.naive_bases.append(i)
+            R.germ_inds.append(-1)
+            R.site_inds.append(-1)
+    for i in range(site_start, site_end):
+        R.state_strs.append(gg.name + ":" + str(i - relpos))
+        R.dels.append(i - relpos if left_end else relpos + gg.length - i - 1)
+        R.ggene_types.append(gg.type)
+        R.naive_bases.append(int(gg.bases[i - relpos]))
+        R.germ_inds.append(i - relpos)
+        R.site_inds.append(i)
+
+
+# src/HMM.cpp:595-619
+def cache_padding_states(gg, fb, relpos, left_end, R):
+    site_start = fb[0] if left_end else min(relpos + gg.length, fb[1])
+    site_end = max(relpos, fb[0]) if left_end else fb[1]
+    rs = len(R.naive_bases)
+    R.ggene_ranges[gg.name] = (rs, rs + (site_end - site_start))
+    for i in range(site_start, site_end):
+        R.naive_bases.append(len(gg.alphabet))
+        R.site_inds.append(i)
+
+
+def _to_info(J, to_name, right_gtype, ggenes):
+    trs, tre = J.ggene_ranges[to_name]
+    tg = ggenes[to_name]
+    nti_len = len(tg.alphabet) if tg.type == right_gtype else 0
+    germ_start = trs + nti_len
+    germ_len = tre - germ_start
+    gi = J.germ_inds[germ_start] if germ_len > 0 else -1
+    si = J.site_inds[germ_start] if germ_len > 0 else -1
+    return trs, tre, tg, nti_len, germ_start, germ_len, gi, si
+
+
+# src/HMM.cpp:647-706
+def compute_germline_junction_transition(G, J, left_gtype, right_gtype, ggenes):
+    T = np.zeros((len(G.state_strs), len(J.state_strs)))
+    for from_i, from_name in enumerate(sorted(G.ggene_ranges)):
+        frs, fre = G.ggene_ranges[from_name]
+        fg = ggenes[from_name]
+        f_gi = G.germ_inds[fre - 1]
+        f_si = G.site_inds[fre - 1]
+        for to_name in sorted(J.ggene_ranges):
+            trs, tre, tg, nti_len, germ_start, germ_len, t_gi, t_si = _to_info(J, to_name, right_gtype, ggenes)
+            fill_transition(fg, tg, left_gtype, right_gtype, f_gi, t_gi, f_si, t_si, 0, trs, 0, nti_len,
+                            0, germ_start, 1, germ_len, T[from_i:from_i + 1, :])
+    return T
+
+
+# src/HMM.cpp:726-784
+def compute_junction_transition(J, left_gtype, right_gtype, ggenes):
+    S = len(J.state_strs)
+    T = np.zeros((S, S))
+    for from_name in sorted(J.ggene_ranges):
+        frs, fre, fg, nti_rl, germ_rs, germ_rl, f_gi, f_si = _to_info(J, from_name, right_gtype, ggenes)
+        for to_name in sorted(J.ggene_ranges):
+            trs, tre, tg, nti_cl, germ_cs, germ_cl, t_gi, t_si = _to_info(J, to_name, right_gtype, ggenes)
+            fill_transition(fg, tg, left_gtype, right_gtype, f_gi, t_gi, f_si, t_si, frs, trs, nti_rl,
+                            nti_cl, germ_rs, germ_cs, germ_rl, germ_cl, T)
+    return T
+
+
+# src/HMM.cpp:812-879
+def compute_junction_germline_transition(J, G, left_gtype, right_gtype, ggenes):
+    T = np.zeros((len(J.state_strs), len(G.state_strs)))
+    for from_name in sorted(J.ggene_ranges):
+        frs, fre, fg, nti_rl, germ_rs, germ_rl, f_gi, f_si = _to_info(J, from_name, right_gtype, ggenes)
+        for to_i, to_name in enumerate(sorted(G.ggene_ranges)):
+            trs, tre = G.ggene_ranges[to_name]
+            tg = ggenes[to_name]
+            t_gi = G.germ_inds[trs]
+            t_si = G.site_inds[trs]
+            col = T[:, to_i:to_i + 1]
+            fill_transition(fg, tg, left_gtype, right_gtype, f_gi, t_gi, f_si, t_si, frs, 0, nti_rl, 0,
+                            germ_rs, 0, germ_rl, 1, col)
+            col[frs:fre, 0] *= np.prod(tg.transition[t_gi:t_gi + (tre - trs - 1)])
+    return T
+
+
+# src/HMM.cpp:891-915
+def compute_padding_transition(P, ggenes):
+    out = np.zeros(len(P.ggene_ranges))
+    for i, gname in enumerate(sorted(P.ggene_ranges)):
+        rs, re_ = P.ggene_ranges[gname]
+        nt = ggenes[gname].n_transition
+        out[i] = (1.0 - nt) * math.pow(nt, re_ - rs)
+    return out
+
+
+# src/HMM.cpp:964-1089
+def fill_transition(fg, tg, left_gtype, right_gtype, germ_ind_row_start, germ_ind_col_start,
+                    site_ind_row_start, site_ind_col_start, nti_row_start, nti_col_start,
+                    nti_row_length, nti_col_length, germ_row_start, germ_col_start, germ_row_length,
+                    germ_col_length, T):
+    if fg.name == tg.name:
+        if fg.type == right_gtype:
+            if nti_col_length > 0:
+                T[nti_row_start:nti_row_start + nti_row_length,
+                  nti_col_start:nti_col_start + nti_col_length] = fg.nti_transition
+            if germ_col_length > 0:
+                T[nti_row_start:nti_row_start + nti_row_length,
+                  germ_col_start:germ_col_start + germ_col_length] = \
+                    fg.nti_landing_out[:, germ_ind_col_start:germ_ind_col_start + germ_col_length]
+        if germ_row_length > 0 and germ_col_length > 0:
+            blk = T[germ_row_start:germ_row_start + germ_row_length,
+                    germ_col_start:germ_col_start + germ_col_length]
+            if germ_ind_row_start == germ_ind_col_start:
+                seg = fg.transition[germ_ind_row_start:germ_ind_row_start + germ_row_length - 1]
+                for k in range(len(seg)):
+                    blk[k, k + 1] = seg[k]
+            else:
+                # Eigen diagonal(-(rows-1)) of the block is its single bottom-left element;
+                # transition().diagonal(-k) of a column vector is element k.
+                blk[germ_row_length - 1, 0] = fg.transition[germ_ind_row_start + germ_row_length - 1]
+    if fg.type == left_gtype and tg.type == right_gtype:
+        if germ_row_length > 0 and nti_col_length > 0:
+            blk = T[germ_row_start:germ_row_start + germ_row_length,
+                    nti_col_start:nti_col_start + nti_col_length]
+            lo = fg.landing_out[germ_ind_row_start:germ_ind_row_start + germ_row_length]
+            blk[:, :] = 1.0
+            blk *= lo[:, None]
+            blk *= tg.gene_prob
+            blk *= tg.nti_landing_in[None, :]
+        if germ_row_length > 0 and germ_col_length > 0:
+            match_found = False
+            mrd = mcd = 0
+            for fs in range(site_ind_row_start, site_ind_row_start + germ_row_length):
+                if match_found:
+                    break
+                if fs == site_ind_col_start - 1:
+                    mrd, mcd, match_found = fs - site_ind_row_start, 0, True
+            for ts in range(site_ind_col_start + 1, site_ind_col_start + germ_col_length):
+                if match_found:
+                    break
+                if site_ind_row_start == ts - 1:
+                    mrd, mcd, match_found = 0, ts - site_ind_col_start, True
+            if match_found:
+                nr, nc = germ_row_length - mrd, germ_col_length - mcd
+                ml = min(nr, nc)
+                for k in range(ml):
+                    T[germ_row_start + mrd + k, germ_col_start + mcd + k] = \
+                        fg.landing_out[germ_ind_row_start + mrd + k] * tg.gene_prob * \
+                        tg.landing_in[germ_ind_col_start + mcd + k]
+
+
+# src/HMM.cpp:1107-1139
+def compute_junction_forward(germ_forward, germ_scaler_count, T_gj, T_jj, E):
+    W, S = E.shape
+    F = np.zeros((W, S))
+    counts = [0] * W
+    for i in range(W):
+        if i == 0:
+            row = germ_forward @ T_gj
+            prev = germ_scaler_count
+        else:
+            row = F[i - 1] @ T_jj
+            prev = counts[i - 1]
+        row = row * E[i]
+        counts[i] = prev + scale_matrix(row)
+        F[i] = row
+    return F, counts
+
+
+# src/HMM.cpp:1160-1177
+def compute_germline_forward(F, counts, T_jg, germ_emission, padding_transition, padding_emission,
+                             germ_scaler_count):
+    f = F[-1] @ T_jg
+    f = f * germ_emission
+    f = f * padding_transition
+    f = f * padding_emission
+    germ_scaler_count += counts[-1] + scale_matrix(f)
+    return f, germ_scaler_count
+
+
+# src/HMM.cpp:1222-1278
+def sample_junction_states(germ_state_ind, T_jg, J, T_jj, F, left_gtype, right_gtype, left_fb, alphabet,
+                           rng, s, germ_left_del):
+    site_start = left_fb[0]
+    W = F.shape[0]
+    strs, inds = [""] * W, [-1] * W
+    insertion = ""
+    germ_right_del = -1
+    for i in range(W - 1, -1, -1):
+        probs = (T_jg[:, germ_state_ind] if i == W - 1 else T_jj[:, inds[i + 1]]) * F[i]
+        k = discrete_distribution_draw(probs, rng)
+        inds[i] = k
+        strs[i] = J.state_strs[k]
+        s[site_start + i] = alphabet[J.naive_bases[k]]
+        if J.ggene_types[k] == right_gtype:
+            if J.dels[k] != -1:
+                germ_left_del = J.dels[k]
+            else:
+                insertion = alphabet[J.naive_bases[k]] + insertion
+        elif J.ggene_types[k] == left_gtype and germ_right_del == -1:
+            germ_right_del = J.dels[k]
+    return germ_left_del, strs, inds, insertion, germ_right_del
+
+
+# src/HMM.cpp:1316-1353
+def sample_germline_state(junction_inds, T_gj, G, germ_forward, alphabet, rng, s, germ_right_del):
+    probs = T_gj[:, junction_inds[0]] * germ_forward
+    k = discrete_distribution_draw(probs, rng)
+    name = G.state_strs[k]
+    left_del = G.left_del[k]
+    if germ_right_del == -1:
+        germ_right_del = G.right_del[k]
+    rs, re_ = G.ggene_ranges[name]
+    for i in range(rs, re_):
+        s[G.site_inds[i]] = alphabet[G.naive_bases[i]]
+    return name, k, left_del, germ_right_del
+
+
+# --------------------------------------------------------------------------------------------
+# SimpleHMM  (src/SimpleHMM.cpp)
+# --------------------------------------------------------------------------------------------
+
+class SimpleHMM(HMM):
+    def __init__(self, yaml_path, cluster_ind, hmm_param_dir, seed):
+        super().__init__(yaml_path, cluster_ind, hmm_param_dir, seed)
+        self.vgerm_scaler_count = 0
+        self.dgerm_scaler_count = 0
+        self.jgerm_scaler_count = 0
+        self._initialize_emission()
+        self.cache_forward = True
+
+    # src/SimpleHMM.cpp:47-77
+    def _initialize_emission(self):
+        fb = self.flexbounds
+        self.vpadding_emission, c = self._fill_padding(self.vpadding)
+        self.vgerm_scaler_count += c
+        self.vgerm_emission, c = self._fill_germline(self.vgerm)
+        self.vgerm_scaler_count += c
+        if self.locus == "igh":
+            self.vd_junction_emission = self._fill_junction(self.vd_junction, fb["v_r"], fb["d_l"])
+            self.dgerm_emission, c = self._fill_germline(self.dgerm)
+            self.dgerm_scaler_count += c
+            self.dj_junction_emission = self._fill_junction(self.dj_junction, fb["d_r"], fb["j_l"])
+        else:
+            self.vd_junction_emission = self._fill_junction(self.vd_junction, fb["v_r"], fb["j_l"])
+        self.jgerm_emission, c = self._fill_germline(self.jgerm)
+        self.jgerm_scaler_count += c
+        self.jpadding_emission, c = self._fill_padding(self.jpadding)
+        self.jgerm_scaler_count += c
+
+    def _equalise(self, em, counts):
+        mx = max(counts) if counts else 0
+        for i in range(len(em)):
+            em[i] *= math.pow(SCALE_FACTOR, mx - counts[i]) if mx - counts[i] < 4 else math.inf
+        return em, mx
+
+    # src/SimpleHMM.cpp:95-139
+    def _fill_germline(self, R):
+        names = sorted(R.ggene_ranges)
+        em = np.ones(len(names))
+        counts = [0] * len(names)
+        N = len(self.alphabet) - 1
+        for i, gname in enumerate(names):
+            rs, re_ = R.ggene_ranges[gname]
+            gg = self.ggenes[gname]
+            for j in range(rs, re_):
+                for k in range(self.msa.shape[0]):
+                    b = self.msa[k, R.site_inds[j]]
+                    if b != N:
+                        em[i] *= gg.emission[b, R.germ_inds[j]]
+                        counts[i] += scale_matrix(em[i:i + 1])
+        return self._equalise(em, counts)
+
+    # src/SimpleHMM.cpp:160-211
+    def _fill_junction(self, R, left_fb, right_fb):
+        site_start, site_end = left_fb[0], right_fb[1]
+        E = np.zeros((site_end - site_start, len(R.naive_bases)))
+        N = len(self.alphabet) - 1
+        for gname in sorted(R.ggene_ranges):
+            rs, re_ = R.ggene_ranges[gname]
+            gg = self.ggenes[gname]
+            for i in range(rs, re_):
+                if R.site_inds[i] == -1:
+                    for site in range(site_start, site_end):
+                        v = 1.0
+                        for j in range(self.msa.shape[0]):
+                            b = self.msa[j, site]
+                            if b != N:
+                                v *= gg.nti_emission[b, R.naive_bases[i]]
+                        E[site - site_start, i] = v
+                else:
+                    v = 1.0
+                    for j in range(self.msa.shape[0]):
+                        b = self.msa[j, R.site_inds[i]]
+                        if b != N:
+                            v *= gg.emission[b, R.germ_inds[i]]
+                    E[R.site_inds[i] - site_start, i] = v
+        return E
+
+    # src/SimpleHMM.cpp:224-271
+    def _fill_padding(self, R):
+        names = sorted(R.ggene_ranges)
+        em = np.ones(len(names))
+        counts = [0] * len(names)
+        N = len(self.alphabet) - 1
+        for i, gname in enumerate(names):
+            rs, re_ = R.ggene_ranges[gname]
+            gg = self.ggenes[gname]
+            for j in range(rs, re_):
+                for k in range(self.msa.shape[0]):
+                    b = self.msa[k, R.site_inds[j]]
+                    if b != N:
+                        em[i] *= gg.n_emission[b]
+                        counts[i] += scale_matrix(em[i:i + 1])
+        return self._equalise(em, counts)
+
+
+# --------------------------------------------------------------------------------------------
+# Third-party numeric engine restated: Newick, GTR+Gamma, pruning  (libptpll / libpll-2 [3P])
+# --------------------------------------------------------------------------------------------
+
+class Tree:
+    """Unrooted binary tree: nodes 0..T-1 are tips (labels), T.. are inner nodes;
+    adj[node] = list of (neighbour, branch_length)."""
+
+    def __init__(self, labels, adj):
+        self.labels = labels
+        self.adj = adj
+        self.n_tips = len(labels)
+
+
+def parse_newick(text, eps=EPS):
+    """pll_utree_parse_newick_string + pt::pll::set_missing_branch_length (src/PhyloHMM.cpp:419-422,
+    354-355).  `[&index=N]` comments are stripped; missing or zero lengths become `eps`.
+    A bifurcating top level (rooted Newick) is unrooted by merging its two branches."""
+    text = re.sub(r"\[\&index=[0-9]+\]", "", text)
+    text = re.sub(r"\[[^\]]*\]", "", text).strip()
+    pos = [0]
+
+    def skip_ws():
+        while pos[0] < len(text) and text[pos[0]].isspace():
+            pos[0] += 1
+
+    def parse_len():
+        skip_ws()
+        if pos[0] < len(text) and text[pos[0]] == ":":
+            pos[0] += 1
+            m = re.match(r"\s*([-+0-9.eE]+)", text[pos[0]:])
+            pos[0] += m.end()
+            return float(m.group(1))
+        return None
+
+    def parse_node():
+        skip_ws()
+        if text[pos[0]] == "(":
+            pos[0] += 1
+            kids = []
+            while True:
+                kids.append(parse_node())
+                skip_ws()
+                if text[pos[0]] == ",":
+                    pos[0] += 1
+                    continue
+                assert text[pos[0]] == ")", text[pos[0]:pos[0] + 20]
+                pos[0] += 1
+                break
+            m = re.match(r"[^,():;\s]*", text[pos[0]:])   # inner label, ignored
+            pos[0] += m.end()
+            return {"kids": kids, "len": parse_len(), "label": None}
+        m = re.match(r"[^,():;\s]+", text[pos[0]:])
+        pos[0] += m.end()
+        return {"kids": [], "len": parse_len(), "label": m.group(0)}
+
+    root = parse_node()
+    labels, adj = [], []
+
+    def fix(l):
+        return eps if (l is None or l == 0.0) else l
+
+    # tips first
+    def collect(n):
+        if not n["kids"]:
+            n["id"] = len(labels)
+            labels.append(n["label"])
+        for k in n["kids"]:
+            collect(k)
+    collect(root)
+    T = len(labels)
+    adj = [[] for _ in range(T)]
+
+    def build(n):
+        if n["kids"]:
+            assert len(n["kids"]) == 2, "inner nodes below the top level must be binary"
+            n["id"] = len(adj)
+            adj.append([])
+            for k in n["kids"]:
+                build(k)
+                link(n["id"], k["id"], fix(k["len"]))
+
+    def link(a, b, l):
+        adj[a].append((b, l))
+        adj[b].append((a, l))
+
+    if len(root["kids"]) == 3:
+        root["id"] = len(adj)
+        adj.append([])
+        for k in root["kids"]:
+            build(k)
+            link(root["id"], k["id"], fix(k["len"]))
+    elif len(root["kids"]) == 2:
+        a, b = root["kids"]
+        build(a)
+        build(b)
+        la = 0.0 if a["len"] is None else a["len"]
+        lb = 0.0 if b["len"] is None else b["len"]
+        link(a["id"], b["id"], fix(la + lb))
+    else:
+        raise ValueError("unsupported Newick top level with %d children" % len(root["kids"]))
+    return Tree(labels, adj)
+
+
+def gamma_rates_mean(alpha, R):
+    """pll_compute_gamma_cats(alpha, R, rates, PLL_GAMMA_RATES_MEAN) [3P] (src/PhyloHMM.cpp:360):
+    means of R equiprobable categories of Gamma(shape alpha, rate alpha)."""
+    from scipy.special import gammainc, gammaincinv
+    if R == 1:
+        return np.array([1.0])
+    q = gammaincinv(alpha, np.arange(1, R) / R)          # alpha * quantile boundaries
+    cum = np.concatenate([[0.0], gammainc(alpha + 1.0, q), [1.0]])
+    return R * np.diff(cum)
+
+
+def gtr_pmatrices(er, pi, rates, brlens):
+    """Per-branch, per-rate P = exp(Q t r) for GTR (Q_ij = er_ij pi_j, mean rate 1) [3P].
+    Returns array [len(brlens), R, 4, 4]."""
+    pi = np.asarray(pi, dtype=float)
+    S = np.zeros((4, 4))
+    k = 0
+    for i in range(4):
+        for j in range(i + 1, 4):
+            S[i, j] = S[j, i] = er[k]       # AC AG AT CG CT GT
+            k += 1
+    Q = S * pi[None, :]
+    np.fill_diagonal(Q, 0.0)
+    np.fill_diagonal(Q, -Q.sum(axis=1))
+    Q /= -np.sum(pi * np.diag(Q))
+    sq = np.sqrt(pi)
+    A = (sq[:, None] * Q) / sq[None, :]      # symmetric similarity transform
+    A = 0.5 * (A + A.T)
+    lam, W = np.linalg.eigh(A)
+    U = W / sq[:, None]
+    Uinv = W.T * sq[None, :]
+    brlens = np.asarray(brlens, dtype=float)
+    rates = np.asarray(rates, dtype=float)
+    ex = np.exp(lam[None, None, :] * brlens[:, None, None] * rates[None, :, None])   # [B,R,4]
+    return np.einsum("ik,brk,kj->brij", U, ex, Uinv)
+
+
+def per_site_loglik(tree, label_to_row, tip_states, er, pi, rates):
+    """Partition::TraversalUpdate(root, FULL) + Partition::LogLikelihood(root, per_site) [3P]
+    (src/PhyloHMM.cpp:224-226).  tip_states: int array [n_labels, C] with values 0..3 or 4 (=N,
+    all-ones CLV).  Returns per-column log-likelihoods (C,).  The virtual root is the last inner
+    node (GetVirtualRoot); by reversibility its placement does not change the result."""
+    T = tree.n_tips
+    C = tip_states.shape[1]
+    R = len(rates)
+    pi = np.asarray(pi, dtype=float)
+    root = len(tree.adj) - 1
+    # gather branch list via DFS from root
+    order = []          # (node, parent, brlen) in pre-order
+    stack = [(root, -1, 0.0)]
+    while stack:
+        node, par, bl = stack.pop()
+        order.append((node, par, bl))
+        for nb, l in tree.adj[node]:
+            if nb != par:
+                stack.append((nb, node, l))
+    brl = [bl for (_, par, bl) in order if par >= 0]
+    nodes_with_branch = [node for (node, par, _) in order if par >= 0]
+    P = gtr_pmatrices(er, pi, rates, brl)
+    Pof = {node: P[i] for i, node in enumerate(nodes_with_branch)}
+    clv = {}
+    scal = {}
+    onehot = np.concatenate([np.eye(4), np.ones((1, 4))], axis=0)     # state 4 (N) -> 1111
+    for node, par, _ in reversed(order):
+        if node < T:
+            st = tip_states[label_to_row[tree.labels[node]]]
+            v = onehot[st].T                                          # [4, C]
+            clv[node] = np.broadcast_to(v[None], (R, 4, C)).copy()
+            scal[node] = np.zeros(C, dtype=np.int64)
+        else:
+            acc = np.ones((R, 4, C))
+            sc = np.zeros(C, dtype=np.int64)
+            for nb, _l in tree.adj[node]:
+                if nb != par:
+                    acc *= np.einsum("rij,rjc->ric", Pof[nb], clv[nb])
+                    sc += scal[nb]
+            mx = acc.max(axis=(0, 1))
+            need = (mx < SCALE_THRESHOLD) & (mx > 0)
+            if need.any():
+                acc[:, :, need] *= SCALE_FACTOR
+                sc = sc + need.astype(np.int64)
+            clv[node] = acc
+            scal[node] = sc
+    site = np.einsum("i,ric->c", pi, clv[root]) / R
+    with np.errstate(divide="ignore"):
+        return np.log(site) - scal[root] * LOG_SCALE_FACTOR
+
+
+# --------------------------------------------------------------------------------------------
+# PhyloHMM  (src/PhyloHMM.cpp)
+# --------------------------------------------------------------------------------------------
+
+def store_xmsa_index(key, xmsa_ids):
+    """src/PhyloHMM.cpp:523-536"""
+    if key not in xmsa_ids:
+        xmsa_ids[key] = len(xmsa_ids)
+    return xmsa_ids[key]
+
+
+class PhyloHMM(HMM):
+    def __init__(self, yaml_path, cluster_ind, hmm_param_dir, seed):
+        super().__init__(yaml_path, cluster_ind, hmm_param_dir, seed)
+        self._initialize_xmsa_structs()
+        self.tree = None
+
+    # src/PhyloHMM.cpp:45-89
+    def _initialize_xmsa_structs(self):
+        self.xmsa_labels = ["naive"] + [str(u) for u in self.cluster_data["unique_ids"]]
+        self.xmsa_naive_ind = 0
+        ids = {}
+        fb = self.flexbounds
+        self.vpadding_xmsa_inds = self._store_gp(self.vpadding, ids)
+        self.vgerm_xmsa_inds = self._store_gp(self.vgerm, ids)
+        if self.locus == "igh":
+            self.vd_junction_xmsa_inds = self._store_junction(self.vd_junction, fb["v_r"], fb["d_l"], ids)
+            self.dgerm_xmsa_inds = self._store_gp(self.dgerm, ids)
+            self.dj_junction_xmsa_inds = self._store_junction(self.dj_junction, fb["d_r"], fb["j_l"], ids)
+        else:
+            self.vd_junction_xmsa_inds = self._store_junction(self.vd_junction, fb["v_r"], fb["j_l"], ids)
+            self.dgerm_xmsa_inds = np.zeros(0, dtype=np.int32)
+            self.dj_junction_xmsa_inds = np.zeros((0, 0), dtype=np.int32)
+        self.jgerm_xmsa_inds = self._store_gp(self.jgerm, ids)
+        self.jpadding_xmsa_inds = self._store_gp(self.jpadding, ids)
+        # BuildXmsa, src/PhyloHMM.cpp:123-144
+        n = self.msa.shape[0]
+        self.xmsa = np.full((n + 1, len(ids)), -1, dtype=np.int32)
+        for (naive_base, msa_ind), xi in ids.items():
+            self.xmsa[0, xi] = naive_base
+            self.xmsa[1:, xi] = self.msa[:, msa_ind]
+        self.xmsa_seqs = ["".join(self.alphabet[b] for b in row) for row in self.xmsa]
+        self.xmsa_ids = ids
+
+    # src/PhyloHMM.cpp:461-471
+    def _store_gp(self, R, ids):
+        return np.array([store_xmsa_index((R.naive_bases[i], R.site_inds[i]), ids)
+                         for i in range(len(R.naive_bases))], dtype=np.int32)
+
+    # src/PhyloHMM.cpp:489-513
+    def _store_junction(self, R, left_fb, right_fb, ids):
+        site_start, site_end = left_fb[0], right_fb[1]
+        M = np.full((site_end - site_start, len(R.naive_bases)), -1, dtype=np.int32)
+        for i in range(len(R.naive_bases)):
+            if R.site_inds[i] == -1:
+                for site in range(site_start, site_end):
+                    M[site - site_start, i] = store_xmsa_index((R.naive_bases[i], site), ids)
+            else:
+                M[R.site_inds[i] - site_start, i] = store_xmsa_index((R.naive_bases[i], R.site_inds[i]), ids)
+        return M
+
+    # src/PhyloHMM.cpp:350-361
+    def initialize_phylo_parameters(self, newick, er, pi, alpha, num_rates, is_path=True):
+        if is_path:
+            with open(newick) as f:
+                newick = f.read()
+        self.tree = parse_newick(newick, EPS)
+        self.er = list(er)
+        self.pi = list(pi)
+        self.alpha = alpha
+        self.sr = gamma_rates_mean(alpha, num_rates)
+
+    # src/PhyloHMM.cpp:366-383
+    def initialize_phylo_emission(self):
+        self.vgerm_scaler_count = 0
+        self.dgerm_scaler_count = 0
+        self.jgerm_scaler_count = 0
+        self._fill_xmsa_emission()
+        self._initialize_emission()
+        self.cache_forward = True
+
+    # src/PhyloHMM.cpp:220-238
+    def _fill_xmsa_emission(self):
+        rows = {lab: i for i, lab in enumerate(self.xmsa_labels)}
+        lnl = per_site_loglik(self.tree, rows, self.xmsa, self.er, self.pi, self.sr)
+        N = len(self.alphabet) - 1
+        for i in range(len(lnl)):
+            if self.xmsa[self.xmsa_naive_ind, i] != N:
+                lnl[i] -= math.log(self.pi[self.xmsa[self.xmsa_naive_ind, i]])
+        self.xmsa_emission = np.exp(lnl)
+
+    # src/PhyloHMM.cpp:94-114
+    def _initialize_emission(self):
+        self.vpadding_emission, c = self._fill_gp(self.vpadding, self.vpadding_xmsa_inds)
+        self.vgerm_scaler_count += c
+        self.vgerm_emission, c = self._fill_gp(self.vgerm, self.vgerm_xmsa_inds)
+        self.vgerm_scaler_count += c
+        self.vd_junction_emission = self._fill_junction(self.vd_junction_xmsa_inds)
+        if self.locus == "igh":
+            self.dgerm_emission, c = self._fill_gp(self.dgerm, self.dgerm_xmsa_inds)
+            self.dgerm_scaler_count += c
+            self.dj_junction_emission = self._fill_junction(self.dj_junction_xmsa_inds)
+        self.jgerm_emission, c = self._fill_gp(self.jgerm, self.jgerm_xmsa_inds)
+        self.jgerm_scaler_count += c
+        self.jpadding_emission, c = self._fill_gp(self.jpadding, self.jpadding_xmsa_inds)
+        self.jgerm_scaler_count += c
+
+    # src/PhyloHMM.cpp:158-193
+    def _fill_gp(self, R, inds):
+        names = sorted(R.ggene_ranges)
+        em = np.ones(len(names))
+        counts = [0] * len(names)
+        for i, gname in enumerate(names):
+            rs, re_ = R.ggene_ranges[gname]
+            v = 1.0
+            c = 0
+            for j in range(rs, re_):
+                v *= self.xmsa_emission[inds[j]]
+                while 0 < v < SCALE_THRESHOLD:
+                    v *= SCALE_FACTOR
+                    c += 1
+            em[i] = v
+            counts[i] = c
+        mx = max(counts) if counts else 0
+        for i in range(len(em)):
+            d = mx - counts[i]
+            em[i] *= math.pow(SCALE_FACTOR, d) if d < 4 else math.inf
+        return em, mx
+
+    # src/PhyloHMM.cpp:202-215
+    def _fill_junction(self, inds):
+        E = np.zeros(inds.shape)
+        mask = inds != -1
+        E[mask] = self.xmsa_emission[inds[mask]]
+        return E
+
+
+def phylo_loglik(yaml_path, hmm_param_dir, newick, er, pi, alpha, num_rates, cluster_ind=0, seed=0,
+                 is_path=True):
+    h = PhyloHMM(yaml_path, cluster_ind, hmm_param_dir, seed)
+    h.initialize_phylo_parameters(newick, er, pi, alpha, num_rates, is_path=is_path)
+    h.initialize_phylo_emission()
+    return h.log_likelihood(), h
