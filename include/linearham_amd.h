@@ -1,0 +1,152 @@
+/* linearham_amd.h -- C ABI of the MI355X phylo-HMM log-likelihood hot path.
+ *
+ * This is the drop-in boundary for linearham's per-tree-sample evaluation.  The reference has no
+ * FFI layer; the seam these entry points replace is the libptpll `pt::pll::Partition` interface
+ * plus the forward-pass free functions, as called from PhyloHMM/HMM member functions
+ * (citations are file:line into matsengrp/linearham):
+ *
+ *   lh_family_create      <- PhyloHMM::InitializeXmsaStructs (src/PhyloHMM.cpp:45-89) +
+ *                            HMM::InitializeTransition (src/HMM.cpp:190-246): everything that is
+ *                            constant for one clonal family, uploaded once.
+ *   lh_schedule_tree      <- pt::pll::GetVirtualRoot + the traversal order built inside
+ *                            Partition::TraversalUpdate(root, FULL) (src/PhyloHMM.cpp:224-225).
+ *   lh_eval_batch[_device]<- pll_compute_gamma_cats (src/PhyloHMM.cpp:425-426) +
+ *                            PhyloHMM::InitializePhyloEmission (src/PhyloHMM.cpp:366-383: Partition
+ *                            ctor, TraversalUpdate, LogLikelihood, naive correction, exp, the five
+ *                            FillGermlinePaddingEmission and two FillJunctionEmission calls) +
+ *                            HMM::LogLikelihood / RunForwardAlgorithm (src/HMM.cpp:254-287,345-354),
+ *                            for a whole batch of RevBayes tree samples at once.
+ *   lh_forward_batch      <- HMM::LogLikelihood on caller-supplied emissions (SimpleHMM,
+ *                            src/SimpleHMM.cpp:26-39 + src/HMM.cpp:345-354).
+ *
+ * All functions return 0 on success and a nonzero status otherwise; lh_last_error() gives the
+ * message (the C++ host wrapper turns it into std::runtime_error, mirroring
+ * src/linearham.cpp:447-454).  Plain pointers and sizes only.  A handle is bound to the HIP device
+ * that was current at lh_family_create and must be used by one host thread at a time.
+ */
+#ifndef LINEARHAM_AMD_H_
+#define LINEARHAM_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LH_ABI_VERSION 1
+
+typedef struct lh_family lh_family; /* opaque: device-resident family constants + workspaces */
+
+/* One running product per gene over its xMSA columns
+ * (PhyloHMM::FillGermlinePaddingEmission, src/PhyloHMM.cpp:158-193).  Genes are in std::map
+ * (sorted gene name) order, as `*_ggene_ranges_` is iterated (src/PhyloHMM.cpp:169). */
+typedef struct {
+  int32_t n_genes;
+  const int32_t* offsets;   /* [n_genes + 1] into xmsa_inds */
+  const int32_t* xmsa_inds; /* [offsets[n_genes]] */
+} lh_segments;
+
+/* One junction region (V-D, D-J or V-J) in structured form: exactly the nonzero pattern that
+ * FillTransition (src/HMM.cpp:964-1089) writes into the dense germline->junction, junction->junction
+ * and junction->germline matrices, indexed by (row = junction site, gene).  "left" genes are the
+ * genes whose 3' end lies in the junction (V in V-D), "right" genes own the four NTI states and
+ * their 5' germline positions (D in V-D).  A zero/-1 entry means "no such state at this row". */
+typedef struct {
+  int32_t n_rows;            /* W = junction sites */
+  int32_t n_left;            /* nL */
+  int32_t n_right;           /* nR */
+  const double* enter_trans; /* [nL] transition[last germline-region idx] if a row-0 state exists */
+  const double* enter_lo;    /* [nL] landing_out[last germline-region idx] */
+  const double* left_trans;  /* [W][nL] transition[p-1] into the row-i state (row 0: 0) */
+  const double* left_lo;     /* [W][nL] landing_out[p] of the row-i state */
+  const int32_t* left_xmsa;  /* [W][nL] xMSA column of the row-i state, or -1 */
+  const double* right_gp_nli;/* [nR][4] gene_prob * nti_landing_in[b] */
+  const double* right_ntt;   /* [nR][4][4] nti_transition[b_from][b_to] */
+  const double* right_nlo;   /* [W][nR][4] nti_landing_out[b_from][q] of the row-i germline state */
+  const double* right_trans; /* [W][nR] transition[q-1] when rows i-1 and i both hold a state */
+  const double* right_gp_li; /* [W][nR] gene_prob * landing_in[q] of the row-i germline state */
+  const int32_t* right_xmsa; /* [W][nR] xMSA column of the row-i germline state, or -1 */
+  const int32_t* nti_xmsa;   /* [W][4]  xMSA column of NTI base b at row i */
+  const double* exit_nlo;    /* [nR][4] nti_landing_out[b][q0] * prod(in-region transitions) */
+  const double* exit_trans;  /* [nR]    transition[q0-1] * prod (0 if no last-row state) */
+  const double* exit_gp_li;  /* [nR]    gene_prob * landing_in[q0] * prod */
+} lh_junction;
+
+/* Everything that is constant for one clonal family (host pointers; copied to the device). */
+typedef struct {
+  int32_t abi_version;    /* LH_ABI_VERSION */
+  int32_t has_d;          /* 1: igh (V-D and D-J junctions); 0: igk/igl (single V-J junction in `vd`) */
+  int32_t n_seqs;         /* n: MSA rows = tips other than `naive` (0 => forward-only family) */
+  int32_t n_sites;        /* L: MSA columns */
+  const uint8_t* msa;     /* [n_seqs][L], A,C,G,T,N = 0..4 (HMM::msa_, src/HMM.cpp:71-83) */
+  int32_t n_xmsa;         /* C: xMSA columns */
+  const int32_t* xmsa_site;       /* [C] MSA site of each xMSA column */
+  const uint8_t* xmsa_naive_base; /* [C] naive base 0..4 of each xMSA column (xmsa_ row 0) */
+  lh_segments vpadding, vgerm, dgerm, jgerm, jpadding;
+  const double* vgerm_gene_prob;     /* [nV] */
+  const double* vpadding_transition; /* [nV] (HMM::vpadding_transition_) */
+  const double* vgerm_trans_prod;    /* [nV] prod transition[germ_ind_start ... ) (src/HMM.cpp:310-313) */
+  const double* jpadding_transition; /* [nJ] */
+  lh_junction vd, dj;
+} lh_family_desc;
+
+/* Optional per-sample outputs of an evaluation (any pointer may be NULL). Host pointers for
+ * lh_eval_batch / lh_forward_batch, device pointers for lh_eval_batch_device. */
+typedef struct {
+  double* rates;          /* [n][R]   discrete-Gamma category rates (PhyloHMM::sr_) */
+  double* xmsa_emission;  /* [n][C]   PhyloHMM::xmsa_emission_ */
+  double* forward;        /* [n][lh_forward_size()] compact forward arrays, see lh_forward_layout */
+  int32_t* scaler_counts; /* [n][lh_scaler_size()]  vgerm, vd rows..., dgerm, dj rows..., jgerm */
+} lh_eval_outputs;
+
+const char* lh_last_error(void);
+int lh_device_count(void);
+
+int lh_family_create(const lh_family_desc* desc, lh_family** out);
+void lh_family_destroy(lh_family* fam);
+
+/* Number of doubles / ints per sample in lh_eval_outputs.forward / .scaler_counts.
+ * forward layout: vgerm[nV] | vd rows i<W: left[nL], nti[nR][4], right[nR] | dgerm[nD] |
+ *                 dj rows likewise | jgerm[nJ]   (dgerm/dj absent when has_d == 0). */
+int64_t lh_forward_size(const lh_family* fam);
+int64_t lh_scaler_size(const lh_family* fam);
+
+/* Tree in rooted-at-naive form: tips are nodes 0..T-1 (0 = `naive`, i = MSA row i-1), inner nodes
+ * T..2T-3.  children[2*(v-T)+{0,1}] are the two children of inner node v when the tree is rooted at
+ * `root`, the inner node adjacent to `naive`.  Writes the kernel's post-order schedule:
+ * ops[4*k+{0..3}] for k < T-2 (the last op computes the root).  *max_depth receives the number of
+ * stack slots the schedule needs.  Pure host integer work. */
+int lh_schedule_tree(int32_t n_tips, const int32_t* children, int32_t root, int32_t* ops,
+                     int32_t* max_depth);
+
+/* Evaluate n tree samples (host pointers).
+ *   ops    [n][T-2][4]  schedules from lh_schedule_tree
+ *   brlen  [n][2T-2]    branch length above each node (root entry ignored)
+ *   er [n][6] (AC,AG,AT,CG,CT,GT), pi [n][4], alpha [n]; num_rates = R
+ *   loglik [n]          HMM::LogLikelihood() per sample */
+int lh_eval_batch(lh_family* fam, int32_t n, int32_t n_tips, int32_t max_depth, const int32_t* ops,
+                  const double* brlen, const double* er, const double* pi, const double* alpha,
+                  int32_t num_rates, double* loglik, const lh_eval_outputs* outs);
+
+/* Same with every array already resident on the handle's device; enqueued on `hip_stream`
+ * (a hipStream_t, NULL = default stream) without synchronising. */
+int lh_eval_batch_device(lh_family* fam, int32_t n, int32_t n_tips, int32_t max_depth,
+                         const int32_t* ops, const double* brlen, const double* er, const double* pi,
+                         const double* alpha, int32_t num_rates, double* loglik,
+                         const lh_eval_outputs* outs, void* hip_stream);
+
+/* Forward pass only, on caller-supplied per-column emissions em[n][C] (host pointers). */
+int lh_forward_batch(lh_family* fam, int32_t n, const double* em, double* loglik,
+                     const lh_eval_outputs* outs);
+
+/* Timing of the kernels of the last lh_eval_batch_device call sequence, measured with HIP events
+ * on the launch stream when enabled (ms per kernel family: model, prune, forward). */
+int lh_profile_enable(lh_family* fam, int enable);
+int lh_profile_read(lh_family* fam, double* ms_model, double* ms_prune, double* ms_forward,
+                    int64_t* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINEARHAM_AMD_H_ */

@@ -1,0 +1,583 @@
+// C ABI of liblinearham_hip.so (see include/linearham_amd.h): family upload, tree scheduling,
+// batched evaluation.  Host-side code only; the kernels live in lh_model/lh_prune/lh_forward.hip.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lh_device.h"
+
+namespace lh {
+size_t forward_lds_bytes(const DevFamily& fam, int max_left, int max_right);
+}
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(const std::string& msg) {
+  g_error = msg;
+  return 1;
+}
+
+#define LH_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+  } while (0)
+
+struct Workspace {
+  int n_cap = 0, R = 0, T = 0;
+  double *rates = nullptr, *eig = nullptr, *pmat = nullptr, *tipvec = nullptr, *site_lik = nullptr,
+         *em = nullptr;
+  int32_t* site_scal = nullptr;
+};
+
+struct Staging {  // device copies of host inputs/outputs for the host-pointer entry points
+  size_t cap[10] = {0};
+  void* ptr[10] = {nullptr};
+};
+
+struct EventSet {
+  hipEvent_t e[4];
+};
+
+}  // namespace
+
+struct lh_family {
+  int device = 0;
+  lh::DevFamily host{};            // device pointers inside
+  lh::DevFamily* dev = nullptr;    // device copy of `host`
+  std::vector<void*> allocs;
+  Workspace ws;
+  Staging st;
+  bool profile = false;
+  std::vector<EventSet> events;
+  double ms[3] = {0, 0, 0};
+  int64_t launches = 0;
+};
+
+namespace {
+
+template <typename T>
+int upload(lh_family* f, const T* src, size_t count, const T** dst) {
+  *dst = nullptr;
+  if (count == 0) {
+    // keep a valid (dummy) pointer so kernels may form addresses
+    void* p = nullptr;
+    LH_HIP(hipMalloc(&p, 16));
+    f->allocs.push_back(p);
+    *dst = static_cast<const T*>(p);
+    return 0;
+  }
+  if (!src) return fail("lh_family_create: null array in descriptor");
+  void* p = nullptr;
+  LH_HIP(hipMalloc(&p, count * sizeof(T)));
+  f->allocs.push_back(p);
+  LH_HIP(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  *dst = static_cast<const T*>(p);
+  return 0;
+}
+
+int upload_segments(lh_family* f, const lh_segments& s, int n_xmsa, lh::DevSegments* d) {
+  if (s.n_genes < 0) return fail("segments: negative gene count");
+  d->n_genes = s.n_genes;
+  if (s.n_genes > 0) {
+    if (!s.offsets) return fail("segments: null offsets");
+    if (s.offsets[0] != 0) return fail("segments: offsets[0] != 0");
+    for (int g = 0; g < s.n_genes; ++g)
+      if (s.offsets[g + 1] < s.offsets[g]) return fail("segments: offsets not monotone");
+    const int total = s.offsets[s.n_genes];
+    for (int j = 0; j < total; ++j)
+      if (s.xmsa_inds[j] < 0 || s.xmsa_inds[j] >= n_xmsa) return fail("segments: xMSA index out of range");
+    if (upload(f, s.offsets, (size_t)s.n_genes + 1, &d->offsets)) return 1;
+    if (upload(f, s.xmsa_inds, (size_t)total, &d->xmsa_inds)) return 1;
+  } else {
+    const int32_t zero = 0;
+    if (upload(f, &zero, 1, &d->offsets)) return 1;
+    if (upload<int32_t>(f, nullptr, 0, &d->xmsa_inds)) return 1;
+  }
+  return 0;
+}
+
+int check_idx(const int32_t* a, size_t n, int n_xmsa, bool allow_neg, const char* what) {
+  for (size_t i = 0; i < n; ++i)
+    if (a[i] >= n_xmsa || (a[i] < 0 && !(allow_neg && a[i] == -1)))
+      return fail(std::string("junction: xMSA index out of range in ") + what);
+  return 0;
+}
+
+int upload_junction(lh_family* f, const lh_junction& j, int n_xmsa, lh::DevJunction* d) {
+  const size_t W = j.n_rows, nL = j.n_left, nR = j.n_right;
+  if (j.n_rows < 1 || j.n_left < 0 || j.n_right < 0) return fail("junction: bad dimensions");
+  d->n_rows = j.n_rows;
+  d->n_left = j.n_left;
+  d->n_right = j.n_right;
+  if (check_idx(j.left_xmsa, W * nL, n_xmsa, true, "left_xmsa")) return 1;
+  if (check_idx(j.right_xmsa, W * nR, n_xmsa, true, "right_xmsa")) return 1;
+  if (check_idx(j.nti_xmsa, W * 4, n_xmsa, nR == 0, "nti_xmsa")) return 1;
+  if (upload(f, j.enter_trans, nL, &d->enter_trans)) return 1;
+  if (upload(f, j.enter_lo, nL, &d->enter_lo)) return 1;
+  if (upload(f, j.left_trans, W * nL, &d->left_trans)) return 1;
+  if (upload(f, j.left_lo, W * nL, &d->left_lo)) return 1;
+  if (upload(f, j.left_xmsa, W * nL, &d->left_xmsa)) return 1;
+  if (upload(f, j.right_gp_nli, nR * 4, &d->right_gp_nli)) return 1;
+  if (upload(f, j.right_ntt, nR * 16, &d->right_ntt)) return 1;
+  if (upload(f, j.right_nlo, W * nR * 4, &d->right_nlo)) return 1;
+  if (upload(f, j.right_trans, W * nR, &d->right_trans)) return 1;
+  if (upload(f, j.right_gp_li, W * nR, &d->right_gp_li)) return 1;
+  if (upload(f, j.right_xmsa, W * nR, &d->right_xmsa)) return 1;
+  if (upload(f, j.nti_xmsa, W * 4, &d->nti_xmsa)) return 1;
+  if (upload(f, j.exit_nlo, nR * 4, &d->exit_nlo)) return 1;
+  if (upload(f, j.exit_trans, nR, &d->exit_trans)) return 1;
+  if (upload(f, j.exit_gp_li, nR, &d->exit_gp_li)) return 1;
+  return 0;
+}
+
+int ensure_workspace(lh_family* f, int n, int R, int T) {
+  Workspace& w = f->ws;
+  if (n <= w.n_cap && R == w.R && T == w.T) return 0;
+  void** bufs[] = {(void**)&w.rates, (void**)&w.eig,       (void**)&w.pmat, (void**)&w.tipvec,
+                   (void**)&w.site_lik, (void**)&w.em, (void**)&w.site_scal};
+  for (void** b : bufs) {
+    if (*b) LH_HIP(hipFree(*b));
+    *b = nullptr;
+  }
+  w.n_cap = 0;
+  const size_t L = f->host.n_sites, C = f->host.n_xmsa;
+  const int cap = std::max(n, 1);
+  LH_HIP(hipMalloc((void**)&w.rates, sizeof(double) * cap * R));
+  LH_HIP(hipMalloc((void**)&w.eig, sizeof(double) * cap * 36));
+  LH_HIP(hipMalloc((void**)&w.pmat, sizeof(double) * cap * R * (size_t)std::max(T - 2, 1) * 16));
+  LH_HIP(hipMalloc((void**)&w.tipvec, sizeof(double) * cap * R * (size_t)T * 20));
+  LH_HIP(hipMalloc((void**)&w.site_lik, sizeof(double) * cap * R * 5 * std::max(L, (size_t)1)));
+  LH_HIP(hipMalloc((void**)&w.site_scal, sizeof(int32_t) * cap * R * std::max(L, (size_t)1)));
+  LH_HIP(hipMalloc((void**)&w.em, sizeof(double) * cap * std::max(C, (size_t)1)));
+  w.n_cap = cap;
+  w.R = R;
+  w.T = T;
+  return 0;
+}
+
+int stage(lh_family* f, int slot, size_t bytes, void** out) {
+  Staging& s = f->st;
+  if (bytes > s.cap[slot]) {
+    if (s.ptr[slot]) LH_HIP(hipFree(s.ptr[slot]));
+    s.ptr[slot] = nullptr;
+    s.cap[slot] = 0;
+    LH_HIP(hipMalloc(&s.ptr[slot], bytes));
+    s.cap[slot] = bytes;
+  }
+  *out = s.ptr[slot];
+  return 0;
+}
+
+constexpr int kChunk = 8192;  // samples per launch group (bounds the workspace)
+
+int run_forward(lh_family* f, int n, const double* em_dev, double* loglik_dev, const lh_eval_outputs* outs,
+                size_t sample_offset, hipStream_t stream) {
+  double* fwd = (outs && outs->forward) ? outs->forward + sample_offset * f->host.forward_size : nullptr;
+  int32_t* sco =
+      (outs && outs->scaler_counts) ? outs->scaler_counts + sample_offset * f->host.scaler_size : nullptr;
+  lh::launch_forward(f->dev, f->host, n, em_dev, loglik_dev, fwd, sco, stream);
+  LH_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lh_last_error(void) { return g_error.c_str(); }
+
+int lh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int lh_family_create(const lh_family_desc* desc, lh_family** out) {
+  if (!desc || !out) return fail("lh_family_create: null argument");
+  *out = nullptr;
+  if (desc->abi_version != LH_ABI_VERSION) return fail("lh_family_create: ABI version mismatch");
+  if (lh_device_count() < 1)
+    return fail("lh_family_create: no HIP device available (this library has no CPU path)");
+  if (desc->n_xmsa < 1) return fail("lh_family_create: n_xmsa must be >= 1");
+  if (desc->n_seqs < 0 || desc->n_sites < 0) return fail("lh_family_create: negative dimension");
+  lh_family* f = new lh_family();
+  if (hipGetDevice(&f->device) != hipSuccess) {
+    delete f;
+    return fail("hipGetDevice failed");
+  }
+  lh::DevFamily& h = f->host;
+  h.has_d = desc->has_d ? 1 : 0;
+  h.n_seqs = desc->n_seqs;
+  h.n_sites = desc->n_sites;
+  h.n_xmsa = desc->n_xmsa;
+  int rc = 0;
+  const size_t C = desc->n_xmsa;
+  if (desc->n_seqs > 0) {
+    for (size_t i = 0; i < (size_t)desc->n_seqs * desc->n_sites && !rc; ++i)
+      if (desc->msa[i] > 4) rc = fail("lh_family_create: msa value out of range");
+    for (size_t c = 0; c < C && !rc; ++c)
+      if (desc->xmsa_site[c] < 0 || desc->xmsa_site[c] >= desc->n_sites || desc->xmsa_naive_base[c] > 4)
+        rc = fail("lh_family_create: xMSA column descriptor out of range");
+    rc = rc || upload(f, desc->msa, (size_t)desc->n_seqs * desc->n_sites, &h.msa);
+    rc = rc || upload(f, desc->xmsa_site, C, &h.xmsa_site);
+    rc = rc || upload(f, desc->xmsa_naive_base, C, &h.xmsa_naive_base);
+  } else {
+    rc = rc || upload<uint8_t>(f, nullptr, 0, &h.msa);
+    rc = rc || upload<int32_t>(f, nullptr, 0, &h.xmsa_site);
+    rc = rc || upload<uint8_t>(f, nullptr, 0, &h.xmsa_naive_base);
+  }
+  rc = rc || upload_segments(f, desc->vpadding, desc->n_xmsa, &h.vpadding);
+  rc = rc || upload_segments(f, desc->vgerm, desc->n_xmsa, &h.vgerm);
+  rc = rc || upload_segments(f, desc->jgerm, desc->n_xmsa, &h.jgerm);
+  rc = rc || upload_segments(f, desc->jpadding, desc->n_xmsa, &h.jpadding);
+  const size_t nV = desc->vgerm.n_genes, nJ = desc->jgerm.n_genes;
+  if (!rc && (desc->vpadding.n_genes != (int)nV || desc->jpadding.n_genes != (int)nJ))
+    rc = fail("lh_family_create: padding/germline gene counts differ");
+  rc = rc || upload(f, desc->vgerm_gene_prob, nV, &h.vgerm_gene_prob);
+  rc = rc || upload(f, desc->vpadding_transition, nV, &h.vpadding_transition);
+  rc = rc || upload(f, desc->vgerm_trans_prod, nV, &h.vgerm_trans_prod);
+  rc = rc || upload(f, desc->jpadding_transition, nJ, &h.jpadding_transition);
+  rc = rc || upload_junction(f, desc->vd, desc->n_xmsa, &h.vd);
+  if (!rc && desc->vd.n_left != (int)nV) rc = fail("lh_family_create: vd.n_left != number of V genes");
+  if (h.has_d) {
+    rc = rc || upload_segments(f, desc->dgerm, desc->n_xmsa, &h.dgerm);
+    rc = rc || upload_junction(f, desc->dj, desc->n_xmsa, &h.dj);
+    if (!rc && (desc->vd.n_right != desc->dgerm.n_genes || desc->dj.n_left != desc->dgerm.n_genes ||
+                desc->dj.n_right != (int)nJ))
+      rc = fail("lh_family_create: junction gene counts do not match the germline regions");
+  } else {
+    lh_segments empty{0, nullptr, nullptr};
+    rc = rc || upload_segments(f, empty, desc->n_xmsa, &h.dgerm);
+    memset(&h.dj, 0, sizeof(h.dj));
+    if (!rc && desc->vd.n_right != (int)nJ) rc = fail("lh_family_create: vd.n_right != number of J genes");
+  }
+  if (!rc) {
+    h.max_genes = std::max({(int)nV, (int)nJ, h.dgerm.n_genes, 1});
+    h.forward_size = (int64_t)nV + (int64_t)h.vd.n_rows * (h.vd.n_left + 5 * (int64_t)h.vd.n_right) + nJ;
+    h.scaler_size = 1 + h.vd.n_rows + 1;
+    if (h.has_d) {
+      h.forward_size += h.dgerm.n_genes + (int64_t)h.dj.n_rows * (h.dj.n_left + 5 * (int64_t)h.dj.n_right);
+      h.scaler_size += h.dj.n_rows + 1;
+    }
+    int ml = h.vd.n_left, mr = h.vd.n_right;
+    if (h.has_d) {
+      ml = std::max(ml, h.dj.n_left);
+      mr = std::max(mr, h.dj.n_right);
+    }
+    if (lh::forward_lds_bytes(h, ml, mr) > 160 * 1024)
+      rc = fail("lh_family_create: family too large for the forward kernel's LDS working set");
+  }
+  if (!rc) {
+    void* p = nullptr;
+    if (hipMalloc(&p, sizeof(lh::DevFamily)) != hipSuccess ||
+        hipMemcpy(p, &h, sizeof(lh::DevFamily), hipMemcpyHostToDevice) != hipSuccess)
+      rc = fail("lh_family_create: device allocation failed");
+    else {
+      f->dev = static_cast<lh::DevFamily*>(p);
+      f->allocs.push_back(p);
+    }
+  }
+  if (rc) {
+    std::string keep = g_error;
+    lh_family_destroy(f);
+    g_error = keep;
+    return 1;
+  }
+  *out = f;
+  return 0;
+}
+
+void lh_family_destroy(lh_family* f) {
+  if (!f) return;
+  for (void* p : f->allocs) (void)hipFree(p);
+  Workspace& w = f->ws;
+  void* bufs[] = {w.rates, w.eig, w.pmat, w.tipvec, w.site_lik, w.em, w.site_scal};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  for (void* p : f->st.ptr)
+    if (p) (void)hipFree(p);
+  for (EventSet& es : f->events)
+    for (hipEvent_t e : es.e) (void)hipEventDestroy(e);
+  delete f;
+}
+
+int64_t lh_forward_size(const lh_family* f) { return f ? f->host.forward_size : 0; }
+int64_t lh_scaler_size(const lh_family* f) { return f ? f->host.scaler_size : 0; }
+
+int lh_schedule_tree(int32_t T, const int32_t* children, int32_t root, int32_t* ops, int32_t* max_depth) {
+  if (T < 3) return fail("lh_schedule_tree: need at least 3 tips (naive + 2 sequences)");
+  const int n_nodes = 2 * T - 2, I = T - 2;
+  if (!children || !ops) return fail("lh_schedule_tree: null argument");
+  if (root < T || root >= n_nodes) return fail("lh_schedule_tree: root must be an inner node");
+  // validate: every node except root and tip 0 (naive) appears exactly once as a child
+  std::vector<int> seen(n_nodes, 0);
+  for (int i = 0; i < 2 * I; ++i) {
+    const int c = children[i];
+    if (c < 1 || c >= n_nodes) return fail("lh_schedule_tree: child id out of range");
+    if (seen[c]++) return fail("lh_schedule_tree: node appears twice as a child");
+  }
+  if (seen[root]) return fail("lh_schedule_tree: root appears as a child");
+  for (int v = 1; v < n_nodes; ++v)
+    if (v != root && !seen[v]) return fail("lh_schedule_tree: node is not attached to the tree");
+  // subtree tip counts + acyclicity (iterative post-order from root)
+  std::vector<int> size(n_nodes, 0), order;
+  order.reserve(I);
+  {
+    std::vector<int> stack{root};
+    std::vector<char> visited(n_nodes, 0);
+    while (!stack.empty()) {
+      const int v = stack.back();
+      stack.pop_back();
+      if (visited[v]) return fail("lh_schedule_tree: cycle in children array");
+      visited[v] = 1;
+      if (v >= T) {
+        order.push_back(v);
+        stack.push_back(children[2 * (v - T)]);
+        stack.push_back(children[2 * (v - T) + 1]);
+      }
+    }
+    if ((int)order.size() != I) return fail("lh_schedule_tree: tree does not span all inner nodes");
+    for (int k = I - 1; k >= 0; --k) {
+      const int v = order[k];
+      const int a = children[2 * (v - T)], b = children[2 * (v - T) + 1];
+      size[v] = (a < T ? 1 : size[a]) + (b < T ? 1 : size[b]);
+    }
+  }
+  // emit ops: explicit stack of (node, phase)
+  struct Frame {
+    int v, phase, first, second;
+  };
+  std::vector<Frame> fs;
+  fs.push_back({root, 0, 0, 0});
+  int n_out = 0, depth = 0, maxd = 0;
+  bool acc_live = false;      // accumulator holds a result that a later op still needs
+  bool push_pending = false;  // the next cherry must push the accumulator first
+  while (!fs.empty()) {
+    Frame& fr = fs.back();
+    const int v = fr.v;
+    const int a = children[2 * (v - T)], b = children[2 * (v - T) + 1];
+    const bool ta = a < T, tb = b < T;
+    int32_t* op = ops + 4 * (size_t)n_out;
+    if (ta && tb) {
+      op[0] = lh::OP_CHERRY;
+      op[1] = a;
+      op[2] = b;
+      op[3] = 0;
+      if (push_pending) {
+        op[0] |= lh::OP_PUSH_FLAG;
+        op[3] = depth++;
+        maxd = std::max(maxd, depth);
+        push_pending = false;
+      }
+      ++n_out;
+      acc_live = true;
+      fs.pop_back();
+    } else if (ta != tb) {
+      const int tip = ta ? a : b, inner = ta ? b : a;
+      if (fr.phase == 0) {
+        fr.phase = 1;
+        fs.push_back({inner, 0, 0, 0});
+      } else {
+        op[0] = lh::OP_TIP_ACC;
+        op[1] = tip;
+        op[2] = inner;
+        op[3] = 0;
+        ++n_out;
+        fs.pop_back();
+      }
+    } else {
+      if (fr.phase == 0) {
+        fr.first = size[a] >= size[b] ? a : b;  // larger subtree first bounds the stack by log2(T)
+        fr.second = size[a] >= size[b] ? b : a;
+        fr.phase = 1;
+        const int first = fr.first;
+        fs.push_back({first, 0, 0, 0});
+      } else if (fr.phase == 1) {
+        fr.phase = 2;
+        push_pending = true;  // first op of the second subtree is a cherry: it pushes `first`
+        const int second = fr.second;
+        fs.push_back({second, 0, 0, 0});
+      } else {
+        op[0] = lh::OP_POP_ACC;
+        op[1] = fr.first;
+        op[2] = fr.second;
+        op[3] = --depth;
+        ++n_out;
+        fs.pop_back();
+      }
+    }
+  }
+  (void)acc_live;
+  if (n_out != I || depth != 0) return fail("lh_schedule_tree: internal scheduling error");
+  if (maxd > 16) return fail("lh_schedule_tree: tree needs more than 16 stack slots");
+  if (max_depth) *max_depth = maxd;
+  return 0;
+}
+
+int lh_profile_enable(lh_family* f, int enable) {
+  if (!f) return fail("null family");
+  f->profile = enable != 0;
+  return 0;
+}
+
+int lh_profile_read(lh_family* f, double* ms_model, double* ms_prune, double* ms_forward, int64_t* n_launches) {
+  if (!f) return fail("null family");
+  for (EventSet& es : f->events) {
+    LH_HIP(hipEventSynchronize(es.e[3]));
+    for (int k = 0; k < 3; ++k) {
+      float ms = 0;
+      LH_HIP(hipEventElapsedTime(&ms, es.e[k], es.e[k + 1]));
+      f->ms[k] += ms;
+    }
+    for (hipEvent_t e : es.e) (void)hipEventDestroy(e);
+    ++f->launches;
+  }
+  f->events.clear();
+  if (ms_model) *ms_model = f->ms[0];
+  if (ms_prune) *ms_prune = f->ms[1];
+  if (ms_forward) *ms_forward = f->ms[2];
+  if (n_launches) *n_launches = f->launches;
+  f->ms[0] = f->ms[1] = f->ms[2] = 0;
+  f->launches = 0;
+  return 0;
+}
+
+int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const int32_t* ops,
+                         const double* brlen, const double* er, const double* pi, const double* alpha,
+                         int32_t R, double* loglik, const lh_eval_outputs* outs, void* hip_stream) {
+  if (!f) return fail("lh_eval_batch: null family");
+  if (n < 0) return fail("lh_eval_batch: negative batch size");
+  if (n == 0) return 0;
+  if (f->host.n_seqs < 1) return fail("lh_eval_batch: family was created without an MSA (forward-only)");
+  if (T != f->host.n_seqs + 1) return fail("lh_eval_batch: n_tips must equal n_seqs + 1 (naive)");
+  if (T < 3) return fail("lh_eval_batch: need at least 3 tips");
+  if (R < 1 || R > 64) return fail("lh_eval_batch: num_rates out of range");
+  if (max_depth < 0 || max_depth > 16) return fail("lh_eval_batch: max_depth out of range");
+  if ((size_t)T * 160 > 160 * 1024) return fail("lh_eval_batch: too many tips for the LDS tip table");
+  if (!ops || !brlen || !er || !pi || !alpha || !loglik) return fail("lh_eval_batch: null array");
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const int chunk = std::min<int>(n, kChunk);
+  if (ensure_workspace(f, chunk, R, T)) return 1;
+  Workspace& w = f->ws;
+  const size_t nodes = 2 * (size_t)T - 2, n_ops = (size_t)T - 2, C = f->host.n_xmsa;
+  for (int off = 0; off < n; off += chunk) {
+    const int m = std::min(chunk, n - off);
+    EventSet es;
+    if (f->profile) {
+      for (hipEvent_t& e : es.e) LH_HIP(hipEventCreate(&e));
+      LH_HIP(hipEventRecord(es.e[0], stream));
+    }
+    double* rates = (outs && outs->rates) ? outs->rates + (size_t)off * R : w.rates;
+    double* em = (outs && outs->xmsa_emission) ? outs->xmsa_emission + (size_t)off * C : w.em;
+    lh::launch_model_setup(m, R, er + (size_t)off * 6, pi + (size_t)off * 4, alpha + off, rates, w.eig,
+                           stream);
+    lh::launch_pmatrices(m, R, T, brlen + (size_t)off * nodes, rates, w.eig, w.pmat, w.tipvec, stream);
+    if (f->profile) LH_HIP(hipEventRecord(es.e[1], stream));
+    lh::launch_prune(f->host, m, R, T, max_depth, ops + (size_t)off * n_ops * 4, w.pmat, w.tipvec,
+                     pi + (size_t)off * 4, w.site_lik, w.site_scal, stream);
+    if (f->profile) LH_HIP(hipEventRecord(es.e[2], stream));
+    lh::launch_xmsa_emission(f->host, m, R, w.site_lik, w.site_scal, pi + (size_t)off * 4, em, stream);
+    if (run_forward(f, m, em, loglik + off, outs, off, stream)) return 1;
+    if (f->profile) {
+      LH_HIP(hipEventRecord(es.e[3], stream));
+      f->events.push_back(es);
+    }
+    LH_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const int32_t* ops,
+                  const double* brlen, const double* er, const double* pi, const double* alpha, int32_t R,
+                  double* loglik, const lh_eval_outputs* outs) {
+  if (!f) return fail("lh_eval_batch: null family");
+  if (n <= 0) return n == 0 ? 0 : fail("lh_eval_batch: negative batch size");
+  if (T < 3) return fail("lh_eval_batch: need at least 3 tips");
+  if (!ops || !brlen || !er || !pi || !alpha || !loglik) return fail("lh_eval_batch: null array");
+  const size_t nodes = 2 * (size_t)T - 2, n_ops = (size_t)T - 2;
+  // host-side validation of the schedules (a malformed op would index out of bounds on the device)
+  for (size_t k = 0; k < (size_t)n * n_ops; ++k) {
+    const int32_t* op = ops + 4 * k;
+    const int kind = op[0] & 15;
+    const bool push = op[0] & lh::OP_PUSH_FLAG;
+    bool ok = (op[0] & ~31) == 0 && kind <= 2;
+    if (kind == lh::OP_CHERRY) ok = ok && op[1] >= 1 && op[1] < T && op[2] >= 1 && op[2] < T;
+    if (kind == lh::OP_TIP_ACC) ok = ok && !push && op[1] >= 1 && op[1] < T && op[2] >= T && op[2] < (int)nodes;
+    if (kind == lh::OP_POP_ACC)
+      ok = ok && !push && op[1] >= T && op[1] < (int)nodes && op[2] >= T && op[2] < (int)nodes;
+    if (push || kind == lh::OP_POP_ACC) ok = ok && op[3] >= 0 && op[3] < max_depth;
+    if (!ok) return fail("lh_eval_batch: malformed schedule op (use lh_schedule_tree)");
+  }
+  void *d_ops, *d_brlen, *d_er, *d_pi, *d_alpha, *d_ll;
+  if (stage(f, 0, sizeof(int32_t) * 4 * n_ops * n, &d_ops)) return 1;
+  if (stage(f, 1, sizeof(double) * nodes * n, &d_brlen)) return 1;
+  if (stage(f, 2, sizeof(double) * 6 * n, &d_er)) return 1;
+  if (stage(f, 3, sizeof(double) * 4 * n, &d_pi)) return 1;
+  if (stage(f, 4, sizeof(double) * n, &d_alpha)) return 1;
+  if (stage(f, 5, sizeof(double) * n, &d_ll)) return 1;
+  LH_HIP(hipMemcpy(d_ops, ops, sizeof(int32_t) * 4 * n_ops * n, hipMemcpyHostToDevice));
+  LH_HIP(hipMemcpy(d_brlen, brlen, sizeof(double) * nodes * n, hipMemcpyHostToDevice));
+  LH_HIP(hipMemcpy(d_er, er, sizeof(double) * 6 * n, hipMemcpyHostToDevice));
+  LH_HIP(hipMemcpy(d_pi, pi, sizeof(double) * 4 * n, hipMemcpyHostToDevice));
+  LH_HIP(hipMemcpy(d_alpha, alpha, sizeof(double) * n, hipMemcpyHostToDevice));
+  lh_eval_outputs d_outs{nullptr, nullptr, nullptr, nullptr};
+  const size_t C = f->host.n_xmsa, FS = f->host.forward_size, SS = f->host.scaler_size;
+  if (outs) {
+    if (outs->rates && stage(f, 6, sizeof(double) * R * n, (void**)&d_outs.rates)) return 1;
+    if (outs->xmsa_emission && stage(f, 7, sizeof(double) * C * n, (void**)&d_outs.xmsa_emission)) return 1;
+    if (outs->forward && stage(f, 8, sizeof(double) * FS * n, (void**)&d_outs.forward)) return 1;
+    if (outs->scaler_counts && stage(f, 9, sizeof(int32_t) * SS * n, (void**)&d_outs.scaler_counts)) return 1;
+  }
+  if (lh_eval_batch_device(f, n, T, max_depth, (const int32_t*)d_ops, (const double*)d_brlen,
+                           (const double*)d_er, (const double*)d_pi, (const double*)d_alpha, R, (double*)d_ll,
+                           &d_outs, nullptr))
+    return 1;
+  LH_HIP(hipDeviceSynchronize());
+  LH_HIP(hipMemcpy(loglik, d_ll, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (outs) {
+    if (outs->rates) LH_HIP(hipMemcpy(outs->rates, d_outs.rates, sizeof(double) * R * n, hipMemcpyDeviceToHost));
+    if (outs->xmsa_emission)
+      LH_HIP(hipMemcpy(outs->xmsa_emission, d_outs.xmsa_emission, sizeof(double) * C * n, hipMemcpyDeviceToHost));
+    if (outs->forward)
+      LH_HIP(hipMemcpy(outs->forward, d_outs.forward, sizeof(double) * FS * n, hipMemcpyDeviceToHost));
+    if (outs->scaler_counts)
+      LH_HIP(hipMemcpy(outs->scaler_counts, d_outs.scaler_counts, sizeof(int32_t) * SS * n,
+                       hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int lh_forward_batch(lh_family* f, int32_t n, const double* em, double* loglik, const lh_eval_outputs* outs) {
+  if (!f) return fail("lh_forward_batch: null family");
+  if (n <= 0) return n == 0 ? 0 : fail("lh_forward_batch: negative batch size");
+  if (!em || !loglik) return fail("lh_forward_batch: null array");
+  const size_t C = f->host.n_xmsa, FS = f->host.forward_size, SS = f->host.scaler_size;
+  void *d_em, *d_ll;
+  if (stage(f, 7, sizeof(double) * C * n, &d_em)) return 1;
+  if (stage(f, 5, sizeof(double) * n, &d_ll)) return 1;
+  LH_HIP(hipMemcpy(d_em, em, sizeof(double) * C * n, hipMemcpyHostToDevice));
+  lh_eval_outputs d_outs{nullptr, nullptr, nullptr, nullptr};
+  if (outs) {
+    if (outs->forward && stage(f, 8, sizeof(double) * FS * n, (void**)&d_outs.forward)) return 1;
+    if (outs->scaler_counts && stage(f, 9, sizeof(int32_t) * SS * n, (void**)&d_outs.scaler_counts)) return 1;
+  }
+  if (run_forward(f, n, (const double*)d_em, (double*)d_ll, &d_outs, 0, nullptr)) return 1;
+  LH_HIP(hipDeviceSynchronize());
+  LH_HIP(hipMemcpy(loglik, d_ll, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (outs) {
+    if (outs->forward)
+      LH_HIP(hipMemcpy(outs->forward, d_outs.forward, sizeof(double) * FS * n, hipMemcpyDeviceToHost));
+    if (outs->scaler_counts)
+      LH_HIP(hipMemcpy(outs->scaler_counts, d_outs.scaler_counts, sizeof(int32_t) * SS * n,
+                       hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+}  // extern "C"

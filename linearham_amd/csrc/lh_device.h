@@ -1,0 +1,72 @@
+// Internal declarations shared by the HIP translation units of liblinearham_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "linearham_amd.h"
+
+namespace lh {
+
+constexpr double kScaleFactor = 0x1p256;      // SCALE_FACTOR, src/utils.hpp:22
+constexpr double kScaleThreshold = 0x1p-256;  // SCALE_THRESHOLD, src/utils.hpp:24
+constexpr double kLogScaleFactor = 177.445678223345993274;  // log(2^256)
+
+// schedule op kinds (ops[4k] & 15); bit 4 = push the accumulator to stack slot ops[4k+3] first
+enum : int { OP_CHERRY = 0, OP_TIP_ACC = 1, OP_POP_ACC = 2, OP_PUSH_FLAG = 16 };
+
+// Device copy of lh_segments / lh_junction / family constants (all pointers are device pointers).
+struct DevSegments {
+  int32_t n_genes;
+  const int32_t* offsets;
+  const int32_t* xmsa_inds;
+};
+
+struct DevJunction {
+  int32_t n_rows, n_left, n_right;
+  const double *enter_trans, *enter_lo, *left_trans, *left_lo;
+  const int32_t* left_xmsa;
+  const double *right_gp_nli, *right_ntt, *right_nlo, *right_trans, *right_gp_li;
+  const int32_t *right_xmsa, *nti_xmsa;
+  const double *exit_nlo, *exit_trans, *exit_gp_li;
+};
+
+struct DevFamily {
+  int32_t has_d, n_seqs, n_sites, n_xmsa;
+  const uint8_t* msa;
+  const int32_t* xmsa_site;
+  const uint8_t* xmsa_naive_base;
+  DevSegments vpadding, vgerm, dgerm, jgerm, jpadding;
+  const double *vgerm_gene_prob, *vpadding_transition, *vgerm_trans_prod, *jpadding_transition;
+  DevJunction vd, dj;
+  int32_t max_genes;      // max over regions of the gene count (LDS sizing)
+  int64_t forward_size;   // doubles per sample in the compact forward output
+  int64_t scaler_size;    // ints per sample in the scaler-count output
+};
+
+// ---- kernel launchers (each enqueues on `stream`, no synchronisation) -------------------------
+
+// K0a: per sample: discrete-Gamma mean rates from alpha, GTR eigendecomposition.
+// eig layout per sample: lambda[4] | U[4][4] | Uinv[4][4]  (36 doubles)
+void launch_model_setup(int n, int R, const double* er, const double* pi, const double* alpha,
+                        double* rates, double* eig, hipStream_t stream);
+
+// K0b: per (sample, rate, node): P = U exp(lambda t r) Uinv for inner nodes -> pmat[n][R][I][16];
+// for tips -> tipvec[n][R][T][5][4] (column s of P for s<4, row sums for s == 4 (N)).
+void launch_pmatrices(int n, int R, int T, const double* brlen, const double* rates, const double* eig,
+                      double* pmat, double* tipvec, hipStream_t stream);
+
+// K1: Felsenstein pruning over the MSA sites with the naive tip factored out.
+// site_lik[n][R][5][L], site_scal[n][R][L]
+void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
+                  const double* pmat, const double* tipvec, const double* pi, double* site_lik,
+                  int32_t* site_scal, hipStream_t stream);
+
+// K2a: combine rate categories -> per-xMSA-column emission em[n][C] (FillXmsaEmission).
+void launch_xmsa_emission(const DevFamily& fam, int n, int R, const double* site_lik,
+                          const int32_t* site_scal, const double* pi, double* em, hipStream_t stream);
+
+// K2b: germline/padding emission products + scaled forward sweep -> loglik[n].
+void launch_forward(const DevFamily* fam_dev, const DevFamily& fam, int n, const double* em,
+                    double* loglik, double* forward_out, int32_t* scaler_out, hipStream_t stream);
+
+}  // namespace lh

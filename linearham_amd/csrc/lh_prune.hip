@@ -1,0 +1,201 @@
+// K1: Felsenstein pruning over the clonal tree for all alignment columns (gfx950).
+//
+// Replaces Partition::TraversalUpdate(root, FULL) + Partition::LogLikelihood(root, per_site)
+// (src/PhyloHMM.cpp:224-226; libpll's pll_update_partials / pll_compute_edge_loglikelihood [3P]).
+//
+// Design ("K1"):
+//  * The reference evaluates every xMSA column, i.e. every (naive base, MSA site) pair, as an
+//    independent alignment column.  All xMSA columns of one MSA site differ only in the state of
+//    the `naive` tip, so the tree is rooted at naive's neighbour: the CLV of that node is
+//    computed ONCE per MSA site and the five possible naive states (A,C,G,T,N) are closed in the
+//    epilogue with the naive branch's P-matrix.  By reversibility of GTR the result is the
+//    libpll value for every xMSA column.
+//  * One workgroup = (site tile, rate category, tree sample); one lane = one MSA site.  The
+//    traversal is a wave-uniform schedule (lh_schedule_tree): every lane executes the same op, so
+//    the 4x4 P-matrices of the op are wave-uniform and are fetched with scalar loads into SGPRs
+//    (no LDS / VGPR cost), and child CLVs never leave the chip: the running CLV lives in VGPRs
+//    and pending siblings live in a register-resident stack of statically indexed slots.
+//  * Tip children need no mat-vec: P * onehot(state) is a column of P.  Those columns (plus the
+//    row sums for N) are staged once per workgroup in LDS as tiptab[tip][state][4] and gathered
+//    with two ds_read_b128 per lane.
+//  * HBM traffic is therefore ~T bytes of tip states per site (L2-resident, shared by all samples)
+//    and 5 doubles out, instead of the 2*I*R*32 bytes per column of a CLV-streaming kernel.
+#include "lh_device.h"
+
+namespace lh {
+
+#define LH_STACK_CASE(d)        \
+  case d:                       \
+    s##d##_0 = a0;              \
+    s##d##_1 = a1;              \
+    s##d##_2 = a2;              \
+    s##d##_3 = a3;              \
+    break;
+#define LH_POP_CASE(d)          \
+  case d:                       \
+    y0 = s##d##_0;              \
+    y1 = s##d##_1;              \
+    y2 = s##d##_2;              \
+    y3 = s##d##_3;              \
+    break;
+#define LH_DECL_SLOT(d) double s##d##_0 = 0, s##d##_1 = 0, s##d##_2 = 0, s##d##_3 = 0;
+
+template <int kDepth>
+__global__ void __launch_bounds__(512)
+    prune_kernel(const uint8_t* __restrict__ msa, int L, int T, int n_ops,
+                 const int32_t* __restrict__ ops, const double* __restrict__ pmat,
+                 const double* __restrict__ tipvec, const double* __restrict__ pi,
+                 double* __restrict__ site_lik, int32_t* __restrict__ site_scal) {
+  extern __shared__ double2 smem2[];
+  double* tiptab = reinterpret_cast<double*>(smem2);  // [T][5][4]
+
+  const int tid = threadIdx.x;
+  const int R = gridDim.y;
+  const int rate = blockIdx.y;
+  const int sample = blockIdx.z;
+  const int site_raw = blockIdx.x * blockDim.x + tid;
+  const int site = site_raw < L ? site_raw : L - 1;
+
+  {  // stage this (sample, rate)'s tip table in LDS
+    const double2* src =
+        reinterpret_cast<const double2*>(tipvec + ((size_t)sample * R + rate) * (size_t)T * 20);
+    for (int i = tid; i < T * 10; i += blockDim.x) smem2[i] = src[i];
+  }
+  __syncthreads();
+
+  const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
+  const double* __restrict__ pm = pmat + ((size_t)sample * R + rate) * (size_t)(T - 2) * 16;
+  const uint8_t* __restrict__ msa_site = msa + site;
+
+  double a0 = 1.0, a1 = 1.0, a2 = 1.0, a3 = 1.0;
+  int scal = 0;
+  LH_DECL_SLOT(0) LH_DECL_SLOT(1) LH_DECL_SLOT(2) LH_DECL_SLOT(3)
+  LH_DECL_SLOT(4) LH_DECL_SLOT(5) LH_DECL_SLOT(6) LH_DECL_SLOT(7)
+  LH_DECL_SLOT(8) LH_DECL_SLOT(9) LH_DECL_SLOT(10) LH_DECL_SLOT(11)
+  LH_DECL_SLOT(12) LH_DECL_SLOT(13) LH_DECL_SLOT(14) LH_DECL_SLOT(15)
+
+  for (int k = 0; k < n_ops; ++k) {
+    const int4 op = op_ptr[k];
+    const int kind = op.x & 15;
+    if (op.x & OP_PUSH_FLAG) {
+      switch (op.w) {
+        LH_STACK_CASE(0) LH_STACK_CASE(1) LH_STACK_CASE(2) LH_STACK_CASE(3)
+        default:
+          if constexpr (kDepth > 4) {
+            switch (op.w) {
+              LH_STACK_CASE(4) LH_STACK_CASE(5) LH_STACK_CASE(6) LH_STACK_CASE(7)
+              default:
+                if constexpr (kDepth > 8) {
+                  switch (op.w) {
+                    LH_STACK_CASE(8) LH_STACK_CASE(9) LH_STACK_CASE(10) LH_STACK_CASE(11)
+                    LH_STACK_CASE(12) LH_STACK_CASE(13) LH_STACK_CASE(14) LH_STACK_CASE(15)
+                  }
+                }
+            }
+          }
+      }
+    }
+    if (kind == OP_CHERRY) {
+      const int sa = msa_site[(size_t)(op.y - 1) * L];
+      const int sb = msa_site[(size_t)(op.z - 1) * L];
+      const double2* ta = reinterpret_cast<const double2*>(tiptab + op.y * 20 + sa * 4);
+      const double2* tb = reinterpret_cast<const double2*>(tiptab + op.z * 20 + sb * 4);
+      const double2 ta0 = ta[0], ta1 = ta[1], tb0 = tb[0], tb1 = tb[1];
+      a0 = ta0.x * tb0.x;
+      a1 = ta0.y * tb0.y;
+      a2 = ta1.x * tb1.x;
+      a3 = ta1.y * tb1.y;
+    } else {
+      const double* __restrict__ pb = pm + (size_t)(op.z - T) * 16;
+      const double x0 = fma(pb[3], a3, fma(pb[2], a2, fma(pb[1], a1, pb[0] * a0)));
+      const double x1 = fma(pb[7], a3, fma(pb[6], a2, fma(pb[5], a1, pb[4] * a0)));
+      const double x2 = fma(pb[11], a3, fma(pb[10], a2, fma(pb[9], a1, pb[8] * a0)));
+      const double x3 = fma(pb[15], a3, fma(pb[14], a2, fma(pb[13], a1, pb[12] * a0)));
+      if (kind == OP_TIP_ACC) {
+        const int sa = msa_site[(size_t)(op.y - 1) * L];
+        const double2* ta = reinterpret_cast<const double2*>(tiptab + op.y * 20 + sa * 4);
+        const double2 ta0 = ta[0], ta1 = ta[1];
+        a0 = ta0.x * x0;
+        a1 = ta0.y * x1;
+        a2 = ta1.x * x2;
+        a3 = ta1.y * x3;
+      } else {  // OP_POP_ACC
+        double y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+        switch (op.w) {
+          LH_POP_CASE(0) LH_POP_CASE(1) LH_POP_CASE(2) LH_POP_CASE(3)
+          default:
+            if constexpr (kDepth > 4) {
+              switch (op.w) {
+                LH_POP_CASE(4) LH_POP_CASE(5) LH_POP_CASE(6) LH_POP_CASE(7)
+                default:
+                  if constexpr (kDepth > 8) {
+                    switch (op.w) {
+                      LH_POP_CASE(8) LH_POP_CASE(9) LH_POP_CASE(10) LH_POP_CASE(11)
+                      LH_POP_CASE(12) LH_POP_CASE(13) LH_POP_CASE(14) LH_POP_CASE(15)
+                    }
+                  }
+              }
+            }
+        }
+        const double* __restrict__ pa = pm + (size_t)(op.y - T) * 16;
+        const double z0 = fma(pa[3], y3, fma(pa[2], y2, fma(pa[1], y1, pa[0] * y0)));
+        const double z1 = fma(pa[7], y3, fma(pa[6], y2, fma(pa[5], y1, pa[4] * y0)));
+        const double z2 = fma(pa[11], y3, fma(pa[10], y2, fma(pa[9], y1, pa[8] * y0)));
+        const double z3 = fma(pa[15], y3, fma(pa[14], y2, fma(pa[13], y1, pa[12] * y0)));
+        a0 = z0 * x0;
+        a1 = z1 * x1;
+        a2 = z2 * x2;
+        a3 = z3 * x3;
+      }
+    }
+    // per-site, per-rate 2^256 rescaling (libpll PLL_ATTRIB_RATE_SCALERS semantics): the single
+    // running counter is valid for the whole tree because scalers are additive along the traversal.
+    const double m = fmax(fmax(a0, a1), fmax(a2, a3));
+    if (m < kScaleThreshold && m > 0.0) {
+      a0 *= kScaleFactor;
+      a1 *= kScaleFactor;
+      a2 *= kScaleFactor;
+      a3 *= kScaleFactor;
+      ++scal;
+    }
+  }
+
+  // epilogue: close the naive branch for each possible naive state b (A,C,G,T,N):
+  //   L_b = sum_i pi_i * clv_root[i] * P_naive[i][b]        (N: row sums of P_naive)
+  const double* __restrict__ p4 = pi + (size_t)sample * 4;
+  const double w0 = p4[0] * a0, w1 = p4[1] * a1, w2 = p4[2] * a2, w3 = p4[3] * a3;
+  if (site_raw < L) {
+    double* out = site_lik + (((size_t)sample * R + rate) * 5) * (size_t)L + site;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      const double* tv = tiptab + b * 4;  // tip 0 = naive
+      out[(size_t)b * L] = fma(w3, tv[3], fma(w2, tv[2], fma(w1, tv[1], w0 * tv[0])));
+    }
+    site_scal[((size_t)sample * R + rate) * (size_t)L + site] = scal;
+  }
+}
+
+void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
+                  const double* pmat, const double* tipvec, const double* pi, double* site_lik,
+                  int32_t* site_scal, hipStream_t stream) {
+  const int L = fam.n_sites;
+  int threads = ((L + 63) / 64) * 64;
+  if (threads > 512) threads = 512;
+  const int tiles = (L + threads - 1) / threads;
+  // rebalance so the tiles are equally full
+  threads = (((L + tiles - 1) / tiles) + 63) / 64 * 64;
+  const size_t lds = (size_t)T * 20 * sizeof(double);
+  dim3 grid(tiles, R, n), block(threads);
+  const int n_ops = T - 2;
+  if (max_depth <= 4)
+    hipLaunchKernelGGL(prune_kernel<4>, grid, block, lds, stream, fam.msa, L, T, n_ops, ops, pmat, tipvec,
+                       pi, site_lik, site_scal);
+  else if (max_depth <= 8)
+    hipLaunchKernelGGL(prune_kernel<8>, grid, block, lds, stream, fam.msa, L, T, n_ops, ops, pmat, tipvec,
+                       pi, site_lik, site_scal);
+  else
+    hipLaunchKernelGGL(prune_kernel<16>, grid, block, lds, stream, fam.msa, L, T, n_ops, ops, pmat, tipvec,
+                       pi, site_lik, site_scal);
+}
+
+}  // namespace lh

@@ -1,0 +1,197 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the dense CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import linearham_oracle as orc
+from tests import desc_builder as db
+
+pytestmark = pytest.mark.gpu
+
+ER, PI, ALPHA = [1.0] * 6, [0.17, 0.19, 0.25, 0.39], 1.0
+RTOL_LOGLIK = 1e-6   # north-star tolerance (BASELINE.json); the asserts below are far tighter
+TOY = [("phylo_hmm_input", "hmm_params", 4), ("phylo_hmm_input_extra", "hmm_params", 4),
+       ("phylo_likelihood_hmm_input", "phylo_likelihood_hmm_params", 1)]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import linearham_amd
+    lib = linearham_amd.load_library()
+    assert lib.device_count() >= 1, "no HIP device visible: the GPU tests need an MI355X"
+    return lib
+
+
+def expand_forward(h, fam_desc, fwd, sco):
+    """Compact forward layout (include/linearham_amd.h) -> the reference's dense arrays."""
+    out = {}
+    pos = [0]
+
+    def take(n):
+        v = fwd[pos[0]:pos[0] + n]
+        pos[0] += n
+        return v
+    nV = len(h.vgerm.state_strs)
+    out["vgerm_forward"] = take(nV)
+    spos = 1
+    out["vgerm_scaler_count"] = int(sco[0])
+
+    def junction(J, G_left, G_right, Jt, left_fb):
+        nonlocal spos
+        W, S = Jt.n_rows, len(J.state_strs)
+        F = np.zeros((W, S))
+        left, right = sorted(G_left.ggene_ranges), sorted(G_right.ggene_ranges)
+        js = left_fb[0]
+        for i in range(W):
+            fL, fN, fR = take(Jt.n_left), take(4 * Jt.n_right).reshape(-1, 4), take(Jt.n_right)
+            for l, name in enumerate(left):
+                rs, re_ = J.ggene_ranges[name]
+                if i < re_ - rs:
+                    F[i, rs + i] = fL[l]
+            for r, name in enumerate(right):
+                rs, re_ = J.ggene_ranges[name]
+                F[i, rs:rs + 4] = fN[r]
+                for k in range(rs + 4, re_):
+                    if J.site_inds[k] - js == i:
+                        F[i, k] = fR[r]
+        counts = [int(x) for x in sco[spos:spos + W]]
+        spos += W
+        return F, counts
+    fb = h.flexbounds
+    out["vd_junction_forward"], out["vd_junction_scaler_counts"] = junction(
+        h.vd_junction, h.vgerm, h.dgerm, fam_desc.vd, fb["v_r"])
+    out["dgerm_forward"] = take(len(h.dgerm.state_strs))
+    out["dgerm_scaler_count"] = int(sco[spos])
+    spos += 1
+    out["dj_junction_forward"], out["dj_junction_scaler_counts"] = junction(
+        h.dj_junction, h.dgerm, h.jgerm, fam_desc.dj, fb["d_r"])
+    out["jgerm_forward"] = take(len(h.jgerm.state_strs))
+    out["jgerm_scaler_count"] = int(sco[spos])
+    return out
+
+
+def run_family(hip, h, samples, num_rates):
+    """samples: list of dict(tree=newick, er, pi, alpha). Returns (gpu results, oracle results)."""
+    import linearham_amd
+    desc = db.build_family_desc(h)
+    fam = linearham_amd.Family(desc, hip)
+    T = h.msa.shape[0] + 1
+    ops, brl, depth = [], [], 0
+    for s in samples:
+        tree = orc.parse_newick(s["tree"])
+        children, root, brlen = db.tree_arrays(tree, h.xmsa_labels)
+        o, d = hip.schedule_tree(T, children, root)
+        ops.append(o)
+        brl.append(brlen)
+        depth = max(depth, d)
+    ll, res = fam.eval_batch(T, depth, np.stack(ops), np.stack(brl), [s["er"] for s in samples],
+                             [s["pi"] for s in samples], [s["alpha"] for s in samples], num_rates,
+                             want=("rates", "xmsa_emission", "forward", "scaler_counts"))
+    ref = []
+    for s in samples:
+        h.initialize_phylo_parameters(s["tree"], s["er"], s["pi"], s["alpha"], num_rates, is_path=False)
+        h.initialize_phylo_emission()
+        r = {"loglik": h.log_likelihood(), "rates": np.array(h.sr), "xmsa_emission": h.xmsa_emission.copy()}
+        for k in ["vgerm_forward", "vd_junction_forward", "dgerm_forward", "dj_junction_forward",
+                  "jgerm_forward", "vgerm_scaler_count", "vd_junction_scaler_counts", "dgerm_scaler_count",
+                  "dj_junction_scaler_counts", "jgerm_scaler_count"]:
+            v = getattr(h, k)
+            r[k] = v.copy() if isinstance(v, np.ndarray) else v
+        ref.append(r)
+    fam.close()
+    return desc, ll, res, ref
+
+
+def compare(h, desc, ll, res, ref, rtol=1e-10):
+    for i, r in enumerate(ref):
+        assert abs(ll[i] - r["loglik"]) <= rtol * abs(r["loglik"]), (i, ll[i], r["loglik"])
+        np.testing.assert_allclose(res["rates"][i], r["rates"], rtol=1e-9)
+        np.testing.assert_allclose(res["xmsa_emission"][i], r["xmsa_emission"], rtol=1e-9)
+        ex = expand_forward(h, desc, res["forward"][i], res["scaler_counts"][i])
+        for k in ["vgerm_scaler_count", "vd_junction_scaler_counts", "dgerm_scaler_count",
+                  "dj_junction_scaler_counts", "jgerm_scaler_count"]:
+            assert ex[k] == r[k], (i, k, ex[k], r[k])
+        for k in ["vgerm_forward", "vd_junction_forward", "dgerm_forward", "dj_junction_forward",
+                  "jgerm_forward"]:
+            np.testing.assert_allclose(ex[k], r[k], rtol=1e-9, atol=0, err_msg="%d %s" % (i, k))
+
+
+@pytest.mark.parametrize("case,params,R", TOY)
+def test_toy_families_match_oracle_and_goldens(hip, goldens, data_dir, case, params, R):
+    h = orc.PhyloHMM(os.path.join(data_dir, case + ".yaml"), 0, os.path.join(data_dir, params), 0)
+    newick = open(os.path.join(data_dir, "newton.tree")).read()
+    samples = [dict(tree=newick, er=ER, pi=PI, alpha=ALPHA)]
+    desc, ll, res, ref = run_family(hip, h, samples, R)
+    compare(h, desc, ll, res, ref)
+    gold = goldens["PhyloHMM:" + case]["vars"]
+    from tests.helpers import catch_approx, eigen_is_approx
+    assert catch_approx(ll[0], gold["loglikelihood"])          # the reference's own acceptance test
+    if "xmsa_emission" in gold:
+        assert eigen_is_approx(res["xmsa_emission"][0], gold["xmsa_emission"], 1e-5)
+
+
+def test_batch_of_varied_models_on_toy_family(hip, data_dir):
+    """Same toy family, many (er, pi, alpha, branch length) draws in one batch, R = 4."""
+    h = orc.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input_extra.yaml"), 0,
+                     os.path.join(data_dir, "hmm_params"), 0)
+    rng = np.random.default_rng(11)
+    samples = []
+    for _ in range(24):
+        bl = rng.exponential(0.2, size=5) + 1e-6
+        tree = "((0:%g,1:%g):%g,naive:%g,2:%g);" % tuple(bl)
+        pi = rng.dirichlet(np.ones(4) * 2)
+        samples.append(dict(tree=tree, er=rng.dirichlet(np.ones(6)).tolist(), pi=pi.tolist(),
+                            alpha=float(max(rng.exponential(1.0), 0.05))))
+    # alternative topologies and a missing / zero branch length (-> 1e-6, src/PhyloHMM.cpp:355)
+    samples.append(dict(tree="((naive:0.1,2:0.3):0.05,0:0.2,1:0.1);", er=ER, pi=PI, alpha=0.3))
+    samples.append(dict(tree="(naive:0.1,(2:0.3,0):0.0,1:0.1);", er=ER, pi=PI, alpha=7.0))
+    desc, ll, res, ref = run_family(hip, h, samples, 4)
+    compare(h, desc, ll, res, ref)
+
+
+def test_small_synthetic_family(hip, tmp_path):
+    """Multi-allele junctions, NNI-perturbed trees with [&index=..] annotations, scaler counts > 0."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(), out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    desc, ll, res, ref = run_family(hip, h, rows, 4)
+    compare(h, desc, ll, res, ref)
+    assert any(r["jgerm_scaler_count"] > 0 for r in ref)
+
+
+def test_gamma_rates_against_scipy(hip, data_dir):
+    """K0a discrete-Gamma means over a grid of shapes (pll_compute_gamma_cats restatement)."""
+    import linearham_amd
+    h = orc.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input.yaml"), 0, os.path.join(data_dir, "hmm_params"), 0)
+    desc = db.build_family_desc(h)
+    fam = linearham_amd.Family(desc, hip)
+    tree = orc.parse_newick(open(os.path.join(data_dir, "newton.tree")).read())
+    children, root, brlen = db.tree_arrays(tree, h.xmsa_labels)
+    ops, depth = hip.schedule_tree(4, children, root)
+    alphas = np.array([0.05, 0.1, 0.2, 0.37, 0.5, 0.9, 1.0, 1.0001, 1.7, 3.0, 8.0, 20.0, 60.0, 150.0])
+    n = len(alphas)
+    for R in (2, 4, 8):
+        ll, res = fam.eval_batch(4, depth, np.stack([ops] * n), np.stack([brlen] * n), [ER] * n, [PI] * n,
+                                 alphas, R, want=("rates",))
+        for i, a in enumerate(alphas):
+            want = orc.gamma_rates_mean(a, R)
+            np.testing.assert_allclose(res["rates"][i], want, rtol=1e-9, atol=1e-13, err_msg="alpha=%g" % a)
+            assert abs(res["rates"][i].mean() - 1.0) < 1e-12
+    fam.close()
+
+
+def test_error_paths(hip, data_dir):
+    import linearham_amd
+    h = orc.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input.yaml"), 0, os.path.join(data_dir, "hmm_params"), 0)
+    desc = db.build_family_desc(h)
+    fam = linearham_amd.Family(desc, hip)
+    bad_ops = np.zeros((1, 2, 4), dtype=np.int32)
+    bad_ops[0, 0] = (0, 9, 1, 0)     # tip id out of range
+    with pytest.raises(RuntimeError):
+        fam.eval_batch(4, 0, bad_ops, np.full((1, 6), 0.1), [ER], [PI], [1.0], 4)
+    with pytest.raises(RuntimeError):   # wrong tip count for this family
+        fam.eval_batch(5, 0, np.zeros((1, 3, 4), dtype=np.int32), np.full((1, 8), 0.1), [ER], [PI], [1.0], 4)
+    fam.close()
