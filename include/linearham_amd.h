@@ -67,7 +67,8 @@ typedef struct {
   const double* right_trans; /* [W][nR] transition[q-1] when rows i-1 and i both hold a state */
   const double* right_gp_li; /* [W][nR] gene_prob * landing_in[q] of the row-i germline state */
   const int32_t* right_xmsa; /* [W][nR] xMSA column of the row-i germline state, or -1 */
-  const int32_t* nti_xmsa;   /* [W][4]  xMSA column of NTI base b at row i */
+  const int32_t* nti_xmsa;   /* [W][nR][4] emission column of NTI base b of right gene r at row i
+                              * (PhyloHMM: the same for every r; SimpleHMM: per-gene nti_emission) */
   const double* exit_nlo;    /* [nR][4] nti_landing_out[b][q0] * prod(in-region transitions) */
   const double* exit_trans;  /* [nR]    transition[q0-1] * prod (0 if no last-row state) */
   const double* exit_gp_li;  /* [nR]    gene_prob * landing_in[q0] * prod */

@@ -1,0 +1,238 @@
+// HMM base class of the MI355X-native linearham host (mirrors the class surface of the reference's
+// src/HMM.hpp:23-412): cluster YAML parsing, state space, dense transition matrices (kept for the
+// accessors and for sampling), and the forward-pass *results*.  The forward pass itself runs on the
+// GPU through the C ABI (include/linearham_amd.h); this class has no CPU forward implementation.
+#ifndef LINEARHAM_HMM_
+#define LINEARHAM_HMM_
+
+#include <map>
+#include <random>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "VDJGermline.hpp"
+#include "linearham_amd.h"
+#include "utils.hpp"
+
+namespace linearham {
+
+typedef std::map<std::string, std::pair<int, int>> GeneRanges;
+
+/// State-space vectors of one HMM region (the reference keeps them as separate members
+/// `<region>_state_strs_`, `<region>_naive_bases_`, ...: src/HMM.hpp:56-110).
+struct RegionStates {
+  std::vector<std::string> state_strs;
+  std::vector<int> left_del, right_del;   // "germline" regions
+  std::vector<int> del;                    // "junction" regions
+  std::vector<GermlineType> ggene_types;   // "junction" regions
+  GeneRanges ggene_ranges;
+  std::vector<int> naive_bases, germ_inds, site_inds;
+};
+
+/// Host copies of the arrays behind lh_junction (structured form of FillTransition's output).
+struct JunctionTables {
+  int n_rows = 0, n_left = 0, n_right = 0;
+  std::vector<double> enter_trans, enter_lo, left_trans, left_lo, right_gp_nli, right_ntt, right_nlo,
+      right_trans, right_gp_li, exit_nlo, exit_trans, exit_gp_li;
+  std::vector<int32_t> left_xmsa, right_xmsa, nti_xmsa;
+  lh_junction c() const;
+};
+
+struct SegmentTables {
+  std::vector<int32_t> offsets, xmsa_inds;
+  lh_segments c() const;
+};
+
+class HMM {
+ protected:
+  std::string locus_;
+  yaml_lite::Node cluster_data_;
+  std::map<std::string, std::pair<int, int>> flexbounds_;
+  std::map<std::string, int> relpos_;
+  std::unordered_map<std::string, GermlineGene> ggenes_;
+  std::string alphabet_;
+  MatrixXi msa_;
+  std::mt19937 rng_;
+  std::discrete_distribution<int> distr_;
+
+  RegionStates vpadding_, vgerm_, vd_junction_, dgerm_, dj_junction_, jgerm_, jpadding_;
+
+  VectorXd vpadding_transition_;
+  MatrixXd vgerm_vd_junction_transition_, vd_junction_transition_, vd_junction_dgerm_transition_;
+  MatrixXd dgerm_dj_junction_transition_, dj_junction_transition_, dj_junction_jgerm_transition_;
+  VectorXd jpadding_transition_;
+
+  bool cache_forward_ = false;
+  double loglikelihood_ = 0.0;
+
+  VectorXd vgerm_forward_, dgerm_forward_, jgerm_forward_;
+  MatrixXd vd_junction_forward_, dj_junction_forward_;
+  int vgerm_scaler_count_ = 0, dgerm_scaler_count_ = 0, jgerm_scaler_count_ = 0;
+  std::vector<int> vd_junction_scaler_counts_, dj_junction_scaler_counts_;
+
+  // naive sequence sample
+  std::string naive_seq_samp_;
+  std::string vgerm_state_str_samp_;
+  int vgerm_state_ind_samp_ = 0, vgerm_left_del_samp_ = 0, vgerm_right_del_samp_ = 0;
+  std::string vgerm_left_insertion_samp_;
+  std::vector<std::string> vd_junction_state_str_samps_;
+  std::vector<int> vd_junction_state_ind_samps_;
+  std::string vd_junction_insertion_samp_;
+  std::string dgerm_state_str_samp_;
+  int dgerm_state_ind_samp_ = 0, dgerm_left_del_samp_ = 0, dgerm_right_del_samp_ = 0;
+  std::vector<std::string> dj_junction_state_str_samps_;
+  std::vector<int> dj_junction_state_ind_samps_;
+  std::string dj_junction_insertion_samp_;
+  std::string jgerm_state_str_samp_;
+  int jgerm_state_ind_samp_ = 0, jgerm_left_del_samp_ = 0, jgerm_right_del_samp_ = 0;
+  std::string jgerm_right_insertion_samp_;
+
+  // GPU side
+  lh_family* family_ = nullptr;
+
+  void InitializeMsa();
+  void InitializeStateSpace();
+  void InitializeTransition();
+
+  /// Runs the device forward pass if needed (pure virtual: the derived class knows how the
+  /// emissions are produced) and unpacks the compact forward arrays into the dense members.
+  virtual void RunForwardAlgorithm() = 0;
+  void UnpackForward(const double* fwd, const int32_t* sco);
+  void SampleInitialState();
+
+  /// Structured junction tables for the C ABI. `xmsa_inds` is the W x S index matrix of the junction
+  /// (row-major), or empty when the caller fills the *_xmsa arrays itself.
+  JunctionTables BuildJunctionTables(const RegionStates& J, const RegionStates& G_left,
+                                     const RegionStates& G_right, std::pair<int, int> left_fb,
+                                     std::pair<int, int> right_fb, const MatrixXi& xmsa_inds) const;
+
+ public:
+  HMM(const std::string& yaml_path, int cluster_ind, const std::string& hmm_param_dir, int seed);
+  virtual ~HMM();
+  HMM(const HMM&) = delete;
+  HMM& operator=(const HMM&) = delete;
+
+  const std::string& locus() const { return locus_; }
+  const std::map<std::string, std::pair<int, int>>& flexbounds() const { return flexbounds_; }
+  const std::map<std::string, int>& relpos() const { return relpos_; }
+  const std::unordered_map<std::string, GermlineGene>& ggenes() const { return ggenes_; }
+  const std::string& alphabet() const { return alphabet_; }
+  const MatrixXi& msa() const { return msa_; }
+
+#define LH_REGION_ACCESSORS(R)                                                               \
+  const GeneRanges& R##_ggene_ranges() const { return R##_.ggene_ranges; }                   \
+  const std::vector<int>& R##_naive_bases() const { return R##_.naive_bases; }               \
+  const std::vector<int>& R##_site_inds() const { return R##_.site_inds; }
+#define LH_GERM_ACCESSORS(R)                                                                 \
+  LH_REGION_ACCESSORS(R)                                                                     \
+  const std::vector<std::string>& R##_state_strs() const { return R##_.state_strs; }         \
+  const std::vector<int>& R##_left_del() const { return R##_.left_del; }                     \
+  const std::vector<int>& R##_right_del() const { return R##_.right_del; }                   \
+  const std::vector<int>& R##_germ_inds() const { return R##_.germ_inds; }
+#define LH_JUNCTION_ACCESSORS(R)                                                             \
+  LH_REGION_ACCESSORS(R)                                                                     \
+  const std::vector<std::string>& R##_state_strs() const { return R##_.state_strs; }         \
+  const std::vector<int>& R##_del() const { return R##_.del; }                               \
+  const std::vector<GermlineType>& R##_ggene_types() const { return R##_.ggene_types; }      \
+  const std::vector<int>& R##_germ_inds() const { return R##_.germ_inds; }
+  LH_REGION_ACCESSORS(vpadding)
+  LH_GERM_ACCESSORS(vgerm)
+  LH_JUNCTION_ACCESSORS(vd_junction)
+  LH_GERM_ACCESSORS(dgerm)
+  LH_JUNCTION_ACCESSORS(dj_junction)
+  LH_GERM_ACCESSORS(jgerm)
+  LH_REGION_ACCESSORS(jpadding)
+#undef LH_REGION_ACCESSORS
+#undef LH_GERM_ACCESSORS
+#undef LH_JUNCTION_ACCESSORS
+
+  const VectorXd& vpadding_transition() const { return vpadding_transition_; }
+  const MatrixXd& vgerm_vd_junction_transition() const { return vgerm_vd_junction_transition_; }
+  const MatrixXd& vd_junction_transition() const { return vd_junction_transition_; }
+  const MatrixXd& vd_junction_dgerm_transition() const { return vd_junction_dgerm_transition_; }
+  const MatrixXd& dgerm_dj_junction_transition() const { return dgerm_dj_junction_transition_; }
+  const MatrixXd& dj_junction_transition() const { return dj_junction_transition_; }
+  const MatrixXd& dj_junction_jgerm_transition() const { return dj_junction_jgerm_transition_; }
+  const VectorXd& jpadding_transition() const { return jpadding_transition_; }
+  bool cache_forward() const { return cache_forward_; }
+  const VectorXd& vgerm_forward() const { return vgerm_forward_; }
+  const MatrixXd& vd_junction_forward() const { return vd_junction_forward_; }
+  const VectorXd& dgerm_forward() const { return dgerm_forward_; }
+  const MatrixXd& dj_junction_forward() const { return dj_junction_forward_; }
+  const VectorXd& jgerm_forward() const { return jgerm_forward_; }
+  int vgerm_scaler_count() const { return vgerm_scaler_count_; }
+  const std::vector<int>& vd_junction_scaler_counts() const { return vd_junction_scaler_counts_; }
+  int dgerm_scaler_count() const { return dgerm_scaler_count_; }
+  const std::vector<int>& dj_junction_scaler_counts() const { return dj_junction_scaler_counts_; }
+  int jgerm_scaler_count() const { return jgerm_scaler_count_; }
+  const std::string& naive_seq_samp() const { return naive_seq_samp_; }
+  const std::string& vgerm_state_str_samp() const { return vgerm_state_str_samp_; }
+  int vgerm_state_ind_samp() const { return vgerm_state_ind_samp_; }
+  int vgerm_left_del_samp() const { return vgerm_left_del_samp_; }
+  int vgerm_right_del_samp() const { return vgerm_right_del_samp_; }
+  const std::string& vgerm_left_insertion_samp() const { return vgerm_left_insertion_samp_; }
+  const std::vector<std::string>& vd_junction_state_str_samps() const { return vd_junction_state_str_samps_; }
+  const std::vector<int>& vd_junction_state_ind_samps() const { return vd_junction_state_ind_samps_; }
+  const std::string& vd_junction_insertion_samp() const { return vd_junction_insertion_samp_; }
+  const std::string& dgerm_state_str_samp() const { return dgerm_state_str_samp_; }
+  int dgerm_state_ind_samp() const { return dgerm_state_ind_samp_; }
+  int dgerm_left_del_samp() const { return dgerm_left_del_samp_; }
+  int dgerm_right_del_samp() const { return dgerm_right_del_samp_; }
+  const std::vector<std::string>& dj_junction_state_str_samps() const { return dj_junction_state_str_samps_; }
+  const std::vector<int>& dj_junction_state_ind_samps() const { return dj_junction_state_ind_samps_; }
+  const std::string& dj_junction_insertion_samp() const { return dj_junction_insertion_samp_; }
+  const std::string& jgerm_state_str_samp() const { return jgerm_state_str_samp_; }
+  int jgerm_state_ind_samp() const { return jgerm_state_ind_samp_; }
+  int jgerm_left_del_samp() const { return jgerm_left_del_samp_; }
+  int jgerm_right_del_samp() const { return jgerm_right_del_samp_; }
+  const std::string& jgerm_right_insertion_samp() const { return jgerm_right_insertion_samp_; }
+
+  double LogLikelihood();
+  std::string SampleNaiveSequence();
+};
+
+// Free functions mirroring src/HMM.hpp:421-540.
+void CacheGermlineStates(GermlinePtr germ_ptr, std::pair<int, int> left_flexbounds,
+                         std::pair<int, int> right_flexbounds, int relpos, bool left_end, bool right_end,
+                         RegionStates& R);
+void CacheJunctionStates(const GermlineGene& ggene, std::pair<int, int> left_flexbounds,
+                         std::pair<int, int> right_flexbounds, int relpos, bool left_end, RegionStates& R);
+void CachePaddingStates(GermlinePtr germ_ptr, std::pair<int, int> leftright_flexbounds, int relpos,
+                        bool left_end, RegionStates& R);
+void ComputeGermlineJunctionTransition(const RegionStates& G, const RegionStates& J, GermlineType left_gtype,
+                                       GermlineType right_gtype,
+                                       const std::unordered_map<std::string, GermlineGene>& ggenes, MatrixXd& T);
+void ComputeJunctionTransition(const RegionStates& J, GermlineType left_gtype, GermlineType right_gtype,
+                               const std::unordered_map<std::string, GermlineGene>& ggenes, MatrixXd& T);
+void ComputeJunctionGermlineTransition(const RegionStates& J, const RegionStates& G, GermlineType left_gtype,
+                                       GermlineType right_gtype,
+                                       const std::unordered_map<std::string, GermlineGene>& ggenes, MatrixXd& T);
+void ComputePaddingTransition(const GeneRanges& ranges, const std::unordered_map<std::string, GermlineGene>& ggenes,
+                              VectorXd& transition);
+void FillTransition(const GermlineGene& from_ggene, const GermlineGene& to_ggene, GermlineType left_gtype,
+                    GermlineType right_gtype, int germ_ind_row_start, int germ_ind_col_start,
+                    int site_ind_row_start, int site_ind_col_start, int nti_row_start, int nti_col_start,
+                    int nti_row_length, int nti_col_length, int germ_row_start, int germ_col_start,
+                    int germ_row_length, int germ_col_length, MatrixXd& T, int row_off, int col_off);
+void SampleJunctionStates(int germ_state_ind_samp, const MatrixXd& junction_germ_transition, const RegionStates& J,
+                          const MatrixXd& junction_transition, const MatrixXd& junction_forward,
+                          GermlineType left_gtype, GermlineType right_gtype, std::pair<int, int> left_flexbounds,
+                          const std::string& alphabet, std::mt19937& rng, std::discrete_distribution<int>& distr,
+                          std::string& naive_seq_samp, int& germ_left_del_samp,
+                          std::vector<std::string>& junction_state_str_samps,
+                          std::vector<int>& junction_state_ind_samps, std::string& junction_insertion_samp,
+                          int& germ_right_del_samp);
+void SampleGermlineState(const std::vector<int>& junction_state_ind_samps, const MatrixXd& germ_junction_transition,
+                         const RegionStates& G, const VectorXd& germ_forward, const std::string& alphabet,
+                         std::mt19937& rng, std::discrete_distribution<int>& distr, std::string& naive_seq_samp,
+                         std::string& germ_state_str_samp, int& germ_state_ind_samp, int& germ_left_del_samp,
+                         int& germ_right_del_samp);
+
+/// Throws std::runtime_error(lh_last_error()) when a C-ABI call fails.
+void CheckHip(int rc, const char* what);
+
+}  // namespace linearham
+
+#endif  // LINEARHAM_HMM_

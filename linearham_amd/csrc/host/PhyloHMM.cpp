@@ -1,0 +1,394 @@
+#include "PhyloHMM.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <sstream>
+
+namespace linearham {
+
+// src/PhyloHMM.cpp:29-34
+PhyloHMM::PhyloHMM(const std::string& yaml_path, int cluster_ind, const std::string& hmm_param_dir, int seed)
+    : HMM(yaml_path, cluster_ind, hmm_param_dir, seed) {
+  InitializeXmsaStructs();
+}
+
+// src/PhyloHMM.cpp:45-89 (+ BuildXmsa, :123-144)
+void PhyloHMM::InitializeXmsaStructs() {
+  xmsa_labels_.push_back("naive");
+  for (const auto& n : cluster_data_["unique_ids"].seq) xmsa_labels_.push_back(n.as_string());
+  xmsa_naive_ind_ = 0;
+  std::map<std::pair<int, int>, int> xmsa_ids;
+  StoreGermlinePaddingXmsaIndices(vpadding_.naive_bases, vpadding_.site_inds, xmsa_ids, vpadding_xmsa_inds_);
+  StoreGermlinePaddingXmsaIndices(vgerm_.naive_bases, vgerm_.site_inds, xmsa_ids, vgerm_xmsa_inds_);
+  if (locus_ == "igh") {
+    StoreJunctionXmsaIndices(vd_junction_.naive_bases, vd_junction_.site_inds, flexbounds_.at("v_r"),
+                             flexbounds_.at("d_l"), xmsa_ids, vd_junction_xmsa_inds_);
+    StoreGermlinePaddingXmsaIndices(dgerm_.naive_bases, dgerm_.site_inds, xmsa_ids, dgerm_xmsa_inds_);
+    StoreJunctionXmsaIndices(dj_junction_.naive_bases, dj_junction_.site_inds, flexbounds_.at("d_r"),
+                             flexbounds_.at("j_l"), xmsa_ids, dj_junction_xmsa_inds_);
+  } else {
+    StoreJunctionXmsaIndices(vd_junction_.naive_bases, vd_junction_.site_inds, flexbounds_.at("v_r"),
+                             flexbounds_.at("j_l"), xmsa_ids, vd_junction_xmsa_inds_);
+  }
+  StoreGermlinePaddingXmsaIndices(jgerm_.naive_bases, jgerm_.site_inds, xmsa_ids, jgerm_xmsa_inds_);
+  StoreGermlinePaddingXmsaIndices(jpadding_.naive_bases, jpadding_.site_inds, xmsa_ids, jpadding_xmsa_inds_);
+
+  const int n = msa_.rows(), C = (int)xmsa_ids.size();
+  xmsa_.setConstant(n + 1, C, -1);
+  xmsa_site_.assign(C, 0);
+  xmsa_base_.assign(C, 0);
+  for (auto it = xmsa_ids.begin(); it != xmsa_ids.end(); ++it) {
+    const int naive_base = it->first.first, msa_ind = it->first.second, xmsa_ind = it->second;
+    xmsa_(0, xmsa_ind) = naive_base;
+    for (int r = 0; r < n; ++r) xmsa_(r + 1, xmsa_ind) = msa_(r, msa_ind);
+    xmsa_site_[xmsa_ind] = msa_ind;
+    xmsa_base_[xmsa_ind] = (uint8_t)naive_base;
+  }
+  xmsa_seqs_.assign(n + 1, "");
+  for (int r = 0; r < n + 1; ++r) {
+    VectorXi row(xmsa_.row(r), xmsa_.row(r) + C);
+    xmsa_seqs_[r] = ConvertIntsToSeq(row, alphabet_);
+  }
+}
+
+namespace {
+
+SegmentTables MakeSegments(const GeneRanges& ranges, const VectorXi& inds) {
+  SegmentTables s;
+  s.offsets.push_back(0);
+  for (auto it = ranges.begin(); it != ranges.end(); ++it) {
+    for (int j = it->second.first; j < it->second.second; ++j) s.xmsa_inds.push_back(inds[j]);
+    s.offsets.push_back((int32_t)s.xmsa_inds.size());
+  }
+  return s;
+}
+
+}  // namespace
+
+// Upload everything that is constant for this clonal family (lh_family_create).  Done lazily at the
+// first evaluation so that the host-only state (state space, transitions, xMSA) can be inspected on a
+// machine without a GPU; any evaluation without a GPU fails here (there is no CPU path).
+void PhyloHMM::CreateFamily() {
+  if (family_) return;
+  const bool igh = locus_ == "igh";
+  const int n = msa_.rows(), L = msa_.cols();
+  std::vector<uint8_t> msa8((std::size_t)n * L);
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < L; ++c) msa8[(std::size_t)r * L + c] = (uint8_t)msa_(r, c);
+  const SegmentTables vpad = MakeSegments(vpadding_.ggene_ranges, vpadding_xmsa_inds_);
+  const SegmentTables vger = MakeSegments(vgerm_.ggene_ranges, vgerm_xmsa_inds_);
+  const SegmentTables dger = MakeSegments(dgerm_.ggene_ranges, dgerm_xmsa_inds_);
+  const SegmentTables jger = MakeSegments(jgerm_.ggene_ranges, jgerm_xmsa_inds_);
+  const SegmentTables jpad = MakeSegments(jpadding_.ggene_ranges, jpadding_xmsa_inds_);
+  std::vector<double> gene_prob, trans_prod;
+  for (auto it = vgerm_.ggene_ranges.begin(); it != vgerm_.ggene_ranges.end(); ++it) {
+    const Germline& g = *ggenes_.at(it->first).germ_ptr;
+    gene_prob.push_back(g.gene_prob());
+    const int gis = vgerm_.germ_inds[it->second.first];
+    double prod = 1.0;  // src/HMM.cpp:310-313
+    for (int k = 0; k < it->second.second - it->second.first - 1; ++k) prod *= g.transition()[gis + k];
+    trans_prod.push_back(prod);
+  }
+  JunctionTables vd, dj;
+  if (igh) {
+    vd = BuildJunctionTables(vd_junction_, vgerm_, dgerm_, flexbounds_.at("v_r"), flexbounds_.at("d_l"),
+                             vd_junction_xmsa_inds_);
+    dj = BuildJunctionTables(dj_junction_, dgerm_, jgerm_, flexbounds_.at("d_r"), flexbounds_.at("j_l"),
+                             dj_junction_xmsa_inds_);
+  } else {
+    vd = BuildJunctionTables(vd_junction_, vgerm_, jgerm_, flexbounds_.at("v_r"), flexbounds_.at("j_l"),
+                             vd_junction_xmsa_inds_);
+  }
+  lh_family_desc d{};
+  d.abi_version = LH_ABI_VERSION;
+  d.has_d = igh ? 1 : 0;
+  d.n_seqs = n;
+  d.n_sites = L;
+  d.msa = msa8.data();
+  d.n_xmsa = xmsa_.cols();
+  d.xmsa_site = xmsa_site_.data();
+  d.xmsa_naive_base = xmsa_base_.data();
+  d.vpadding = vpad.c();
+  d.vgerm = vger.c();
+  d.dgerm = dger.c();
+  d.jgerm = jger.c();
+  d.jpadding = jpad.c();
+  d.vgerm_gene_prob = gene_prob.data();
+  d.vpadding_transition = vpadding_transition_.data();
+  d.vgerm_trans_prod = trans_prod.data();
+  d.jpadding_transition = jpadding_transition_.data();
+  d.vd = vd.c();
+  if (igh) d.dj = dj.c();
+  CheckHip(lh_family_create(&d, &family_), "lh_family_create");
+}
+
+// src/PhyloHMM.cpp:350-361
+void PhyloHMM::InitializePhyloParameters(const std::string& newick_path, const std::vector<double>& er,
+                                         const std::vector<double>& pi, double alpha, int num_rates) {
+  std::ifstream in(newick_path);
+  if (!in) throw std::runtime_error("Can't open Newick file " + newick_path);
+  std::stringstream ss;
+  ss << in.rdbuf();
+  InitializePhyloParametersFromString(ss.str(), er, pi, alpha, num_rates);
+}
+
+void PhyloHMM::InitializePhyloParametersFromString(const std::string& newick, const std::vector<double>& er,
+                                                   const std::vector<double>& pi, double alpha, int num_rates) {
+  Require(er.size() == 6 && pi.size() == 4, "er must have 6 and pi 4 entries");
+  Require(num_rates >= 1, "num_rates must be positive");
+  tree_ = ParseNewick(newick, xmsa_labels_, EPS);
+  have_tree_ = true;
+  er_ = er;
+  pi_ = pi;
+  alpha_ = alpha;
+  num_rates_ = num_rates;
+  sr_.assign(num_rates, 0.0);
+}
+
+PhyloHMM::DeviceBatch PhyloHMM::FlattenBatch(const std::vector<TreeSample>& samples) const {
+  DeviceBatch b;
+  const int T = (int)xmsa_labels_.size();
+  b.n = (int)samples.size();
+  b.n_tips = T;
+  b.ops.resize((std::size_t)b.n * (T - 2) * 4);
+  b.brlen.resize((std::size_t)b.n * (2 * T - 2));
+  b.er.resize((std::size_t)b.n * 6);
+  b.pi.resize((std::size_t)b.n * 4);
+  b.alpha.resize(b.n);
+  for (int s = 0; s < b.n; ++s) {
+    const TreeSample& ts = samples[s];
+    Require(ts.er.size() == 6 && ts.pi.size() == 4, "er must have 6 and pi 4 entries");
+    const TreeArrays tr = ParseNewick(ts.newick, xmsa_labels_, EPS);
+    int32_t depth = 0;
+    CheckHip(lh_schedule_tree(T, tr.children.data(), tr.root, b.ops.data() + (std::size_t)s * (T - 2) * 4, &depth),
+             "lh_schedule_tree");
+    b.max_depth = std::max(b.max_depth, (int)depth);
+    std::copy(tr.brlen.begin(), tr.brlen.end(), b.brlen.begin() + (std::size_t)s * (2 * T - 2));
+    std::copy(ts.er.begin(), ts.er.end(), b.er.begin() + (std::size_t)s * 6);
+    std::copy(ts.pi.begin(), ts.pi.end(), b.pi.begin() + (std::size_t)s * 4);
+    b.alpha[s] = ts.alpha;
+  }
+  return b;
+}
+
+std::vector<double> PhyloHMM::LogLikelihoodBatch(const std::vector<TreeSample>& samples, int num_rates) {
+  CreateFamily();
+  const DeviceBatch b = FlattenBatch(samples);
+  std::vector<double> ll(b.n);
+  if (b.n == 0) return ll;
+  CheckHip(lh_eval_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(),
+                         b.pi.data(), b.alpha.data(), num_rates, ll.data(), nullptr),
+           "lh_eval_batch");
+  return ll;
+}
+
+// src/PhyloHMM.cpp:366-383: one evaluation on the device (gamma rates, P-matrices, pruning, emission
+// assembly, forward sweep).  The results are unpacked lazily, like the reference's cache_forward_.
+void PhyloHMM::InitializePhyloEmission() {
+  Require(have_tree_, "InitializePhyloParameters must be called first");
+  CreateFamily();
+  const int T = tree_.n_tips;
+  std::vector<int32_t> ops((std::size_t)(T - 2) * 4);
+  int32_t depth = 0;
+  CheckHip(lh_schedule_tree(T, tree_.children.data(), tree_.root, ops.data(), &depth), "lh_schedule_tree");
+  xmsa_emission_.assign(xmsa_.cols(), 0.0);
+  pending_forward_.assign(lh_forward_size(family_), 0.0);
+  pending_scalers_.assign(lh_scaler_size(family_), 0);
+  lh_eval_outputs outs{sr_.data(), xmsa_emission_.data(), pending_forward_.data(), pending_scalers_.data()};
+  CheckHip(lh_eval_batch(family_, 1, T, depth, ops.data(), tree_.brlen.data(), er_.data(), pi_.data(), &alpha_,
+                         num_rates_, &pending_loglik_, &outs),
+           "lh_eval_batch");
+  cache_forward_ = true;
+}
+
+void PhyloHMM::RunForwardAlgorithm() {
+  UnpackForward(pending_forward_.data(), pending_scalers_.data());
+  loglikelihood_ = pending_loglik_;
+}
+
+// src/PhyloHMM.cpp:244-282
+void PhyloHMM::WriteOutputHeaders(std::ofstream& outfile) const {
+  outfile << "Iteration\tRBLogLikelihood\tPrior\talpha\t";
+  for (std::size_t i = 1; i <= er_.size(); i++) outfile << ("er[" + std::to_string(i) + "]\t");
+  for (std::size_t i = 1; i <= pi_.size(); i++) outfile << ("pi[" + std::to_string(i) + "]\t");
+  outfile << "tree\t";
+  for (std::size_t i = 1; i <= sr_.size(); i++) outfile << ("sr[" + std::to_string(i) + "]\t");
+  outfile << "LHLogLikelihood\tLogWeight\tNaiveSequence\tVGene\tV5pDel\tV3pDel\tVFwkInsertion\t";
+  if (locus_ == "igh") {
+    outfile << "VDInsertion\tDGene\tD5pDel\tD3pDel\tDJInsertion\t";
+  } else {
+    outfile << "VJInsertion\t";
+  }
+  outfile << "JGene\tJ5pDel\tJ3pDel\tJFwkInsertion\n";
+}
+
+// src/PhyloHMM.cpp:288-327
+void PhyloHMM::WriteOutputLine(std::ofstream& outfile) const {
+  outfile << iteration_ << "\t" << rb_loglikelihood_ << "\t" << prior_ << "\t" << alpha_ << "\t";
+  for (auto er : er_) outfile << er << "\t";
+  for (auto pi : pi_) outfile << pi << "\t";
+  outfile << ExportNewick(tree_, xmsa_labels_) << "\t";
+  for (auto sr : sr_) outfile << sr << "\t";
+  outfile << lh_loglikelihood_ << "\t" << logweight_ << "\t" << naive_sequence_ << "\t";
+  outfile << vgerm_state_str_samp_ << "\t" << vgerm_left_del_samp_ << "\t" << vgerm_right_del_samp_ << "\t"
+          << vgerm_left_insertion_samp_ << "\t";
+  if (locus_ == "igh") {
+    outfile << vd_junction_insertion_samp_ << "\t" << dgerm_state_str_samp_ << "\t" << dgerm_left_del_samp_ << "\t"
+            << dgerm_right_del_samp_ << "\t" << dj_junction_insertion_samp_ << "\t";
+  } else {
+    outfile << vd_junction_insertion_samp_ << "\t";
+  }
+  outfile << jgerm_state_str_samp_ << "\t" << jgerm_left_del_samp_ << "\t" << jgerm_right_del_samp_ << "\t"
+          << jgerm_right_insertion_samp_ << "\n";
+}
+
+namespace {
+
+// One row of the RevBayes table (io::CSVReader<15, trim_chars<>, double_quote_escape<'\t','"'>>,
+// src/PhyloHMM.cpp:396-400): tab separated, optional double quotes, extra columns ignored.
+std::vector<std::string> SplitTsv(const std::string& line) {
+  std::vector<std::string> out;
+  std::string cur;
+  bool quoted = false;
+  for (std::size_t i = 0; i < line.size(); ++i) {
+    const char c = line[i];
+    if (c == '"') {
+      if (quoted && i + 1 < line.size() && line[i + 1] == '"') {
+        cur.push_back('"');
+        ++i;
+      } else {
+        quoted = !quoted;
+      }
+    } else if (c == '\t' && !quoted) {
+      out.push_back(cur);
+      cur.clear();
+    } else if (c != '\r') {
+      cur.push_back(c);
+    }
+  }
+  out.push_back(cur);
+  return out;
+}
+
+}  // namespace
+
+// src/PhyloHMM.cpp:393-446.  The reference evaluates row by row; here the whole table is evaluated
+// on the GPU in batches, then naive sequences are sampled on the host strictly in file order (one
+// std::mt19937 stream, src/HMM.cpp:56) and the rows are written.
+void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& output_path, int num_rates) {
+  std::ifstream in(input_path);
+  if (!in) throw std::runtime_error("Can't open RevBayes output file " + input_path);
+  std::string line;
+  if (!std::getline(in, line)) throw std::runtime_error("Empty RevBayes output file " + input_path);
+  const std::vector<std::string> header = SplitTsv(line);
+  const char* names[15] = {"Iteration", "Likelihood", "Prior", "alpha", "er[1]", "er[2]", "er[3]", "er[4]",
+                           "er[5]",     "er[6]",      "pi[1]", "pi[2]", "pi[3]", "pi[4]", "tree"};
+  int col[15];
+  for (int k = 0; k < 15; ++k) {
+    const auto it = std::find(header.begin(), header.end(), names[k]);
+    if (it == header.end()) throw std::runtime_error(std::string("Missing column \"") + names[k] + "\" in " + input_path);
+    col[k] = (int)(it - header.begin());
+  }
+  struct Row {
+    int iteration;
+    double lik, prior;
+    TreeSample ts;
+  };
+  std::vector<Row> rows;
+  while (std::getline(in, line)) {
+    if (line.empty()) continue;
+    const std::vector<std::string> f = SplitTsv(line);
+    Row r;
+    auto get = [&](int k) -> const std::string& {
+      if (col[k] >= (int)f.size()) throw std::runtime_error("Too few columns in " + input_path);
+      return f[col[k]];
+    };
+    r.iteration = std::stoi(get(0));
+    r.lik = std::stod(get(1));
+    r.prior = std::stod(get(2));
+    r.ts.alpha = std::stod(get(3));
+    for (int k = 0; k < 6; ++k) r.ts.er.push_back(std::stod(get(4 + k)));
+    for (int k = 0; k < 4; ++k) r.ts.pi.push_back(std::stod(get(10 + k)));
+    r.ts.newick = get(14);
+    rows.push_back(std::move(r));
+  }
+
+  CreateFamily();
+  std::ofstream outfile(output_path);
+  if (!outfile) throw std::runtime_error("Can't open output file " + output_path);
+  er_.assign(6, 0.0);
+  pi_.assign(4, 0.0);
+  sr_.assign(num_rates, 0.0);
+  num_rates_ = num_rates;
+  const std::size_t kBatch = 1024;
+  const std::size_t FS = lh_forward_size(family_), SS = lh_scaler_size(family_);
+  int line_ind = 0;
+  for (std::size_t off = 0; off < rows.size(); off += kBatch) {
+    const std::size_t m = std::min(kBatch, rows.size() - off);
+    std::vector<TreeSample> samples;
+    for (std::size_t i = 0; i < m; ++i) samples.push_back(rows[off + i].ts);
+    const DeviceBatch b = FlattenBatch(samples);
+    std::vector<double> ll(m), rates(m * num_rates), fwd(m * FS);
+    std::vector<int32_t> sco(m * SS);
+    lh_eval_outputs outs{rates.data(), nullptr, fwd.data(), sco.data()};
+    CheckHip(lh_eval_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(),
+                           b.pi.data(), b.alpha.data(), num_rates, ll.data(), &outs),
+             "lh_eval_batch");
+    for (std::size_t i = 0; i < m; ++i) {
+      const Row& r = rows[off + i];
+      iteration_ = r.iteration;
+      rb_loglikelihood_ = r.lik;
+      prior_ = r.prior;
+      alpha_ = r.ts.alpha;
+      er_ = r.ts.er;
+      pi_ = r.ts.pi;
+      tree_ = ParseNewick(r.ts.newick, xmsa_labels_, EPS);
+      have_tree_ = true;
+      sr_.assign(rates.begin() + i * num_rates, rates.begin() + (i + 1) * num_rates);
+      pending_forward_.assign(fwd.begin() + i * FS, fwd.begin() + (i + 1) * FS);
+      pending_scalers_.assign(sco.begin() + i * SS, sco.begin() + (i + 1) * SS);
+      pending_loglik_ = ll[i];
+      cache_forward_ = true;
+      lh_loglikelihood_ = LogLikelihood();
+      logweight_ = lh_loglikelihood_ - rb_loglikelihood_;
+      naive_sequence_ = SampleNaiveSequence();
+      if (line_ind == 0) WriteOutputHeaders(outfile);
+      WriteOutputLine(outfile);
+      line_ind += 1;
+    }
+  }
+  outfile.close();
+}
+
+// src/PhyloHMM.cpp:461-471
+void StoreGermlinePaddingXmsaIndices(const std::vector<int>& naive_bases, const std::vector<int>& site_inds,
+                                     std::map<std::pair<int, int>, int>& xmsa_ids, VectorXi& xmsa_inds) {
+  xmsa_inds.assign(naive_bases.size(), -1);
+  for (std::size_t i = 0; i < naive_bases.size(); i++)
+    StoreXmsaIndex({naive_bases[i], site_inds[i]}, xmsa_ids, xmsa_inds[i]);
+}
+
+// src/PhyloHMM.cpp:489-513
+void StoreJunctionXmsaIndices(const std::vector<int>& naive_bases, const std::vector<int>& site_inds,
+                              std::pair<int, int> left_flexbounds, std::pair<int, int> right_flexbounds,
+                              std::map<std::pair<int, int>, int>& xmsa_ids, MatrixXi& xmsa_inds) {
+  const int site_start = left_flexbounds.first, site_end = right_flexbounds.second;
+  xmsa_inds.setConstant(site_end - site_start, (int)naive_bases.size(), -1);
+  for (std::size_t i = 0; i < naive_bases.size(); i++) {
+    if (site_inds[i] == -1) {
+      for (int site_ind = site_start; site_ind < site_end; site_ind++)
+        StoreXmsaIndex({naive_bases[i], site_ind}, xmsa_ids, xmsa_inds(site_ind - site_start, (int)i));
+    } else {
+      StoreXmsaIndex({naive_bases[i], site_inds[i]}, xmsa_ids, xmsa_inds(site_inds[i] - site_start, (int)i));
+    }
+  }
+}
+
+// src/PhyloHMM.cpp:523-536
+void StoreXmsaIndex(std::pair<int, int> id, std::map<std::pair<int, int>, int>& xmsa_ids, int& xmsa_ind) {
+  const int next = (int)xmsa_ids.size();
+  auto res = xmsa_ids.emplace(id, next);
+  xmsa_ind = res.first->second;
+}
+
+}  // namespace linearham

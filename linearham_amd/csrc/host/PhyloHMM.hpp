@@ -1,0 +1,119 @@
+// PhyloHMM of the MI355X-native linearham host (class surface of src/PhyloHMM.hpp:23-126).
+// Per tree sample the reference builds a libpll partition, prunes every xMSA column, fills the
+// emission matrices and runs the forward algorithm on one CPU core; here all of that is ONE batched
+// call into the HIP library (lh_eval_batch) and this class only prepares inputs / unpacks outputs.
+#ifndef LINEARHAM_PHYLOHMM_
+#define LINEARHAM_PHYLOHMM_
+
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "HMM.hpp"
+#include "newick.hpp"
+
+namespace linearham {
+
+class PhyloHMM : public HMM {
+ private:
+  MatrixXi xmsa_;
+  std::vector<std::string> xmsa_labels_, xmsa_seqs_;
+  int xmsa_naive_ind_ = 0;
+  VectorXd xmsa_emission_;
+  VectorXi vpadding_xmsa_inds_, vgerm_xmsa_inds_, dgerm_xmsa_inds_, jgerm_xmsa_inds_, jpadding_xmsa_inds_;
+  MatrixXi vd_junction_xmsa_inds_, dj_junction_xmsa_inds_;
+  std::vector<int32_t> xmsa_site_;       // MSA site of each xMSA column
+  std::vector<uint8_t> xmsa_base_;       // naive base of each xMSA column
+
+  int iteration_ = 0;
+  double rb_loglikelihood_ = 0, prior_ = 0, alpha_ = 1.0;
+  std::vector<double> er_, pi_, sr_;
+  TreeArrays tree_;
+  bool have_tree_ = false;
+  int num_rates_ = 1;
+  double lh_loglikelihood_ = 0, logweight_ = 0;
+  std::string naive_sequence_;
+
+  // raw device outputs of the pending evaluation (unpacked by RunForwardAlgorithm)
+  std::vector<double> pending_forward_;
+  std::vector<int32_t> pending_scalers_;
+  double pending_loglik_ = 0;
+
+  void InitializeXmsaStructs();
+  void CreateFamily();
+  void RunForwardAlgorithm() override;
+  void WriteOutputHeaders(std::ofstream& outfile) const;
+  void WriteOutputLine(std::ofstream& outfile) const;
+
+ public:
+  PhyloHMM(const std::string& yaml_path, int cluster_ind, const std::string& hmm_param_dir, int seed);
+
+  const MatrixXi& xmsa() const { return xmsa_; }
+  const std::vector<std::string>& xmsa_labels() const { return xmsa_labels_; }
+  const std::vector<std::string>& xmsa_seqs() const { return xmsa_seqs_; }
+  int xmsa_naive_ind() const { return xmsa_naive_ind_; }
+  const VectorXd& xmsa_emission() const { return xmsa_emission_; }
+  const VectorXi& vpadding_xmsa_inds() const { return vpadding_xmsa_inds_; }
+  const VectorXi& vgerm_xmsa_inds() const { return vgerm_xmsa_inds_; }
+  const MatrixXi& vd_junction_xmsa_inds() const { return vd_junction_xmsa_inds_; }
+  const VectorXi& dgerm_xmsa_inds() const { return dgerm_xmsa_inds_; }
+  const MatrixXi& dj_junction_xmsa_inds() const { return dj_junction_xmsa_inds_; }
+  const VectorXi& jgerm_xmsa_inds() const { return jgerm_xmsa_inds_; }
+  const VectorXi& jpadding_xmsa_inds() const { return jpadding_xmsa_inds_; }
+  int iteration() const { return iteration_; }
+  double rb_loglikelihood() const { return rb_loglikelihood_; }
+  double prior() const { return prior_; }
+  double alpha() const { return alpha_; }
+  const std::vector<double>& er() const { return er_; }
+  const std::vector<double>& pi() const { return pi_; }
+  const TreeArrays& tree() const { return tree_; }
+  /// Discrete-Gamma category rates; computed on the device, valid after InitializePhyloEmission().
+  const std::vector<double>& sr() const { return sr_; }
+  double lh_loglikelihood() const { return lh_loglikelihood_; }
+  double logweight() const { return logweight_; }
+  const std::string& naive_sequence() const { return naive_sequence_; }
+
+  void InitializePhyloParameters(const std::string& newick_path, const std::vector<double>& er,
+                                 const std::vector<double>& pi, double alpha, int num_rates);
+  /// Same with the Newick text given directly (RunPipeline rows).
+  void InitializePhyloParametersFromString(const std::string& newick, const std::vector<double>& er,
+                                           const std::vector<double>& pi, double alpha, int num_rates);
+  void InitializePhyloEmission();
+  void RunPipeline(const std::string& input_path, const std::string& output_path, int num_rates);
+
+  /// Batched log-likelihoods of many tree samples (the GPU-native entry point RunPipeline uses).
+  /// Rows are (newick, er[6], pi[4], alpha).  Returns HMM::LogLikelihood() per row.
+  struct TreeSample {
+    std::string newick;
+    std::vector<double> er, pi;
+    double alpha;
+  };
+  std::vector<double> LogLikelihoodBatch(const std::vector<TreeSample>& samples, int num_rates);
+
+  /// Flattened device inputs of a batch (used by LogLikelihoodBatch and by the benchmark harness).
+  struct DeviceBatch {
+    int n = 0, n_tips = 0, max_depth = 0;
+    std::vector<int32_t> ops;
+    std::vector<double> brlen, er, pi, alpha;
+  };
+  DeviceBatch FlattenBatch(const std::vector<TreeSample>& samples) const;
+  lh_family* family() {
+    CreateFamily();
+    return family_;
+  }
+  int n_xmsa() const { return xmsa_.cols(); }
+};
+
+typedef std::shared_ptr<PhyloHMM> PhyloHMMPtr;
+
+void StoreGermlinePaddingXmsaIndices(const std::vector<int>& naive_bases, const std::vector<int>& site_inds,
+                                     std::map<std::pair<int, int>, int>& xmsa_ids, VectorXi& xmsa_inds);
+void StoreJunctionXmsaIndices(const std::vector<int>& naive_bases, const std::vector<int>& site_inds,
+                              std::pair<int, int> left_flexbounds, std::pair<int, int> right_flexbounds,
+                              std::map<std::pair<int, int>, int>& xmsa_ids, MatrixXi& xmsa_inds);
+void StoreXmsaIndex(std::pair<int, int> id, std::map<std::pair<int, int>, int>& xmsa_ids, int& xmsa_ind);
+
+}  // namespace linearham
+
+#endif  // LINEARHAM_PHYLOHMM_

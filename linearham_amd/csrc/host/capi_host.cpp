@@ -1,0 +1,328 @@
+// Test/bench-facing C entry points of liblinearham_host.so: construct the C++ host classes and dump
+// their accessors as JSON so that the pytest suite can compare them with the reference's goldens
+// (test/test.cpp) -- the role the Catch binary plays upstream.
+#include <cstring>
+#include <iomanip>
+#include <sstream>
+#include <string>
+
+#include "PhyloHMM.hpp"
+#include "SimpleHMM.hpp"
+
+using namespace linearham;
+
+namespace {
+
+thread_local std::string g_err, g_out;
+
+struct Json {
+  std::ostringstream o;
+  bool first = true;
+  Json() { o << std::setprecision(17); }
+  void key(const std::string& k) {
+    o << (first ? "{" : ",") << "\"" << k << "\":";
+    first = false;
+  }
+  static std::string esc(const std::string& s) {
+    std::string r = "\"";
+    for (char c : s) {
+      if (c == '"' || c == '\\') r.push_back('\\');
+      r.push_back(c);
+    }
+    return r + "\"";
+  }
+  void num(double v) {
+    if (std::isnan(v)) o << "NaN";
+    else if (std::isinf(v)) o << (v > 0 ? "Infinity" : "-Infinity");
+    else o << v;
+  }
+  void put(const std::string& k, const std::string& v) { key(k); o << esc(v); }
+  void put(const std::string& k, int v) { key(k); o << v; }
+  void put(const std::string& k, bool v) { key(k); o << (v ? "true" : "false"); }
+  void put(const std::string& k, double v) { key(k); num(v); }
+  void put(const std::string& k, const std::vector<int>& v) {
+    key(k); o << "[";
+    for (std::size_t i = 0; i < v.size(); ++i) o << (i ? "," : "") << v[i];
+    o << "]";
+  }
+  void put(const std::string& k, const std::vector<double>& v) {
+    key(k); o << "[";
+    for (std::size_t i = 0; i < v.size(); ++i) { if (i) o << ","; num(v[i]); }
+    o << "]";
+  }
+  void put(const std::string& k, const std::vector<std::string>& v) {
+    key(k); o << "[";
+    for (std::size_t i = 0; i < v.size(); ++i) o << (i ? "," : "") << esc(v[i]);
+    o << "]";
+  }
+  void put(const std::string& k, const std::vector<GermlineType>& v) {
+    key(k); o << "[";
+    for (std::size_t i = 0; i < v.size(); ++i)
+      o << (i ? "," : "") << (v[i] == GermlineType::V ? "\"V\"" : v[i] == GermlineType::D ? "\"D\"" : "\"J\"");
+    o << "]";
+  }
+  template <typename T>
+  void put(const std::string& k, const Matrix<T>& m) {
+    key(k); o << "[";
+    for (int r = 0; r < m.rows(); ++r) {
+      o << (r ? ",[" : "[");
+      for (int c = 0; c < m.cols(); ++c) { if (c) o << ","; num((double)m(r, c)); }
+      o << "]";
+    }
+    o << "]";
+  }
+  void put(const std::string& k, const GeneRanges& g) {
+    key(k); o << "{";
+    bool f = true;
+    for (const auto& kv : g) {
+      o << (f ? "" : ",") << esc(kv.first) << ":[" << kv.second.first << "," << kv.second.second << "]";
+      f = false;
+    }
+    o << "}";
+  }
+  void put(const std::string& k, const std::map<std::string, int>& g) {
+    key(k); o << "{";
+    bool f = true;
+    for (const auto& kv : g) { o << (f ? "" : ",") << esc(kv.first) << ":" << kv.second; f = false; }
+    o << "}";
+  }
+  std::string str() { return first ? "{}" : o.str() + "}"; }
+};
+
+void DumpHMM(const HMM& h, Json& j) {
+  j.put("locus", h.locus());
+  j.put("flexbounds", GeneRanges(h.flexbounds().begin(), h.flexbounds().end()));
+  j.put("relpos", h.relpos());
+  j.put("alphabet", h.alphabet());
+  j.put("msa", h.msa());
+#define DUMP(name) j.put(#name, h.name());
+  DUMP(vpadding_ggene_ranges) DUMP(vpadding_naive_bases) DUMP(vpadding_site_inds)
+  DUMP(vgerm_state_strs) DUMP(vgerm_left_del) DUMP(vgerm_right_del) DUMP(vgerm_ggene_ranges)
+  DUMP(vgerm_naive_bases) DUMP(vgerm_germ_inds) DUMP(vgerm_site_inds)
+  DUMP(vd_junction_state_strs) DUMP(vd_junction_del) DUMP(vd_junction_ggene_types)
+  DUMP(vd_junction_ggene_ranges) DUMP(vd_junction_naive_bases) DUMP(vd_junction_germ_inds)
+  DUMP(vd_junction_site_inds)
+  DUMP(dgerm_state_strs) DUMP(dgerm_left_del) DUMP(dgerm_right_del) DUMP(dgerm_ggene_ranges)
+  DUMP(dgerm_naive_bases) DUMP(dgerm_germ_inds) DUMP(dgerm_site_inds)
+  DUMP(dj_junction_state_strs) DUMP(dj_junction_del) DUMP(dj_junction_ggene_types)
+  DUMP(dj_junction_ggene_ranges) DUMP(dj_junction_naive_bases) DUMP(dj_junction_germ_inds)
+  DUMP(dj_junction_site_inds)
+  DUMP(jgerm_state_strs) DUMP(jgerm_left_del) DUMP(jgerm_right_del) DUMP(jgerm_ggene_ranges)
+  DUMP(jgerm_naive_bases) DUMP(jgerm_germ_inds) DUMP(jgerm_site_inds)
+  DUMP(jpadding_ggene_ranges) DUMP(jpadding_naive_bases) DUMP(jpadding_site_inds)
+  DUMP(vpadding_transition) DUMP(vgerm_vd_junction_transition) DUMP(vd_junction_transition)
+  DUMP(vd_junction_dgerm_transition) DUMP(dgerm_dj_junction_transition) DUMP(dj_junction_transition)
+  DUMP(dj_junction_jgerm_transition) DUMP(jpadding_transition) DUMP(cache_forward)
+}
+
+void DumpForward(const HMM& h, Json& j) {
+  DUMP(vgerm_forward) DUMP(vd_junction_forward) DUMP(dgerm_forward) DUMP(dj_junction_forward) DUMP(jgerm_forward)
+  DUMP(vgerm_scaler_count) DUMP(vd_junction_scaler_counts) DUMP(dgerm_scaler_count)
+  DUMP(dj_junction_scaler_counts) DUMP(jgerm_scaler_count)
+}
+
+void DumpSample(const HMM& h, Json& j) {
+  DUMP(naive_seq_samp) DUMP(vgerm_state_str_samp) DUMP(vgerm_state_ind_samp) DUMP(vgerm_left_del_samp)
+  DUMP(vgerm_right_del_samp) DUMP(vgerm_left_insertion_samp) DUMP(vd_junction_state_str_samps)
+  DUMP(vd_junction_state_ind_samps) DUMP(vd_junction_insertion_samp) DUMP(dgerm_state_str_samp)
+  DUMP(dgerm_state_ind_samp) DUMP(dgerm_left_del_samp) DUMP(dgerm_right_del_samp)
+  DUMP(dj_junction_state_str_samps) DUMP(dj_junction_state_ind_samps) DUMP(dj_junction_insertion_samp)
+  DUMP(jgerm_state_str_samp) DUMP(jgerm_state_ind_samp) DUMP(jgerm_left_del_samp) DUMP(jgerm_right_del_samp)
+  DUMP(jgerm_right_insertion_samp)
+}
+
+void DumpPhylo(const PhyloHMM& h, Json& j) {
+  DUMP(xmsa) DUMP(xmsa_labels) DUMP(xmsa_seqs) DUMP(xmsa_naive_ind) DUMP(vpadding_xmsa_inds) DUMP(vgerm_xmsa_inds)
+  DUMP(vd_junction_xmsa_inds) DUMP(dgerm_xmsa_inds) DUMP(dj_junction_xmsa_inds) DUMP(jgerm_xmsa_inds)
+  DUMP(jpadding_xmsa_inds)
+}
+#undef DUMP
+
+template <typename F>
+int Guard(F f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lhh_last_error() { return g_err.c_str(); }
+
+// Germline parameter parsing only (no GPU): JSON of one allele file parsed as V, D or J.
+int lhh_germline_json(const char* yaml_path, char type, const char** out) {
+  return Guard([&] {
+    const yaml_lite::Node root = yaml_lite::LoadFile(yaml_path);
+    Json j;
+    const Germline g(root);
+    j.put("landing_in", g.landing_in());
+    j.put("landing_out", g.landing_out());
+    j.put("transition", g.transition());
+    j.put("gene_prob", g.gene_prob());
+    j.put("alphabet", g.alphabet());
+    j.put("name", g.name());
+    j.put("emission", g.emission());
+    j.put("bases", g.bases());
+    j.put("length", g.length());
+    if (type == 'D' || type == 'J') {
+      const NTInsertion n(root);
+      j.put("nti_landing_in", n.nti_landing_in());
+      j.put("nti_landing_out", n.nti_landing_out());
+      j.put("nti_transition", n.nti_transition());
+      j.put("nti_emission", n.nti_emission());
+    }
+    if (type == 'V' || type == 'J') {
+      const NPadding p(root);
+      j.put("n_transition", p.n_transition());
+      j.put("n_emission", p.n_emission());
+    }
+    g_out = j.str();
+    *out = g_out.c_str();
+  });
+}
+
+int lhh_simple_create(const char* yaml, int cluster_ind, const char* dir, int seed, void** out) {
+  return Guard([&] { *out = new SimpleHMM(yaml, cluster_ind, dir, seed); });
+}
+int lhh_phylo_create(const char* yaml, int cluster_ind, const char* dir, int seed, void** out) {
+  return Guard([&] { *out = static_cast<HMM*>(new PhyloHMM(yaml, cluster_ind, dir, seed)); });
+}
+void lhh_destroy(void* h) { delete static_cast<HMM*>(h); }
+
+int lhh_phylo_init_parameters(void* h, const char* newick_path, const double* er, const double* pi, double alpha,
+                              int num_rates) {
+  return Guard([&] {
+    dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h))
+        .InitializePhyloParameters(newick_path, std::vector<double>(er, er + 6), std::vector<double>(pi, pi + 4),
+                                   alpha, num_rates);
+  });
+}
+int lhh_phylo_init_parameters_str(void* h, const char* newick, const double* er, const double* pi, double alpha,
+                                  int num_rates) {
+  return Guard([&] {
+    dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h))
+        .InitializePhyloParametersFromString(newick, std::vector<double>(er, er + 6),
+                                             std::vector<double>(pi, pi + 4), alpha, num_rates);
+  });
+}
+int lhh_phylo_init_emission(void* h) {
+  return Guard([&] { dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h)).InitializePhyloEmission(); });
+}
+int lhh_loglikelihood(void* h, double* out) {
+  return Guard([&] { *out = static_cast<HMM*>(h)->LogLikelihood(); });
+}
+int lhh_sample(void* h, const char** out) {
+  return Guard([&] {
+    g_out = static_cast<HMM*>(h)->SampleNaiveSequence();
+    *out = g_out.c_str();
+  });
+}
+int lhh_run_pipeline(void* h, const char* input_path, const char* output_path, int num_rates) {
+  return Guard([&] { dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h)).RunPipeline(input_path, output_path, num_rates); });
+}
+// what: bit 0 = state space + transitions, bit 1 = forward arrays, bit 2 = sample, bit 3 = xMSA structures
+int lhh_dump_json(void* h, int what, const char** out) {
+  return Guard([&] {
+    HMM* hmm = static_cast<HMM*>(h);
+    Json j;
+    if (what & 1) DumpHMM(*hmm, j);
+    if (what & 2) DumpForward(*hmm, j);
+    if (what & 4) DumpSample(*hmm, j);
+    if (what & 8) {
+      PhyloHMM& p = dynamic_cast<PhyloHMM&>(*hmm);
+      DumpPhylo(p, j);
+      j.put("xmsa_emission", p.xmsa_emission());
+      j.put("sr", p.sr());
+      j.put("er", p.er());
+      j.put("pi", p.pi());
+      j.put("alpha", p.alpha());
+    }
+    g_out = j.str();
+    *out = g_out.c_str();
+  });
+}
+
+// Flatten a RevBayes table into the device inputs of lh_eval_batch_device (bench.py): fills
+// caller-allocated arrays; returns max_depth through *max_depth.  n rows are taken cyclically from
+// the table.  ops [n][T-2][4], brlen [n][2T-2], er [n][6], pi [n][4], alpha [n].
+int lhh_phylo_flatten_tsv(void* h, const char* tsv_path, int n, int32_t* ops, double* brlen, double* er,
+                          double* pi, double* alpha, int* n_tips, int* max_depth, int* n_rows_in_file,
+                          int need_family, void** family) {
+  return Guard([&] {
+    PhyloHMM& p = dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h));
+    std::ifstream in(tsv_path);
+    if (!in) throw std::runtime_error(std::string("Can't open ") + tsv_path);
+    std::string line;
+    std::getline(in, line);
+    std::vector<std::string> header;
+    {
+      std::stringstream ss(line);
+      std::string f;
+      while (std::getline(ss, f, '\t')) header.push_back(f);
+    }
+    auto colidx = [&](const std::string& name) {
+      for (std::size_t i = 0; i < header.size(); ++i)
+        if (header[i] == name) return (int)i;
+      throw std::runtime_error("Missing column " + name);
+    };
+    const int c_alpha = colidx("alpha"), c_tree = colidx("tree");
+    int c_er[6], c_pi[4];
+    for (int k = 0; k < 6; ++k) c_er[k] = colidx("er[" + std::to_string(k + 1) + "]");
+    for (int k = 0; k < 4; ++k) c_pi[k] = colidx("pi[" + std::to_string(k + 1) + "]");
+    std::vector<PhyloHMM::TreeSample> rows;
+    while (std::getline(in, line)) {
+      if (line.empty()) continue;
+      std::vector<std::string> f;
+      std::stringstream ss(line);
+      std::string x;
+      while (std::getline(ss, x, '\t')) f.push_back(x);
+      PhyloHMM::TreeSample ts;
+      ts.alpha = std::stod(f.at(c_alpha));
+      for (int k = 0; k < 6; ++k) ts.er.push_back(std::stod(f.at(c_er[k])));
+      for (int k = 0; k < 4; ++k) ts.pi.push_back(std::stod(f.at(c_pi[k])));
+      ts.newick = f.at(c_tree);
+      rows.push_back(ts);
+    }
+    if (rows.empty()) throw std::runtime_error("no rows in table");
+    *n_rows_in_file = (int)rows.size();
+    const PhyloHMM::DeviceBatch b = p.FlattenBatch(rows);
+    *n_tips = b.n_tips;
+    *max_depth = b.max_depth;
+    *family = need_family ? p.family() : nullptr;
+    if (n > 0 && ops) {
+      const std::size_t T = b.n_tips, no = (T - 2) * 4, nb = 2 * T - 2;
+      for (int s = 0; s < n; ++s) {
+        const std::size_t r = s % rows.size();
+        std::memcpy(ops + s * no, b.ops.data() + r * no, no * sizeof(int32_t));
+        std::memcpy(brlen + s * nb, b.brlen.data() + r * nb, nb * sizeof(double));
+        std::memcpy(er + s * 6, b.er.data() + r * 6, 6 * sizeof(double));
+        std::memcpy(pi + s * 4, b.pi.data() + r * 4, 4 * sizeof(double));
+        alpha[s] = b.alpha[r];
+      }
+    }
+  });
+}
+
+int lhh_phylo_sizes(void* h, int* n_tips, int* n_sites, int* n_xmsa, int* s_vd, int* s_dj, int* w_vd, int* w_dj,
+                    int* g_total) {
+  return Guard([&] {
+    PhyloHMM& p = dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h));
+    *n_tips = p.msa().rows() + 1;
+    *n_sites = p.msa().cols();
+    *n_xmsa = p.n_xmsa();
+    *s_vd = (int)p.vd_junction_state_strs().size();
+    *s_dj = (int)p.dj_junction_state_strs().size();
+    *w_vd = p.vd_junction_xmsa_inds().rows();
+    *w_dj = p.dj_junction_xmsa_inds().rows();
+    *g_total = (int)(p.vpadding_xmsa_inds().size() + p.vgerm_xmsa_inds().size() + p.dgerm_xmsa_inds().size() +
+                     p.jgerm_xmsa_inds().size() + p.jpadding_xmsa_inds().size());
+  });
+}
+
+}  // extern "C"

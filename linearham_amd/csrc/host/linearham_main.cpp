@@ -1,0 +1,86 @@
+// `linearham` command line (same sub-commands and flag names as src/linearham.cpp:268-455 of the
+// reference, without TCLAP): --compute-logl | --sample | --pipeline.
+#include <cstdlib>
+#include <iostream>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "PhyloHMM.hpp"
+
+namespace {
+
+struct Args {
+  std::map<std::string, std::vector<std::string>> v;
+  const std::string& one(const std::string& k) const {
+    auto it = v.find(k);
+    if (it == v.end() || it->second.empty()) throw std::invalid_argument("Required argument missing: " + k);
+    if (it->second.size() > 1) throw std::invalid_argument("Argument already set! for arg --" + k);
+    return it->second[0];
+  }
+  std::string opt(const std::string& k, const std::string& dflt) const {
+    auto it = v.find(k);
+    return (it == v.end() || it->second.empty()) ? dflt : it->second.back();
+  }
+  std::vector<double> multi(const std::string& k) const {
+    auto it = v.find(k);
+    if (it == v.end() || it->second.empty()) throw std::invalid_argument("Required argument missing: " + k);
+    std::vector<double> out;
+    for (const auto& s : it->second) out.push_back(std::stod(s));
+    return out;
+  }
+};
+
+Args Parse(int argc, char** argv, int first) {
+  Args a;
+  for (int i = first; i < argc; ++i) {
+    std::string k = argv[i];
+    if (k.rfind("--", 0) != 0) throw std::invalid_argument("Couldn't find match for argument " + k);
+    k = k.substr(2);
+    if (i + 1 >= argc) throw std::invalid_argument("Missing a value for this argument! --" + k);
+    a.v[k].push_back(argv[++i]);
+  }
+  return a;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  try {
+    if (argc < 2 || std::string(argv[1]) == "-h" || std::string(argv[1]) == "--help") {
+      std::cout << "A Phylo-HMM implementation for B cell receptor sequence analysis.\n"
+                   "USAGE: linearham {--compute-logl|--sample|--pipeline} --yaml-path <string> --cluster-ind <int> "
+                   "--hmm-param-dir <string> [--seed <int>] [--num-rates <int>] ...\n";
+      return argc < 2 ? EXIT_FAILURE : EXIT_SUCCESS;
+    }
+    const std::string subcmd = argv[1];
+    const Args a = Parse(argc, argv, 2);
+    if (subcmd != "--compute-logl" && subcmd != "--sample" && subcmd != "--pipeline")
+      throw std::invalid_argument("'" + subcmd + "' is not a valid subcommand.");
+    const std::string yaml_path = a.one("yaml-path");
+    const int cluster_ind = std::stoi(a.one("cluster-ind"));
+    const std::string hmm_param_dir = a.one("hmm-param-dir");
+    const int seed = std::stoi(a.opt("seed", "0"));
+    const int num_rates = std::stoi(a.opt("num-rates", "1"));
+    linearham::PhyloHMMPtr phylo_hmm_ptr =
+        std::make_shared<linearham::PhyloHMM>(yaml_path, cluster_ind, hmm_param_dir, seed);
+    if (subcmd == "--pipeline") {
+      phylo_hmm_ptr->RunPipeline(a.one("input-path"), a.one("output-path"), num_rates);
+      return EXIT_SUCCESS;
+    }
+    phylo_hmm_ptr->InitializePhyloParameters(a.one("newick-path"), a.multi("er"), a.multi("pi"),
+                                             std::stod(a.opt("alpha", "1.0")), num_rates);
+    phylo_hmm_ptr->InitializePhyloEmission();
+    if (subcmd == "--compute-logl") {
+      std::cout << phylo_hmm_ptr->LogLikelihood() << std::endl;
+    } else {
+      const int N = std::stoi(a.opt("N", "1"));
+      for (int i = 0; i < N; i++) std::cout << phylo_hmm_ptr->SampleNaiveSequence() << std::endl;
+    }
+    return EXIT_SUCCESS;
+  } catch (const std::exception& e) {
+    std::cerr << "ERROR: " << e.what() << std::endl;
+  }
+  return EXIT_FAILURE;
+}

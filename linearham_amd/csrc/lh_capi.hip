@@ -117,7 +117,7 @@ int upload_junction(lh_family* f, const lh_junction& j, int n_xmsa, lh::DevJunct
   d->n_right = j.n_right;
   if (check_idx(j.left_xmsa, W * nL, n_xmsa, true, "left_xmsa")) return 1;
   if (check_idx(j.right_xmsa, W * nR, n_xmsa, true, "right_xmsa")) return 1;
-  if (check_idx(j.nti_xmsa, W * 4, n_xmsa, nR == 0, "nti_xmsa")) return 1;
+  if (check_idx(j.nti_xmsa, W * nR * 4, n_xmsa, false, "nti_xmsa")) return 1;
   if (upload(f, j.enter_trans, nL, &d->enter_trans)) return 1;
   if (upload(f, j.enter_lo, nL, &d->enter_lo)) return 1;
   if (upload(f, j.left_trans, W * nL, &d->left_trans)) return 1;
@@ -129,7 +129,7 @@ int upload_junction(lh_family* f, const lh_junction& j, int n_xmsa, lh::DevJunct
   if (upload(f, j.right_trans, W * nR, &d->right_trans)) return 1;
   if (upload(f, j.right_gp_li, W * nR, &d->right_gp_li)) return 1;
   if (upload(f, j.right_xmsa, W * nR, &d->right_xmsa)) return 1;
-  if (upload(f, j.nti_xmsa, W * 4, &d->nti_xmsa)) return 1;
+  if (upload(f, j.nti_xmsa, W * nR * 4, &d->nti_xmsa)) return 1;
   if (upload(f, j.exit_nlo, nR * 4, &d->exit_nlo)) return 1;
   if (upload(f, j.exit_trans, nR, &d->exit_trans)) return 1;
   if (upload(f, j.exit_gp_li, nR, &d->exit_gp_li)) return 1;

@@ -190,7 +190,7 @@ __device__ static int junction_forward(const DevJunction& J, const FwdShared& sh
       for (int b = 0; b < 4; ++b) {
         double s = ((n0 * ntt[b] + n1 * ntt[4 + b]) + n2 * ntt[8 + b]) + n3 * ntt[12 + b];
         s += A * J.right_gp_nli[(size_t)t * 4 + b];
-        const double v = s * em[J.nti_xmsa[i * 4 + b]];
+        const double v = s * em[J.nti_xmsa[((size_t)i * nR + t) * 4 + b]];
         sh.fN[cur][t * 4 + b] = v;
         mp = posmin(mp, v);
       }

@@ -1,0 +1,127 @@
+"""ctypes binding of the C++ host library (liblinearham_host.so): linearham's HMM / SimpleHMM /
+PhyloHMM class surface.  Used by tests/ and bench.py; no numerics live here."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def host_library_path():
+    return os.path.join(_HERE, "lib", "liblinearham_host.so")
+
+
+def load_host():
+    global _LIB
+    if _LIB is None:
+        p = host_library_path()
+        if not os.path.exists(p):
+            raise RuntimeError("host library %s is missing: run __graft_entry__.build()" % p)
+        lib = C.CDLL(p)
+        lib.lhh_last_error.restype = C.c_char_p
+        _LIB = lib
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(load_host().lhh_last_error().decode())
+
+
+def germline_json(path, gtype):
+    out = C.c_char_p()
+    _check(load_host().lhh_germline_json(path.encode(), C.c_char(gtype.encode()), C.byref(out)))
+    return json.loads(out.value.decode())
+
+
+class _HMM:
+    def __init__(self, handle):
+        self.h = handle
+        self.lib = load_host()
+
+    def close(self):
+        if self.h:
+            self.lib.lhh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dump(self, what):
+        """what: bit 0 state space + transitions, bit 1 forward arrays, bit 2 sample, bit 3 xMSA."""
+        out = C.c_char_p()
+        _check(self.lib.lhh_dump_json(self.h, what, C.byref(out)))
+        return json.loads(out.value.decode())
+
+    def log_likelihood(self):
+        v = C.c_double()
+        _check(self.lib.lhh_loglikelihood(self.h, C.byref(v)))
+        return v.value
+
+    def sample_naive_sequence(self):
+        out = C.c_char_p()
+        _check(self.lib.lhh_sample(self.h, C.byref(out)))
+        return out.value.decode()
+
+
+class SimpleHMM(_HMM):
+    def __init__(self, yaml_path, cluster_ind, hmm_param_dir, seed):
+        h = C.c_void_p()
+        _check(load_host().lhh_simple_create(yaml_path.encode(), cluster_ind, hmm_param_dir.encode(), seed,
+                                             C.byref(h)))
+        super().__init__(h)
+
+
+class PhyloHMM(_HMM):
+    def __init__(self, yaml_path, cluster_ind, hmm_param_dir, seed):
+        h = C.c_void_p()
+        _check(load_host().lhh_phylo_create(yaml_path.encode(), cluster_ind, hmm_param_dir.encode(), seed,
+                                            C.byref(h)))
+        super().__init__(h)
+
+    def initialize_phylo_parameters(self, newick, er, pi, alpha, num_rates, is_path=True):
+        er = (C.c_double * 6)(*er)
+        pi = (C.c_double * 4)(*pi)
+        f = self.lib.lhh_phylo_init_parameters if is_path else self.lib.lhh_phylo_init_parameters_str
+        _check(f(self.h, newick.encode(), er, pi, C.c_double(alpha), num_rates))
+
+    def initialize_phylo_emission(self):
+        _check(self.lib.lhh_phylo_init_emission(self.h))
+
+    def run_pipeline(self, input_path, output_path, num_rates):
+        _check(self.lib.lhh_run_pipeline(self.h, input_path.encode(), output_path.encode(), num_rates))
+
+    def sizes(self):
+        v = [C.c_int() for _ in range(8)]
+        _check(self.lib.lhh_phylo_sizes(self.h, *[C.byref(x) for x in v]))
+        keys = ["n_tips", "n_sites", "n_xmsa", "s_vd", "s_dj", "w_vd", "w_dj", "g_total"]
+        return {k: x.value for k, x in zip(keys, v)}
+
+    def flatten_tsv(self, tsv_path, n, need_family=True):
+        """Device-ready inputs for lh_eval_batch_device: n samples taken cyclically from the table.
+        Returns dict(ops, brlen, er, pi, alpha, n_tips, max_depth, n_rows, family)."""
+        n_tips, depth, n_rows = C.c_int(), C.c_int(), C.c_int()
+        fam = C.c_void_p()
+        flag = C.c_int(1 if need_family else 0)
+        _check(self.lib.lhh_phylo_flatten_tsv(self.h, tsv_path.encode(), 0, None, None, None, None, None,
+                                              C.byref(n_tips), C.byref(depth), C.byref(n_rows), flag,
+                                              C.byref(fam)))
+        T = n_tips.value
+        ops = np.zeros((n, T - 2, 4), dtype=np.int32)
+        brlen = np.zeros((n, 2 * T - 2))
+        er, pi, alpha = np.zeros((n, 6)), np.zeros((n, 4)), np.zeros(n)
+
+        def p(a, t):
+            return a.ctypes.data_as(C.POINTER(t))
+        _check(self.lib.lhh_phylo_flatten_tsv(self.h, tsv_path.encode(), n, p(ops, C.c_int32),
+                                              p(brlen, C.c_double), p(er, C.c_double), p(pi, C.c_double),
+                                              p(alpha, C.c_double), C.byref(n_tips), C.byref(depth),
+                                              C.byref(n_rows), flag, C.byref(fam)))
+        return dict(ops=ops, brlen=brlen, er=er, pi=pi, alpha=alpha, n_tips=T, max_depth=depth.value,
+                    n_rows=n_rows.value, family=fam.value)

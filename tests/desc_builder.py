@@ -33,7 +33,7 @@ def junction_tables(h, J, Jx, G_left, G_right, left_fb):
              left_lo=np.zeros((W, nL)), left_xmsa=-np.ones((W, nL), dtype=np.int32),
              right_gp_nli=np.zeros((nR, 4)), right_ntt=np.zeros((nR, 4, 4)), right_nlo=np.zeros((W, nR, 4)),
              right_trans=np.zeros((W, nR)), right_gp_li=np.zeros((W, nR)),
-             right_xmsa=-np.ones((W, nR), dtype=np.int32), nti_xmsa=-np.ones((W, 4), dtype=np.int32),
+             right_xmsa=-np.ones((W, nR), dtype=np.int32), nti_xmsa=-np.ones((W, nR, 4), dtype=np.int32),
              exit_nlo=np.zeros((nR, 4)), exit_trans=np.zeros(nR), exit_gp_li=np.zeros(nR))
     for l, name in enumerate(left):
         gg = h.ggenes[name]
@@ -58,7 +58,7 @@ def junction_tables(h, J, Jx, G_left, G_right, left_fb):
         t["right_ntt"][r] = gg.nti_transition
         for b in range(4):
             for i in range(W):
-                t["nti_xmsa"][i, b] = Jx[i, rs + b]
+                t["nti_xmsa"][i, r, b] = Jx[i, rs + b]
         first = True
         last_row = -1
         for k in range(rs + 4, re_):
@@ -215,12 +215,12 @@ def _junction(J, em, g_in, count, germ_em, pad_trans, pad_em):
             prevL, lo = g_in, J.enter_lo
             A = float(np.sum(prevL * lo))
             fL2 = prevL * J.enter_trans * E(J.left_xmsa[0])
-            fN2 = (A * J.right_gp_nli) * E(J.nti_xmsa[0])[None, :]
+            fN2 = (A * J.right_gp_nli) * E(J.nti_xmsa[0])
             fR2 = (A * J.right_gp_li[0]) * E(J.right_xmsa[0])
         else:
             A = float(np.sum(fL * J.left_lo[i - 1]))
             fL2 = fL * J.left_trans[i] * E(J.left_xmsa[i])
-            fN2 = (np.einsum("rb,rbc->rc", fN, J.right_ntt) + A * J.right_gp_nli) * E(J.nti_xmsa[i])[None, :]
+            fN2 = (np.einsum("rb,rbc->rc", fN, J.right_ntt) + A * J.right_gp_nli) * E(J.nti_xmsa[i])
             fR2 = (np.einsum("rb,rb->r", fN, J.right_nlo[i]) + fR * J.right_trans[i] + A * J.right_gp_li[i]) \
                 * E(J.right_xmsa[i])
         allv = np.concatenate([fL2.ravel(), fN2.ravel(), fR2.ravel()])

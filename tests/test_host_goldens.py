@@ -1,0 +1,115 @@
+"""CPU tests of the C++ host (liblinearham_host.so): parameter parsing, state space, dense transition
+matrices and xMSA structures against the reference's Catch-test literals (test/test.cpp) and, on a
+synthetic multi-allele family, against the oracle.  No GPU needed: these objects are host-only."""
+import os
+
+import numpy as np
+import pytest
+
+from linearham_amd import host
+from oracle import linearham_oracle as orc
+from tests.helpers import assert_close_struct, oracle_accessors
+
+HMM_KEYS_EXACT = ["locus", "flexbounds", "relpos", "alphabet", "msa"]
+
+
+def _compare_to_golden(dump, want):
+    checked = 0
+    for k, v in dump.items():
+        if k not in want:
+            continue
+        tol = 1e-15 if k.endswith("_transition") else 0.0
+        assert_close_struct(v, want[k], k, rtol=tol)
+        checked += 1
+    return checked
+
+
+@pytest.mark.parametrize("g", ["V", "D", "J"])
+def test_germline_parsing(goldens, data_dir, g):
+    j = host.germline_json(os.path.join(data_dir, "hmm_params", "IGH%s_ex_star_01.yaml" % g), g)
+    want = goldens["Germline"]["vars"]
+    for key in ["landing_in", "landing_out", "transition", "emission", "bases", "gene_prob", "alphabet", "name",
+                "length"]:
+        assert_close_struct(j[key], want["%s_%s" % (g, key)], key)
+    if g in "DJ":
+        for key in ["nti_landing_in", "nti_landing_out", "nti_transition", "nti_emission"]:
+            assert_close_struct(j[key], goldens["NTInsertion"]["vars"]["%s_%s" % (g, key)], key)
+    if g in "VJ":
+        for key in ["n_transition", "n_emission"]:
+            assert_close_struct(j[key], goldens["NPadding"]["vars"]["%s_%s" % (g, key)], key)
+
+
+@pytest.mark.parametrize("case", ["simple_hmm_input", "simple_hmm_input_extra"])
+def test_simple_hmm_state_space_and_transitions(goldens, data_dir, case):
+    h = host.SimpleHMM(os.path.join(data_dir, case + ".yaml"), 0, os.path.join(data_dir, "hmm_params"), 0)
+    n = _compare_to_golden(h.dump(1), goldens["SimpleHMM:" + case]["vars"])
+    assert n >= 55
+
+
+@pytest.mark.parametrize("case", ["phylo_hmm_input", "phylo_hmm_input_extra"])
+def test_phylo_hmm_state_space_transitions_xmsa(goldens, data_dir, case):
+    h = host.PhyloHMM(os.path.join(data_dir, case + ".yaml"), 0, os.path.join(data_dir, "hmm_params"), 0)
+    d = h.dump(1 | 8)
+    want = dict(goldens["PhyloHMM:" + case]["vars"])
+    want.pop("xmsa_emission")          # needs the GPU; checked in test_host_gpu.py
+    want.pop("er"), want.pop("pi")
+    want["cache_forward"] = False      # nothing evaluated yet
+    d = {k: v for k, v in d.items() if k not in ("xmsa_emission", "er", "pi", "sr", "alpha")}
+    n = _compare_to_golden(d, want)
+    assert n >= 65
+
+
+def test_synthetic_family_host_matches_oracle(tmp_path):
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(), out)
+    yaml_path, pdir = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params")
+    o = orc.PhyloHMM(yaml_path, 0, pdir, 0)
+    h = host.PhyloHMM(yaml_path, 0, pdir, 0)
+    d = h.dump(1 | 8)
+    want = oracle_accessors(o)
+    for k, v in want.items():
+        assert_close_struct(d[k], v, k, rtol=1e-15 if k.endswith("_transition") else 0.0)
+    assert d["xmsa"] == o.xmsa.tolist()
+    assert d["xmsa_seqs"] == o.xmsa_seqs
+    for k in ["vpadding_xmsa_inds", "vgerm_xmsa_inds", "vd_junction_xmsa_inds", "dgerm_xmsa_inds",
+              "dj_junction_xmsa_inds", "jgerm_xmsa_inds", "jpadding_xmsa_inds"]:
+        assert d[k] == np.asarray(getattr(o, k)).tolist(), k
+    # the flattened device inputs (Newick ingest + lh_schedule_tree) need no GPU either
+    flat = h.flatten_tsv(os.path.join(out, "trees.tsv"), 7, need_family=False)
+    assert flat["n_rows"] == 5 and flat["ops"].shape == (7, 7, 4)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    np.testing.assert_allclose(flat["alpha"][:5], [r["alpha"] for r in rows])
+    assert np.array_equal(flat["ops"][5], flat["ops"][0])
+    for i, r in enumerate(rows):
+        t = orc.parse_newick(r["tree"])
+        total = sum(l for a in t.adj for _, l in a) / 2
+        assert abs(flat["brlen"][i].sum() - total) < 1e-12
+
+
+def test_host_errors(data_dir, tmp_path):
+    with pytest.raises(RuntimeError, match="does not exist"):
+        host.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input.yaml"), 0, str(tmp_path / "nope"), 0)
+    bad = tmp_path / "bad.yaml"
+    bad.write_text('{"germline-info": {"locus": "igh"}, "events": [{"unique_ids": ["a"]}]}')
+    with pytest.raises(RuntimeError, match="flexbounds"):
+        host.PhyloHMM(str(bad), 0, os.path.join(data_dir, "hmm_params"), 0)
+    h = host.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input.yaml"), 0, os.path.join(data_dir, "hmm_params"), 0)
+    for tree in ["((0:0.2,1:0.4):0.6,naive:0.3);",               # a tip is missing
+                 "((0:0.2,1:0.4):0.6,naive:0.3,3:0.5);",          # unknown label
+                 "((0:0.2,1:0.4,2:0.1):0.6,naive:0.3);",          # multifurcation below the top
+                 "((0:0.2,1:0.4):0.6,naive:0.3,2:0.5"]:           # truncated
+        with pytest.raises(RuntimeError):
+            h.initialize_phylo_parameters(tree, [1.0] * 6, [0.25] * 4, 1.0, 4, is_path=False)
+
+
+def test_yaml_reader_dialects(tmp_path, data_dir):
+    """Wrapped flow maps, comments and `key:` followed by a same-indent sequence (partis/PyYAML dumps)."""
+    src = open(os.path.join(data_dir, "hmm_params", "IGHD_ex_star_01.yaml")).read()
+    wrapped = src.replace("insert_left_G: 0.05, insert_left_T: 0.025}",
+                          "insert_left_G: 0.05,\n    insert_left_T: 0.025}  # wrapped by the dumper")
+    p = tmp_path / "IGHD_ex_star_01.yaml"
+    p.write_text("# leading comment\n" + wrapped)
+    a = host.germline_json(str(p), "D")
+    b = host.germline_json(os.path.join(data_dir, "hmm_params", "IGHD_ex_star_01.yaml"), "D")
+    assert a == b

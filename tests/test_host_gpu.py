@@ -1,0 +1,135 @@
+"""GPU tests of the product path end to end: C++ host classes (linearham's SimpleHMM / PhyloHMM
+surface) -> C ABI -> HIP kernels, against the reference's goldens and the CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from linearham_amd import host
+from oracle import linearham_oracle as orc
+from tests.helpers import catch_approx, eigen_is_approx
+from tests.test_oracle_goldens import SAMPLE_KEYS
+
+pytestmark = pytest.mark.gpu
+ER, PI = [1.0] * 6, [0.17, 0.19, 0.25, 0.39]
+FWD_KEYS = ["vgerm_forward", "vd_junction_forward", "dgerm_forward", "dj_junction_forward", "jgerm_forward"]
+CNT_KEYS = ["vgerm_scaler_count", "vd_junction_scaler_counts", "dgerm_scaler_count", "dj_junction_scaler_counts",
+            "jgerm_scaler_count"]
+
+
+def _check_against_oracle(h, o, rtol=1e-9):
+    ll = h.log_likelihood()
+    ref = o.log_likelihood()
+    assert abs(ll - ref) <= 1e-10 * abs(ref), (ll, ref)
+    d = h.dump(2)
+    for k in FWD_KEYS:
+        np.testing.assert_allclose(np.asarray(d[k], dtype=float), getattr(o, k), rtol=rtol, atol=0, err_msg=k)
+    for k in CNT_KEYS:
+        assert d[k] == getattr(o, k), k
+    return ll
+
+
+@pytest.mark.parametrize("case", ["simple_hmm_input", "simple_hmm_input_extra"])
+def test_simple_hmm(goldens, data_dir, case):
+    # BASELINE.json configs[0]; test/test.cpp:457,718 and the seed-0 sampled paths :377-399,640-660
+    want = goldens["SimpleHMM:" + case]["vars"]
+    yaml_path, pdir = os.path.join(data_dir, case + ".yaml"), os.path.join(data_dir, "hmm_params")
+    h = host.SimpleHMM(yaml_path, 0, pdir, 0)
+    o = orc.SimpleHMM(yaml_path, 0, pdir, 0)
+    assert h.dump(1)["cache_forward"] is True
+    ll = _check_against_oracle(h, o)
+    assert catch_approx(ll, want["loglikelihood"]) and abs(ll - want["loglikelihood"]) < 1e-9
+    for k in CNT_KEYS:
+        assert h.dump(2)[k] == want[k]
+    assert h.sample_naive_sequence() == want["naive_seq_samp"]
+    s = h.dump(4)
+    for k in SAMPLE_KEYS:
+        assert s[k] == want[k], k
+
+
+@pytest.mark.parametrize("case,params,R", [("phylo_hmm_input", "hmm_params", 4),
+                                          ("phylo_hmm_input_extra", "hmm_params", 4),
+                                          ("phylo_likelihood_hmm_input", "phylo_likelihood_hmm_params", 1)])
+def test_phylo_hmm(goldens, data_dir, case, params, R):
+    # BASELINE.json configs[1]; test/test.cpp:750-1398
+    want = goldens["PhyloHMM:" + case]["vars"]
+    yaml_path, pdir = os.path.join(data_dir, case + ".yaml"), os.path.join(data_dir, params)
+    tree = os.path.join(data_dir, "newton.tree")
+    h = host.PhyloHMM(yaml_path, 0, pdir, 0)
+    h.initialize_phylo_parameters(tree, ER, PI, 1.0, R)
+    h.initialize_phylo_emission()
+    o = orc.PhyloHMM(yaml_path, 0, pdir, 0)
+    o.initialize_phylo_parameters(tree, ER, PI, 1.0, R)
+    o.initialize_phylo_emission()
+    assert h.dump(1)["cache_forward"] is True
+    ll = _check_against_oracle(h, o)
+    assert catch_approx(ll, want["loglikelihood"])
+    d = h.dump(8)
+    np.testing.assert_allclose(d["xmsa_emission"], o.xmsa_emission, rtol=1e-10)
+    np.testing.assert_allclose(d["sr"], o.sr, rtol=1e-10)
+    if "xmsa_emission" in want:
+        assert eigen_is_approx(d["xmsa_emission"], want["xmsa_emission"], 1e-5)
+        assert h.sample_naive_sequence() == want["naive_seq_samp"]
+        s = h.dump(4)
+        for k in SAMPLE_KEYS:
+            assert s[k] == want[k], k
+
+
+def test_run_pipeline_matches_oracle(tmp_path):
+    """PhyloHMM::RunPipeline (src/PhyloHMM.cpp:393-446) on a synthetic RevBayes table: batched GPU
+    evaluation + in-order host sampling must reproduce the row-by-row oracle, including the RNG stream."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_samples=9), out)
+    yaml_path, pdir, tsv = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params"), os.path.join(out, "trees.tsv")
+    h = host.PhyloHMM(yaml_path, 0, pdir, 3)
+    res = os.path.join(out, "lh.tsv")
+    h.run_pipeline(tsv, res, 4)
+    lines = [l.rstrip("\n").split("\t") for l in open(res)]
+    header, body = lines[0], lines[1:]
+    col = {name: i for i, name in enumerate(header)}
+    assert header[:4] == ["Iteration", "RBLogLikelihood", "Prior", "alpha"] and header[-1] == "JFwkInsertion"
+    o = orc.PhyloHMM(yaml_path, 0, pdir, 3)
+    rows = sf.read_trees_tsv(tsv)
+    assert len(body) == len(rows)
+    for r, got in zip(rows, body):
+        o.initialize_phylo_parameters(r["tree"], r["er"], r["pi"], r["alpha"], 4, is_path=False)
+        o.initialize_phylo_emission()
+        ll = o.log_likelihood()
+        seq = o.sample_naive_sequence()
+        assert int(got[col["Iteration"]]) == r["iteration"]
+        assert abs(float(got[col["LHLogLikelihood"]]) - ll) <= 5e-6 * abs(ll)        # 6 significant digits
+        assert abs(float(got[col["LogWeight"]]) - (ll - r["likelihood"])) <= 5e-6 * abs(ll - r["likelihood"]) + 1e-9
+        assert got[col["NaiveSequence"]] == seq
+        assert got[col["VGene"]] == o.sample["vgerm_state_str_samp"]
+        assert got[col["DGene"]] == o.sample["dgerm_state_str_samp"]
+        assert got[col["JGene"]] == o.sample["jgerm_state_str_samp"]
+        assert got[col["VDInsertion"]] == o.sample["vd_junction_insertion_samp"]
+        assert got[col["DJInsertion"]] == o.sample["dj_junction_insertion_samp"]
+        for k, c in [("vgerm_left_del_samp", "V5pDel"), ("vgerm_right_del_samp", "V3pDel"),
+                     ("dgerm_left_del_samp", "D5pDel"), ("dgerm_right_del_samp", "D3pDel"),
+                     ("jgerm_left_del_samp", "J5pDel"), ("jgerm_right_del_samp", "J3pDel")]:
+            assert int(got[col[c]]) == o.sample[k], c
+        np.testing.assert_allclose([float(got[col["sr[%d]" % i]]) for i in range(1, 5)], o.sr, rtol=5e-6)
+        # the re-exported tree is the same unrooted tree
+        t1, t2 = orc.parse_newick(got[col["tree"]]), orc.parse_newick(r["tree"])
+        assert abs(sum(l for a in t1.adj for _, l in a) - sum(l for a in t2.adj for _, l in a)) < 1e-4
+
+
+def test_cli_compute_logl(data_dir):
+    """`linearham --compute-logl` prints the log-likelihood with 6 significant digits
+    (src/linearham.cpp:341-348)."""
+    exe = os.path.join(os.path.dirname(host.host_library_path()), "linearham")
+    cmd = [exe, "--compute-logl", "--yaml-path", os.path.join(data_dir, "phylo_hmm_input.yaml"), "--cluster-ind", "0",
+           "--hmm-param-dir", os.path.join(data_dir, "hmm_params"), "--newick-path",
+           os.path.join(data_dir, "newton.tree"), "--num-rates", "4"]
+    for x in ER:
+        cmd += ["--er", str(x)]
+    for x in PI:
+        cmd += ["--pi", str(x)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "-75.8136"
+    bad = subprocess.run([exe, "--nonsense", "--yaml-path", "x"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "ERROR:" in bad.stderr

@@ -146,27 +146,44 @@ def _mutate(seq, frac, rng):
 
 
 def make_germline_set(spec, outdir, rng):
+    """Returns {"V"|"D"|"J": [(gene name, sequence, relpos)]}.
+
+    Every allele is cut out of one site-aligned root sequence per segment (so that all alleles agree
+    on which germline base sits at which MSA site, as Smith-Waterman candidates of ONE rearrangement
+    do) and then mutated in two levels: ancestor = <= `divergence` mutant of the root, allele =
+    <= `divergence` mutant of its ancestor.  Unrelated or misaligned alleles would differ by more than
+    2^1024 in likelihood and trip the reference's 2^(256*d) equalisation overflow
+    (src/PhyloHMM.cpp:190-192), giving NaN on both sides."""
     os.makedirs(outdir, exist_ok=True)
+    fb = spec.flexbounds
+    L = spec.n_sites
     genes = {"V": [], "D": [], "J": []}
     for gtype, n, n_anc in (("V", spec.n_v, spec.v_ancestors), ("D", spec.n_d, spec.d_ancestors),
                             ("J", spec.n_j, spec.j_ancestors)):
-        ancestors = []
-        for a in range(n_anc):
-            if gtype == "V":
-                ln = spec.len_v
-            else:
-                lo, hi = spec.len_d if gtype == "D" else spec.len_j
-                ln = int(rng.integers(lo, hi + 1))
-            ancestors.append("".join(rng.choice(list(BASES), size=ln)))
-        probs = rng.dirichlet(np.ones(n))
-        probs = np.round(probs, 6)
+        root = "".join(rng.choice(list(BASES), size=L + 80))        # root[s + 40] = base at MSA site s
+        ancestors = [root] + [_mutate(root, spec.divergence, rng) for _ in range(n_anc - 1)]
+        probs = np.round(rng.dirichlet(np.ones(n)), 6)
         for k in range(n):
             anc = k % n_anc
-            seq = ancestors[anc] if k < n_anc else _mutate(ancestors[anc], spec.divergence, rng)
+            if gtype == "V":
+                ln = spec.len_v
+                relpos = 1 if k == 0 else int(rng.integers(0, fb["v_l"][1] + 1))
+            elif gtype == "D":
+                ln = int(rng.integers(spec.len_d[0], spec.len_d[1] + 1))
+                lo, hi = fb["d_r"][0] - ln, fb["d_l"][1]            # must cover [d_l.second, d_r.first)
+                relpos = int(rng.integers(max(lo, fb["v_r"][0] - 5), hi + 1))
+                if k == 0:
+                    relpos = min(max(fb["d_l"][0] + 1, lo), hi)
+            else:
+                ln = int(rng.integers(spec.len_j[0], spec.len_j[1] + 1))
+                relpos = fb["j_l"][0] + 1 if k == 0 else int(rng.integers(fb["j_l"][0], fb["j_l"][1] + 1))
+            seq = ancestors[anc][relpos + 40:relpos + 40 + ln]
+            if k >= n_anc:
+                seq = _mutate(seq, spec.divergence, rng)
             name = "IGH%s_syn%d_star_%02d" % (gtype, anc + 1, k // n_anc + 1)
             write_allele(os.path.join(outdir, name + ".yaml"), name, gtype, seq, max(float(probs[k]), 1e-6),
                          rng)
-            genes[gtype].append((name.replace("_star_", "*"), seq))
+            genes[gtype].append((name.replace("_star_", "*"), seq, relpos))
     return genes
 
 
@@ -287,22 +304,20 @@ def generate(spec, outdir):
     genes = make_germline_set(spec, os.path.join(outdir, "hmm_params"), np.random.default_rng(spec.seed + 2))
     fb = spec.flexbounds
     L = spec.n_sites
-    # true rearrangement: allele 0 of each segment
-    vname, vseq = genes["V"][0]
-    dname, dseq = genes["D"][0]
-    jname, jseq = genes["J"][0]
+    # true rearrangement: allele 0 of each segment, placed at its own relpos
+    vname, vseq, v_relpos = genes["V"][0]
+    dname, dseq, d_relpos = genes["D"][0]
+    jname, jseq, j_relpos = genes["J"][0]
     rng_s = np.random.default_rng(spec.seed + 3)
-    v_relpos = 1
-    v_end = fb["v_r"][1] - 2                                # V 3' deletion of (v_relpos+len_v - v_end)
-    d_start = fb["d_l"][0] + 2
+    v_end = fb["v_r"][1] - 2                                # V 3' deletion
     d_del5 = 1
-    d_end = min(d_start + len(dseq) - d_del5, fb["d_r"][1] - 1)
-    j_start = fb["j_l"][0] + 3
+    d_start = d_relpos + d_del5
+    d_end = min(d_relpos + len(dseq), fb["d_r"][1] - 1)
     j_del5 = 2
-    j_end = min(j_start + len(jseq) - j_del5, L)
+    j_start = j_relpos + j_del5
+    j_end = min(j_relpos + len(jseq), L)
     naive = np.full(L, -1, dtype=np.int64)
     rnd = lambda n: rng_s.integers(0, 4, size=n)
-    naive[:v_relpos] = -1
     naive[v_relpos:v_end] = [BASES.index(c) for c in vseq[:v_end - v_relpos]]
     naive[v_end:d_start] = rnd(d_start - v_end)
     naive[d_start:d_end] = [BASES.index(c) for c in dseq[d_del5:d_del5 + d_end - d_start]]
@@ -321,17 +336,15 @@ def generate(spec, outdir):
     to_str = lambda a: "".join("N" if x < 0 else BASES[x] for x in a)
     # relpos per allele, consistent with the constraints of SURVEY.md 8.1
     relpos = {}
-    rp = np.random.default_rng(spec.seed + 4)
-    for k, (name, seq) in enumerate(genes["V"]):
-        relpos[name] = v_relpos if k == 0 else int(rp.integers(0, fb["v_l"][1] + 1))
-        assert relpos[name] + len(seq) >= fb["v_r"][0]
-    for k, (name, seq) in enumerate(genes["D"]):
-        lo, hi = fb["d_r"][0] - len(seq), fb["d_l"][1]
-        relpos[name] = (d_start - d_del5) if k == 0 else int(rp.integers(max(lo, fb["v_r"][0] - 5), hi + 1))
-        relpos[name] = min(max(relpos[name], lo), hi)
-    for k, (name, seq) in enumerate(genes["J"]):
-        relpos[name] = (j_start - j_del5) if k == 0 else int(rp.integers(fb["j_l"][0], fb["j_l"][1] + 1))
-        relpos[name] = min(relpos[name], fb["j_l"][1])
+    for name, seq, rp_ in genes["V"]:
+        relpos[name] = rp_
+        assert rp_ + len(seq) >= fb["v_r"][0]
+    for name, seq, rp_ in genes["D"]:
+        relpos[name] = rp_
+        assert rp_ <= fb["d_l"][1] and rp_ + len(seq) >= fb["d_r"][0]
+    for name, seq, rp_ in genes["J"]:
+        relpos[name] = rp_
+        assert rp_ <= fb["j_l"][1]
     cluster = {
         "germline-info": {"locus": "igh"},
         "events": [{
