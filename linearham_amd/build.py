@@ -64,7 +64,7 @@ def build_oracle(verbose=False, force=False):
         return None
     out = os.path.join(ROOT, "oracle", "liboracle_kernels.so")
     if force or _stale(out, [src]):
-        _run(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-fopenmp", src, "-o", out, "-lm"], verbose)
+        _run(["gcc", "-O3", "-march=x86-64-v3", "-fPIC", "-shared", "-fopenmp", src, "-o", out, "-lm"], verbose)
     return out
 
 

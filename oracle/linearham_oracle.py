@@ -24,6 +24,8 @@ import re
 import numpy as np
 import yaml
 
+_YAML_LOADER = getattr(yaml, "CSafeLoader", yaml.SafeLoader)
+
 EPS = 1e-6                      # src/utils.hpp:20
 SCALE_FACTOR = 2.0 ** 256       # src/utils.hpp:22
 SCALE_THRESHOLD = 1.0 / SCALE_FACTOR  # src/utils.hpp:24
@@ -224,7 +226,7 @@ def create_germline_gene_map(hmm_param_dir):
         if m.group(3) == "D" and m.group(2) in "KL":
             continue
         with open(os.path.join(hmm_param_dir, fn)) as f:
-            root = yaml.safe_load(f)
+            root = yaml.load(f, Loader=_YAML_LOADER)
         ggenes[fix_gene_name(m.group(1))] = GermlineGene(root, m.group(3))
     return ggenes
 

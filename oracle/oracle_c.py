@@ -1,0 +1,144 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  ctypes wrapper of oracle/oracle_kernels.c: the dense,
+reference-algorithm evaluation in plain C, fed from an oracle PhyloHMM object.  Used by tests/ as a
+second checker and by bench.py's cpu_baseline leg; never by the product."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from oracle import linearham_oracle as orc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+c_i32p = C.POINTER(C.c_int32)
+c_f64p = C.POINTER(C.c_double)
+c_u8p = C.POINTER(C.c_uint8)
+
+
+class _Seg(C.Structure):
+    _fields_ = [("n_genes", C.c_int), ("offsets", c_i32p), ("xmsa_inds", c_i32p)]
+
+
+class _Junc(C.Structure):
+    _fields_ = [("W", C.c_int), ("S", C.c_int), ("n_from", C.c_int), ("n_to", C.c_int), ("T_gj", c_f64p),
+                ("T_jj", c_f64p), ("T_jg", c_f64p), ("xmsa", c_i32p)]
+
+
+class _Family(C.Structure):
+    _fields_ = [("T", C.c_int), ("C", C.c_int), ("R", C.c_int), ("has_d", C.c_int), ("xmsa", c_u8p),
+                ("vpadding", _Seg), ("vgerm", _Seg), ("dgerm", _Seg), ("jgerm", _Seg), ("jpadding", _Seg),
+                ("vgerm_gene_prob", c_f64p), ("vpadding_transition", c_f64p), ("vgerm_trans_prod", c_f64p),
+                ("jpadding_transition", c_f64p), ("vd", _Junc), ("dj", _Junc)]
+
+
+def build(verbose=False):
+    from linearham_amd import build as lb
+    return lb.build_oracle(verbose=verbose)
+
+
+def _lib():
+    path = os.path.join(_HERE, "liboracle_kernels.so")
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    lib.oc_eval_batch.argtypes = [C.POINTER(_Family), C.c_int, c_i32p, c_i32p, c_i32p, c_f64p, c_f64p, c_f64p,
+                                  c_f64p, c_f64p, c_f64p, C.c_int]
+    return lib
+
+
+class COracleFamily:
+    """Dense family constants of one oracle PhyloHMM (kept alive as numpy arrays)."""
+
+    def __init__(self, h, num_rates):
+        self.h = h
+        self.keep = []
+        self.lib = _lib()
+        f = _Family()
+        f.T, f.C, f.R, f.has_d = h.xmsa.shape[0], h.xmsa.shape[1], num_rates, int(h.locus == "igh")
+        f.xmsa = self._u8(h.xmsa)
+        f.vpadding = self._seg(h.vpadding, h.vpadding_xmsa_inds)
+        f.vgerm = self._seg(h.vgerm, h.vgerm_xmsa_inds)
+        f.jgerm = self._seg(h.jgerm, h.jgerm_xmsa_inds)
+        f.jpadding = self._seg(h.jpadding, h.jpadding_xmsa_inds)
+        names = sorted(h.vgerm.ggene_ranges)
+        prod = []
+        for g in names:
+            rs, re_ = h.vgerm.ggene_ranges[g]
+            gis = h.vgerm.germ_inds[rs]
+            prod.append(float(np.prod(h.ggenes[g].transition[gis:gis + (re_ - rs - 1)])))
+        f.vgerm_gene_prob = self._f64([h.ggenes[g].gene_prob for g in names])
+        f.vpadding_transition = self._f64(h.vpadding_transition)
+        f.vgerm_trans_prod = self._f64(prod)
+        f.jpadding_transition = self._f64(h.jpadding_transition)
+        f.vd = self._junc(h.vgerm_vd_junction_transition, h.vd_junction_transition,
+                          h.vd_junction_dgerm_transition, h.vd_junction_xmsa_inds)
+        if f.has_d:
+            f.dgerm = self._seg(h.dgerm, h.dgerm_xmsa_inds)
+            f.dj = self._junc(h.dgerm_dj_junction_transition, h.dj_junction_transition,
+                              h.dj_junction_jgerm_transition, h.dj_junction_xmsa_inds)
+        self.f = f
+        self.num_rates = num_rates
+
+    def _f64(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self.keep.append(a)
+        return a.ctypes.data_as(c_f64p)
+
+    def _i32(self, a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        self.keep.append(a)
+        return a.ctypes.data_as(c_i32p)
+
+    def _u8(self, a):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        self.keep.append(a)
+        return a.ctypes.data_as(c_u8p)
+
+    def _seg(self, R, inds):
+        offs, out = [0], []
+        for g in sorted(R.ggene_ranges):
+            rs, re_ = R.ggene_ranges[g]
+            out.extend(int(x) for x in inds[rs:re_])
+            offs.append(len(out))
+        return _Seg(len(offs) - 1, self._i32(offs), self._i32(out if out else [0]))
+
+    def _junc(self, T_gj, T_jj, T_jg, xm):
+        j = _Junc()
+        j.W, j.S, j.n_from, j.n_to = xm.shape[0], xm.shape[1], T_gj.shape[0], T_jg.shape[1]
+        j.T_gj = self._f64(T_gj)                          # row-major [n_from][S]
+        j.T_jj = self._f64(np.asfortranarray(T_jj).T)     # column-major storage of T_jj
+        j.T_jg = self._f64(np.asfortranarray(T_jg).T)
+        j.xmsa = self._i32(xm)
+        return j
+
+    def eval(self, trees, er, pi, alphas, n_threads=1, want_em=False):
+        """trees: list of (children [(T-2)*2], root, brlen [2T-2]) in the C-ABI form."""
+        n, T = len(trees), self.f.T
+        children = np.stack([np.asarray(t[0], dtype=np.int32) for t in trees])
+        roots = np.array([t[1] for t in trees], dtype=np.int32)
+        brlen = np.stack([np.asarray(t[2], dtype=np.float64) for t in trees])
+        order = np.zeros((n, T - 2), dtype=np.int32)
+        for s in range(n):
+            order[s] = postorder(T, children[s], roots[s])
+        rates = np.stack([orc.gamma_rates_mean(a, self.num_rates) for a in alphas])
+        er, pi = np.ascontiguousarray(er, dtype=np.float64), np.ascontiguousarray(pi, dtype=np.float64)
+        ll = np.zeros(n)
+        em = np.zeros((n, self.f.C)) if want_em else None
+        self.lib.oc_eval_batch(C.byref(self.f), n, children.ctypes.data_as(c_i32p), roots.ctypes.data_as(c_i32p),
+                               order.ctypes.data_as(c_i32p), brlen.ctypes.data_as(c_f64p),
+                               er.ctypes.data_as(c_f64p), pi.ctypes.data_as(c_f64p), rates.ctypes.data_as(c_f64p),
+                               ll.ctypes.data_as(c_f64p), em.ctypes.data_as(c_f64p) if want_em else None, n_threads)
+        return (ll, em) if want_em else ll
+
+
+def postorder(T, children, root):
+    out, stack = [], [(int(root), False)]
+    while stack:
+        v, done = stack.pop()
+        if done:
+            out.append(v)
+            continue
+        stack.append((v, True))
+        for c in children[2 * (v - T):2 * (v - T) + 2]:
+            if c >= T:
+                stack.append((int(c), False))
+    return np.array(out, dtype=np.int32)
