@@ -30,7 +30,7 @@ int fail(const std::string& msg) {
 
 struct Workspace {
   int n_cap = 0, R = 0, T = 0;
-  double *rates = nullptr, *eig = nullptr, *pmat = nullptr, *tipvec = nullptr, *site_lik = nullptr,
+  double *rates = nullptr, *eig = nullptr, *pmat = nullptr, *site_lik = nullptr,
          *em = nullptr;
   int32_t* site_scal = nullptr;
 };
@@ -92,12 +92,17 @@ int upload_segments(lh_family* f, const lh_segments& s, int n_xmsa, lh::DevSegme
     const int total = s.offsets[s.n_genes];
     for (int j = 0; j < total; ++j)
       if (s.xmsa_inds[j] < 0 || s.xmsa_inds[j] >= n_xmsa) return fail("segments: xMSA index out of range");
-    if (upload(f, s.offsets, (size_t)s.n_genes + 1, &d->offsets)) return 1;
-    if (upload(f, s.xmsa_inds, (size_t)total, &d->xmsa_inds)) return 1;
+    int longest = 0;
+    for (int g = 0; g < s.n_genes; ++g) longest = std::max(longest, s.offsets[g + 1] - s.offsets[g]);
+    d->n_rows = (longest + 7) / 8 * 8;
+    std::vector<int32_t> t((size_t)d->n_rows * s.n_genes, n_xmsa);  // sentinel = column C (em = 1)
+    for (int g = 0; g < s.n_genes; ++g)
+      for (int j = s.offsets[g]; j < s.offsets[g + 1]; ++j)
+        t[(size_t)(j - s.offsets[g]) * s.n_genes + g] = s.xmsa_inds[j];
+    if (upload(f, t.data(), t.size(), &d->inds_t)) return 1;
   } else {
-    const int32_t zero = 0;
-    if (upload(f, &zero, 1, &d->offsets)) return 1;
-    if (upload<int32_t>(f, nullptr, 0, &d->xmsa_inds)) return 1;
+    d->n_rows = 0;
+    if (upload<int32_t>(f, nullptr, 0, &d->inds_t)) return 1;
   }
   return 0;
 }
@@ -139,7 +144,7 @@ int upload_junction(lh_family* f, const lh_junction& j, int n_xmsa, lh::DevJunct
 int ensure_workspace(lh_family* f, int n, int R, int T) {
   Workspace& w = f->ws;
   if (n <= w.n_cap && R == w.R && T == w.T) return 0;
-  void** bufs[] = {(void**)&w.rates, (void**)&w.eig,       (void**)&w.pmat, (void**)&w.tipvec,
+  void** bufs[] = {(void**)&w.rates, (void**)&w.eig,       (void**)&w.pmat,
                    (void**)&w.site_lik, (void**)&w.em, (void**)&w.site_scal};
   for (void** b : bufs) {
     if (*b) LH_HIP(hipFree(*b));
@@ -151,7 +156,6 @@ int ensure_workspace(lh_family* f, int n, int R, int T) {
   LH_HIP(hipMalloc((void**)&w.rates, sizeof(double) * cap * R));
   LH_HIP(hipMalloc((void**)&w.eig, sizeof(double) * cap * 36));
   LH_HIP(hipMalloc((void**)&w.pmat, sizeof(double) * cap * R * (size_t)std::max(T - 2, 1) * 16));
-  LH_HIP(hipMalloc((void**)&w.tipvec, sizeof(double) * cap * R * (size_t)T * 20));
   LH_HIP(hipMalloc((void**)&w.site_lik, sizeof(double) * cap * R * 5 * std::max(L, (size_t)1)));
   LH_HIP(hipMalloc((void**)&w.site_scal, sizeof(int32_t) * cap * R * std::max(L, (size_t)1)));
   LH_HIP(hipMalloc((void**)&w.em, sizeof(double) * cap * std::max(C, (size_t)1)));
@@ -297,7 +301,7 @@ void lh_family_destroy(lh_family* f) {
   if (!f) return;
   for (void* p : f->allocs) (void)hipFree(p);
   Workspace& w = f->ws;
-  void* bufs[] = {w.rates, w.eig, w.pmat, w.tipvec, w.site_lik, w.em, w.site_scal};
+  void* bufs[] = {w.rates, w.eig, w.pmat, w.site_lik, w.em, w.site_scal};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* p : f->st.ptr)
@@ -477,10 +481,10 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
     double* em = (outs && outs->xmsa_emission) ? outs->xmsa_emission + (size_t)off * C : w.em;
     lh::launch_model_setup(m, R, er + (size_t)off * 6, pi + (size_t)off * 4, alpha + off, rates, w.eig,
                            stream);
-    lh::launch_pmatrices(m, R, T, brlen + (size_t)off * nodes, rates, w.eig, w.pmat, w.tipvec, stream);
+    lh::launch_pmatrices(m, R, T, brlen + (size_t)off * nodes, rates, w.eig, w.pmat, stream);
     if (f->profile) LH_HIP(hipEventRecord(es.e[1], stream));
-    lh::launch_prune(f->host, m, R, T, max_depth, ops + (size_t)off * n_ops * 4, w.pmat, w.tipvec,
-                     pi + (size_t)off * 4, w.site_lik, w.site_scal, stream);
+    lh::launch_prune(f->host, m, R, T, max_depth, ops + (size_t)off * n_ops * 4, w.pmat, w.eig, rates,
+                     brlen + (size_t)off * nodes, pi + (size_t)off * 4, w.site_lik, w.site_scal, stream);
     if (f->profile) LH_HIP(hipEventRecord(es.e[2], stream));
     lh::launch_xmsa_emission(f->host, m, R, w.site_lik, w.site_scal, pi + (size_t)off * 4, em, stream);
     if (run_forward(f, m, em, loglik + off, outs, off, stream)) return 1;

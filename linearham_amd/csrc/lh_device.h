@@ -17,8 +17,9 @@ enum : int { OP_CHERRY = 0, OP_TIP_ACC = 1, OP_POP_ACC = 2, OP_PUSH_FLAG = 16 };
 // Device copy of lh_segments / lh_junction / family constants (all pointers are device pointers).
 struct DevSegments {
   int32_t n_genes;
-  const int32_t* offsets;
-  const int32_t* xmsa_inds;
+  int32_t n_rows;            // longest segment, rounded up to a multiple of 8
+  const int32_t* inds_t;     // [n_rows][n_genes] transposed + padded with the sentinel column C
+                             // (em[C] = 1.0), so that lane g's j-th factor is a coalesced load
 };
 
 struct DevJunction {
@@ -43,6 +44,24 @@ struct DevFamily {
   int64_t scaler_size;    // ints per sample in the scaler-count output
 };
 
+// P = I + U expm1(lambda * t*r) Uinv, clamped at 0 (shared by K0b for inner-node branches and by
+// K1's prologue for the tip tables, so both see bit-identical matrices).
+// e: lambda[4] | U[4][4] | Uinv[4][4]
+__device__ static inline void compute_pmatrix(const double* __restrict__ e, double tr, double P[4][4]) {
+  double ex[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ex[k] = expm1(e[k] * tr);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double v = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v = fma(e[4 + i * 4 + k] * ex[k], e[20 + k * 4 + j], v);
+      P[i][j] = fmax(v, 0.0);
+    }
+}
+
 // ---- kernel launchers (each enqueues on `stream`, no synchronisation) -------------------------
 
 // K0a: per sample: discrete-Gamma mean rates from alpha, GTR eigendecomposition.
@@ -50,16 +69,16 @@ struct DevFamily {
 void launch_model_setup(int n, int R, const double* er, const double* pi, const double* alpha,
                         double* rates, double* eig, hipStream_t stream);
 
-// K0b: per (sample, rate, node): P = U exp(lambda t r) Uinv for inner nodes -> pmat[n][R][I][16];
-// for tips -> tipvec[n][R][T][5][4] (column s of P for s<4, row sums for s == 4 (N)).
+// K0b: per (sample, rate, inner node): P -> pmat[n][R][I][16].  (Tip branches are handled inside K1:
+// their P columns go straight into the workgroup's LDS tip table.)
 void launch_pmatrices(int n, int R, int T, const double* brlen, const double* rates, const double* eig,
-                      double* pmat, double* tipvec, hipStream_t stream);
+                      double* pmat, hipStream_t stream);
 
 // K1: Felsenstein pruning over the MSA sites with the naive tip factored out.
 // site_lik[n][R][5][L], site_scal[n][R][L]
 void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
-                  const double* pmat, const double* tipvec, const double* pi, double* site_lik,
-                  int32_t* site_scal, hipStream_t stream);
+                  const double* pmat, const double* eig, const double* rates, const double* brlen,
+                  const double* pi, double* site_lik, int32_t* site_scal, hipStream_t stream);
 
 // K2a: combine rate categories -> per-xMSA-column emission em[n][C] (FillXmsaEmission).
 void launch_xmsa_emission(const DevFamily& fam, int n, int R, const double* site_lik,

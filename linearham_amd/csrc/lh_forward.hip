@@ -110,9 +110,9 @@ struct FwdShared {
   double* gB;      // [max_genes] (pong)
   double* e1;      // [max_genes] emission products of the current region
   double* e2;      // [max_genes] padding emission products
-  double* fL[2];   // [max_left]
-  double* fN[2];   // [max_right*4]
-  double* fR[2];   // [max_right]
+  double *fL0, *fL1;   // [max_left]
+  double *fN0, *fN1;   // [max_right*4]
+  double *fR0, *fR1;   // [max_right]
   double* red;     // [4]
   int* redi;       // [4]
   int* cnt;        // [max_genes]
@@ -126,12 +126,22 @@ __device__ static int fill_segments(const DevSegments& seg, const double* em, do
   for (int g = threadIdx.x; g < seg.n_genes; g += kFwdThreads) {
     double v = 1.0;
     int c = 0;
-    const int j1 = seg.offsets[g + 1];
-    for (int j = seg.offsets[g]; j < j1; ++j) {
-      v *= em[seg.xmsa_inds[j]];
-      while (v > 0.0 && v < kScaleThreshold) {
-        v *= kScaleFactor;
-        ++c;
+    const int32_t* __restrict__ col = seg.inds_t + g;
+    const int stride = seg.n_genes;
+    for (int j0 = 0; j0 < seg.n_rows; j0 += 8) {
+      int idx[8];
+      double e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) idx[u] = col[(size_t)(j0 + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e[u] = em[idx[u]];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {  // padded factors are exactly 1.0: no effect on (v, c)
+        v *= e[u];
+        while (v > 0.0 && v < kScaleThreshold) {
+          v *= kScaleFactor;
+          ++c;
+        }
       }
     }
     out[g] = v;
@@ -155,35 +165,35 @@ __device__ static int junction_forward(const DevJunction& J, const FwdShared& sh
   const int W = J.n_rows, nL = J.n_left, nR = J.n_right;
   const double* em = sh.em;
   int count = count_in;
-  int cur = 0;
+  // explicit pointer ping-pong (indexing a pointer array with a run-time value would go to scratch)
+  double *fLc = sh.fL0, *fLp = sh.fL1, *fNc = sh.fN0, *fNp = sh.fN1, *fRc = sh.fR0, *fRp = sh.fR1;
   const size_t row_stride = (size_t)nL + 5 * (size_t)nR;
   for (int i = 0; i < W; ++i) {
-    const int prv = cur ^ 1;
     // rank-one cross-gene term: A = sum_l f_prev[l] * landing_out_l
     double part = 0.0;
     for (int t = threadIdx.x; t < nL; t += kFwdThreads) {
-      const double f = (i == 0) ? g_in[t] : sh.fL[prv][t];
+      const double f = (i == 0) ? g_in[t] : fLp[t];
       const double lo = (i == 0) ? J.enter_lo[t] : J.left_lo[(size_t)(i - 1) * nL + t];
       part += f * lo;
     }
     const double A = block_sum(part, sh.red);
     double mp = __builtin_inf();
     for (int t = threadIdx.x; t < nL; t += kFwdThreads) {
-      const double f = (i == 0) ? g_in[t] : sh.fL[prv][t];
+      const double f = (i == 0) ? g_in[t] : fLp[t];
       const double tr = (i == 0) ? J.enter_trans[t] : J.left_trans[(size_t)i * nL + t];
       const int idx = J.left_xmsa[(size_t)i * nL + t];
       const double v = (f * tr) * (idx >= 0 ? em[idx] : 0.0);
-      sh.fL[cur][t] = v;
+      fLc[t] = v;
       mp = posmin(mp, v);
     }
     for (int t = threadIdx.x; t < nR; t += kFwdThreads) {
       double n0 = 0, n1 = 0, n2 = 0, n3 = 0, fr = 0;
       if (i > 0) {
-        n0 = sh.fN[prv][t * 4 + 0];
-        n1 = sh.fN[prv][t * 4 + 1];
-        n2 = sh.fN[prv][t * 4 + 2];
-        n3 = sh.fN[prv][t * 4 + 3];
-        fr = sh.fR[prv][t];
+        n0 = fNp[t * 4 + 0];
+        n1 = fNp[t * 4 + 1];
+        n2 = fNp[t * 4 + 2];
+        n3 = fNp[t * 4 + 3];
+        fr = fRp[t];
       }
       const double* ntt = J.right_ntt + (size_t)t * 16;
 #pragma unroll
@@ -191,7 +201,7 @@ __device__ static int junction_forward(const DevJunction& J, const FwdShared& sh
         double s = ((n0 * ntt[b] + n1 * ntt[4 + b]) + n2 * ntt[8 + b]) + n3 * ntt[12 + b];
         s += A * J.right_gp_nli[(size_t)t * 4 + b];
         const double v = s * em[J.nti_xmsa[((size_t)i * nR + t) * 4 + b]];
-        sh.fN[cur][t * 4 + b] = v;
+        fNc[t * 4 + b] = v;
         mp = posmin(mp, v);
       }
       const double* nlo = J.right_nlo + ((size_t)i * nR + t) * 4;
@@ -200,39 +210,41 @@ __device__ static int junction_forward(const DevJunction& J, const FwdShared& sh
       s += A * J.right_gp_li[(size_t)i * nR + t];
       const int idx = J.right_xmsa[(size_t)i * nR + t];
       const double v = s * (idx >= 0 ? em[idx] : 0.0);
-      sh.fR[cur][t] = v;
+      fRc[t] = v;
       mp = posmin(mp, v);
     }
     const int k = scale_count(block_minpos(mp, sh.red));  // also orders the writes above
     if (k > 0) {
       for (int q = 0; q < k; ++q) {
-        for (int t = threadIdx.x; t < nL; t += kFwdThreads) sh.fL[cur][t] *= kScaleFactor;
-        for (int t = threadIdx.x; t < nR * 4; t += kFwdThreads) sh.fN[cur][t] *= kScaleFactor;
-        for (int t = threadIdx.x; t < nR; t += kFwdThreads) sh.fR[cur][t] *= kScaleFactor;
+        for (int t = threadIdx.x; t < nL; t += kFwdThreads) fLc[t] *= kScaleFactor;
+        for (int t = threadIdx.x; t < nR * 4; t += kFwdThreads) fNc[t] *= kScaleFactor;
+        for (int t = threadIdx.x; t < nR; t += kFwdThreads) fRc[t] *= kScaleFactor;
       }
       __syncthreads();
     }
     count += k;
     if (fwd_out) {
       double* o = fwd_out + (size_t)i * row_stride;
-      for (int t = threadIdx.x; t < nL; t += kFwdThreads) o[t] = sh.fL[cur][t];
-      for (int t = threadIdx.x; t < nR * 4; t += kFwdThreads) o[nL + t] = sh.fN[cur][t];
-      for (int t = threadIdx.x; t < nR; t += kFwdThreads) o[nL + 4 * (size_t)nR + t] = sh.fR[cur][t];
+      for (int t = threadIdx.x; t < nL; t += kFwdThreads) o[t] = fLc[t];
+      for (int t = threadIdx.x; t < nR * 4; t += kFwdThreads) o[nL + t] = fNc[t];
+      for (int t = threadIdx.x; t < nR; t += kFwdThreads) o[nL + 4 * (size_t)nR + t] = fRc[t];
     }
     if (scal_out && threadIdx.x == 0) scal_out[i] = count;
-    cur ^= 1;
+    double* t;
+    t = fLc; fLc = fLp; fLp = t;
+    t = fNc; fNc = fNp; fNp = t;
+    t = fRc; fRc = fRp; fRp = t;
   }
-  const int last = cur ^ 1;
   double part = 0.0;
   for (int t = threadIdx.x; t < nL; t += kFwdThreads)
-    part += sh.fL[last][t] * J.left_lo[(size_t)(W - 1) * nL + t];
+    part += fLp[t] * J.left_lo[(size_t)(W - 1) * nL + t];
   const double A = block_sum(part, sh.red);
   double mp = __builtin_inf();
   for (int t = threadIdx.x; t < nR; t += kFwdThreads) {
     const double* xn = J.exit_nlo + (size_t)t * 4;
-    const double* fn = sh.fN[last] + t * 4;
+    const double* fn = fNp + t * 4;
     double s = ((fn[0] * xn[0] + fn[1] * xn[1]) + fn[2] * xn[2]) + fn[3] * xn[3];
-    s += sh.fR[last][t] * J.exit_trans[t];
+    s += fRp[t] * J.exit_trans[t];
     s += A * J.exit_gp_li[t];
     double v = s * germ_em[t];
     if (pad_trans) v *= pad_trans[t];
@@ -260,23 +272,24 @@ __global__ void __launch_bounds__(kFwdThreads)
 
   FwdShared sh;
   double* p = lds;
-  sh.em = p;            p += (C + 1) & ~1;
+  sh.em = p;            p += (C + 2) & ~1;   // + sentinel em[C] = 1.0
   sh.gA = p;            p += max_genes;
   sh.gB = p;            p += max_genes;
   sh.e1 = p;            p += max_genes;
   sh.e2 = p;            p += max_genes;
-  sh.fL[0] = p;         p += max_left;
-  sh.fL[1] = p;         p += max_left;
-  sh.fN[0] = p;         p += 4 * max_right;
-  sh.fN[1] = p;         p += 4 * max_right;
-  sh.fR[0] = p;         p += max_right;
-  sh.fR[1] = p;         p += max_right;
+  sh.fL0 = p;           p += max_left;
+  sh.fL1 = p;           p += max_left;
+  sh.fN0 = p;           p += 4 * max_right;
+  sh.fN1 = p;           p += 4 * max_right;
+  sh.fR0 = p;           p += max_right;
+  sh.fR1 = p;           p += max_right;
   sh.red = p;           p += 4;
   sh.redi = reinterpret_cast<int*>(p);  p += 2;
   sh.cnt = reinterpret_cast<int*>(p);
 
   const double* em_g = em_all + (size_t)s * C;
   for (int c = threadIdx.x; c < C; c += kFwdThreads) sh.em[c] = em_g[c];
+  if (threadIdx.x == 0) sh.em[C] = 1.0;
   __syncthreads();
 
   double* fwd = fwd_all ? fwd_all + (size_t)s * fam.forward_size : nullptr;
@@ -369,7 +382,7 @@ void launch_xmsa_emission(const DevFamily& fam, int n, int R, const double* site
 }
 
 size_t forward_lds_bytes(const DevFamily& fam, int max_left, int max_right) {
-  size_t d = ((size_t)fam.n_xmsa + 1) & ~(size_t)1;
+  size_t d = ((size_t)fam.n_xmsa + 2) & ~(size_t)1;
   d += 4 * (size_t)fam.max_genes + 2 * (size_t)max_left + 10 * (size_t)max_right + 4 + 2;
   return d * sizeof(double) + (size_t)fam.max_genes * sizeof(int) + 16;
 }

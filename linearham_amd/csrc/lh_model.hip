@@ -192,46 +192,21 @@ __global__ void __launch_bounds__(64) model_setup_kernel(int n, int R, const dou
 __global__ void __launch_bounds__(256) pmatrix_kernel(int n, int R, int T, const double* __restrict__ brlen,
                                                       const double* __restrict__ rates,
                                                       const double* __restrict__ eig,
-                                                      double* __restrict__ pmat,
-                                                      double* __restrict__ tipvec) {
-  const int nodes = 2 * T - 2;
+                                                      double* __restrict__ pmat) {
+  const int I = T - 2, nodes = 2 * T - 2;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)n * R * nodes;
+  const long long total = (long long)n * R * I;
   if (gid >= total) return;
-  const int node = (int)(gid % nodes);
-  const int r = (int)((gid / nodes) % R);
-  const int s = (int)(gid / ((long long)nodes * R));
-
-  const double* e = eig + (size_t)s * 36;
-  const double tr = brlen[(size_t)s * nodes + node] * rates[(size_t)s * R + r];
-  double ex[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) ex[k] = expm1(e[k] * tr);
+  const int inner = (int)(gid % I);
+  const int r = (int)((gid / I) % R);
+  const int s = (int)(gid / ((long long)I * R));
   double P[4][4];
+  compute_pmatrix(eig + (size_t)s * 36, brlen[(size_t)s * nodes + T + inner] * rates[(size_t)s * R + r], P);
+  double* o = pmat + (((size_t)s * R + r) * I + inner) * 16;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      double v = (i == j) ? 1.0 : 0.0;  // P = I + U expm1(lambda t r) Uinv
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v = fma(e[4 + i * 4 + k] * ex[k], e[20 + k * 4 + j], v);
-      P[i][j] = fmax(v, 0.0);
-    }
-  if (node < T) {
-    double* o = tipvec + (((size_t)s * R + r) * T + node) * 20;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
-      o[16 + i] = ((P[i][0] + P[i][1]) + P[i][2]) + P[i][3];
-    }
-  } else {
-    double* o = pmat + (((size_t)s * R + r) * (T - 2) + (node - T)) * 16;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[i * 4 + j] = P[i][j];
-  }
+    for (int j = 0; j < 4; ++j) o[i * 4 + j] = P[i][j];
 }
 
 void launch_model_setup(int n, int R, const double* er, const double* pi, const double* alpha,
@@ -241,10 +216,10 @@ void launch_model_setup(int n, int R, const double* er, const double* pi, const 
 }
 
 void launch_pmatrices(int n, int R, int T, const double* brlen, const double* rates, const double* eig,
-                      double* pmat, double* tipvec, hipStream_t stream) {
-  const long long total = (long long)n * R * (2 * T - 2);
+                      double* pmat, hipStream_t stream) {
+  const long long total = (long long)n * R * (T - 2);
   hipLaunchKernelGGL(pmatrix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, n, R, T,
-                     brlen, rates, eig, pmat, tipvec);
+                     brlen, rates, eig, pmat);
 }
 
 }  // namespace lh
