@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="tree samples per GPU per step")
     ap.add_argument("--preset", default="config2", choices=["config2", "config4", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="kernel timing experiments only")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -154,7 +155,7 @@ def main():
                                       C.byref(groups)))
     lib.check(lib.lib.lh_profile_enable(C.c_void_p(fam_handle), 0))
     ll_host = loglik.cpu().numpy()
-    if not np.all(np.isfinite(ll_host)):
+    if not args.no_check and not np.all(np.isfinite(ll_host)):
         raise SystemExit("non-finite log-likelihoods in the benchmark batch")
 
     if rank == 0:

@@ -8,10 +8,6 @@
 
 #include "lh_device.h"
 
-namespace lh {
-size_t forward_lds_bytes(const DevFamily& fam, int max_left, int max_right);
-}
-
 namespace {
 
 thread_local std::string g_error;
@@ -30,8 +26,7 @@ int fail(const std::string& msg) {
 
 struct Workspace {
   int n_cap = 0, R = 0, T = 0;
-  double *rates = nullptr, *eig = nullptr, *pmat = nullptr, *site_lik = nullptr,
-         *em = nullptr;
+  double *rates = nullptr, *eig = nullptr, *pmat = nullptr, *tipvec = nullptr, *site_lik = nullptr;
   int32_t* site_scal = nullptr;
 };
 
@@ -51,6 +46,8 @@ struct lh_family {
   lh::DevFamily host{};            // device pointers inside
   lh::DevFamily* dev = nullptr;    // device copy of `host`
   std::vector<void*> allocs;
+  char* arena_ptr = nullptr;
+  size_t arena_left = 0;
   Workspace ws;
   Staging st;
   bool profile = false;
@@ -61,22 +58,34 @@ struct lh_family {
 
 namespace {
 
+// All family tables are sub-allocated from a few large device chunks: the forward kernel touches ~45
+// small tables per junction row, and one allocation (and page) per table costs TLB reach.
+int arena_alloc(lh_family* f, size_t bytes, void** out) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes == 0) bytes = 256;
+  if (f->arena_left < bytes) {
+    const size_t chunk = std::max(bytes, (size_t)8 << 20);
+    void* p = nullptr;
+    LH_HIP(hipMalloc(&p, chunk));
+    f->allocs.push_back(p);
+    f->arena_ptr = static_cast<char*>(p);
+    f->arena_left = chunk;
+  }
+  *out = f->arena_ptr;
+  f->arena_ptr += bytes;
+  f->arena_left -= bytes;
+  return 0;
+}
+
 template <typename T>
 int upload(lh_family* f, const T* src, size_t count, const T** dst) {
   *dst = nullptr;
-  if (count == 0) {
-    // keep a valid (dummy) pointer so kernels may form addresses
-    void* p = nullptr;
-    LH_HIP(hipMalloc(&p, 16));
-    f->allocs.push_back(p);
-    *dst = static_cast<const T*>(p);
-    return 0;
-  }
-  if (!src) return fail("lh_family_create: null array in descriptor");
   void* p = nullptr;
-  LH_HIP(hipMalloc(&p, count * sizeof(T)));
-  f->allocs.push_back(p);
-  LH_HIP(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  if (arena_alloc(f, count * sizeof(T), &p)) return 1;  // count == 0: a valid dummy address
+  if (count > 0) {
+    if (!src) return fail("lh_family_create: null array in descriptor");
+    LH_HIP(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  }
   *dst = static_cast<const T*>(p);
   return 0;
 }
@@ -144,8 +153,8 @@ int upload_junction(lh_family* f, const lh_junction& j, int n_xmsa, lh::DevJunct
 int ensure_workspace(lh_family* f, int n, int R, int T) {
   Workspace& w = f->ws;
   if (n <= w.n_cap && R == w.R && T == w.T) return 0;
-  void** bufs[] = {(void**)&w.rates, (void**)&w.eig,       (void**)&w.pmat,
-                   (void**)&w.site_lik, (void**)&w.em, (void**)&w.site_scal};
+  void** bufs[] = {(void**)&w.rates, (void**)&w.eig,       (void**)&w.pmat, (void**)&w.tipvec,
+                   (void**)&w.site_lik, (void**)&w.site_scal};
   for (void** b : bufs) {
     if (*b) LH_HIP(hipFree(*b));
     *b = nullptr;
@@ -155,10 +164,10 @@ int ensure_workspace(lh_family* f, int n, int R, int T) {
   const int cap = std::max(n, 1);
   LH_HIP(hipMalloc((void**)&w.rates, sizeof(double) * cap * R));
   LH_HIP(hipMalloc((void**)&w.eig, sizeof(double) * cap * 36));
-  LH_HIP(hipMalloc((void**)&w.pmat, sizeof(double) * cap * R * (size_t)std::max(T - 2, 1) * 16));
+  LH_HIP(hipMalloc((void**)&w.pmat, sizeof(double) * cap * R * (size_t)std::max(T - 2, 1) * 32));
+  LH_HIP(hipMalloc((void**)&w.tipvec, sizeof(double) * cap * R * (size_t)T * 20));
   LH_HIP(hipMalloc((void**)&w.site_lik, sizeof(double) * cap * R * 5 * std::max(L, (size_t)1)));
   LH_HIP(hipMalloc((void**)&w.site_scal, sizeof(int32_t) * cap * R * std::max(L, (size_t)1)));
-  LH_HIP(hipMalloc((void**)&w.em, sizeof(double) * cap * std::max(C, (size_t)1)));
   w.n_cap = cap;
   w.R = R;
   w.T = T;
@@ -180,12 +189,13 @@ int stage(lh_family* f, int slot, size_t bytes, void** out) {
 
 constexpr int kChunk = 8192;  // samples per launch group (bounds the workspace)
 
-int run_forward(lh_family* f, int n, const double* em_dev, double* loglik_dev, const lh_eval_outputs* outs,
+int run_forward(lh_family* f, int n, int R, const double* site_lik, const int32_t* site_scal, const double* pi,
+                const double* em_in, double* em_out, double* loglik_dev, const lh_eval_outputs* outs,
                 size_t sample_offset, hipStream_t stream) {
   double* fwd = (outs && outs->forward) ? outs->forward + sample_offset * f->host.forward_size : nullptr;
   int32_t* sco =
       (outs && outs->scaler_counts) ? outs->scaler_counts + sample_offset * f->host.scaler_size : nullptr;
-  lh::launch_forward(f->dev, f->host, n, em_dev, loglik_dev, fwd, sco, stream);
+  lh::launch_forward(f->host, n, R, site_lik, site_scal, pi, em_in, em_out, loglik_dev, fwd, sco, stream);
   LH_HIP(hipGetLastError());
   return 0;
 }
@@ -269,12 +279,7 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
       h.forward_size += h.dgerm.n_genes + (int64_t)h.dj.n_rows * (h.dj.n_left + 5 * (int64_t)h.dj.n_right);
       h.scaler_size += h.dj.n_rows + 1;
     }
-    int ml = h.vd.n_left, mr = h.vd.n_right;
-    if (h.has_d) {
-      ml = std::max(ml, h.dj.n_left);
-      mr = std::max(mr, h.dj.n_right);
-    }
-    if (lh::forward_lds_bytes(h, ml, mr) > 160 * 1024)
+    if (lh::forward_lds_bytes(h) > 160 * 1024 || h.max_genes > 1024)
       rc = fail("lh_family_create: family too large for the forward kernel's LDS working set");
   }
   if (!rc) {
@@ -301,7 +306,7 @@ void lh_family_destroy(lh_family* f) {
   if (!f) return;
   for (void* p : f->allocs) (void)hipFree(p);
   Workspace& w = f->ws;
-  void* bufs[] = {w.rates, w.eig, w.pmat, w.site_lik, w.em, w.site_scal};
+  void* bufs[] = {w.rates, w.eig, w.pmat, w.tipvec, w.site_lik, w.site_scal};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* p : f->st.ptr)
@@ -478,16 +483,18 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
       LH_HIP(hipEventRecord(es.e[0], stream));
     }
     double* rates = (outs && outs->rates) ? outs->rates + (size_t)off * R : w.rates;
-    double* em = (outs && outs->xmsa_emission) ? outs->xmsa_emission + (size_t)off * C : w.em;
+    double* em_out = (outs && outs->xmsa_emission) ? outs->xmsa_emission + (size_t)off * C : nullptr;
     lh::launch_model_setup(m, R, er + (size_t)off * 6, pi + (size_t)off * 4, alpha + off, rates, w.eig,
                            stream);
-    lh::launch_pmatrices(m, R, T, brlen + (size_t)off * nodes, rates, w.eig, w.pmat, stream);
+    lh::launch_pmatrices(m, R, T, ops + (size_t)off * n_ops * 4, brlen + (size_t)off * nodes, rates, w.eig, w.pmat,
+                         w.tipvec, stream);
     if (f->profile) LH_HIP(hipEventRecord(es.e[1], stream));
-    lh::launch_prune(f->host, m, R, T, max_depth, ops + (size_t)off * n_ops * 4, w.pmat, w.eig, rates,
-                     brlen + (size_t)off * nodes, pi + (size_t)off * 4, w.site_lik, w.site_scal, stream);
+    lh::launch_prune(f->host, m, R, T, max_depth, ops + (size_t)off * n_ops * 4, w.pmat, w.tipvec,
+                     pi + (size_t)off * 4, w.site_lik, w.site_scal, stream);
     if (f->profile) LH_HIP(hipEventRecord(es.e[2], stream));
-    lh::launch_xmsa_emission(f->host, m, R, w.site_lik, w.site_scal, pi + (size_t)off * 4, em, stream);
-    if (run_forward(f, m, em, loglik + off, outs, off, stream)) return 1;
+    if (run_forward(f, m, R, w.site_lik, w.site_scal, pi + (size_t)off * 4, nullptr, em_out, loglik + off, outs, off,
+                    stream))
+      return 1;
     if (f->profile) {
       LH_HIP(hipEventRecord(es.e[3], stream));
       f->events.push_back(es);
@@ -571,7 +578,8 @@ int lh_forward_batch(lh_family* f, int32_t n, const double* em, double* loglik, 
     if (outs->forward && stage(f, 8, sizeof(double) * FS * n, (void**)&d_outs.forward)) return 1;
     if (outs->scaler_counts && stage(f, 9, sizeof(int32_t) * SS * n, (void**)&d_outs.scaler_counts)) return 1;
   }
-  if (run_forward(f, n, (const double*)d_em, (double*)d_ll, &d_outs, 0, nullptr)) return 1;
+  if (run_forward(f, n, 1, nullptr, nullptr, nullptr, (const double*)d_em, nullptr, (double*)d_ll, &d_outs, 0, nullptr))
+    return 1;
   LH_HIP(hipDeviceSynchronize());
   LH_HIP(hipMemcpy(loglik, d_ll, sizeof(double) * n, hipMemcpyDeviceToHost));
   if (outs) {

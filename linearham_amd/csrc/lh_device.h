@@ -69,23 +69,24 @@ __device__ static inline void compute_pmatrix(const double* __restrict__ e, doub
 void launch_model_setup(int n, int R, const double* er, const double* pi, const double* alpha,
                         double* rates, double* eig, hipStream_t stream);
 
-// K0b: per (sample, rate, inner node): P -> pmat[n][R][I][16].  (Tip branches are handled inside K1:
-// their P columns go straight into the workgroup's LDS tip table.)
-void launch_pmatrices(int n, int R, int T, const double* brlen, const double* rates, const double* eig,
-                      double* pmat, hipStream_t stream);
+// K0b: P-matrices in schedule order: pmat[n][R][T-2][2][16] (op k: [0] = matrix of the child whose CLV is
+// in the accumulator, [1] = matrix of the popped child; unused slots are left untouched) and the tip
+// tables tipvec[n][R][T][5][4] (columns of P for A,C,G,T and the row sums for N).
+void launch_pmatrices(int n, int R, int T, const int32_t* ops, const double* brlen, const double* rates,
+                      const double* eig, double* pmat, double* tipvec, hipStream_t stream);
 
 // K1: Felsenstein pruning over the MSA sites with the naive tip factored out.
 // site_lik[n][R][5][L], site_scal[n][R][L]
 void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
-                  const double* pmat, const double* eig, const double* rates, const double* brlen,
-                  const double* pi, double* site_lik, int32_t* site_scal, hipStream_t stream);
+                  const double* pmat, const double* tipvec, const double* pi, double* site_lik,
+                  int32_t* site_scal, hipStream_t stream);
 
-// K2a: combine rate categories -> per-xMSA-column emission em[n][C] (FillXmsaEmission).
-void launch_xmsa_emission(const DevFamily& fam, int n, int R, const double* site_lik,
-                          const int32_t* site_scal, const double* pi, double* em, hipStream_t stream);
-
-// K2b: germline/padding emission products + scaled forward sweep -> loglik[n].
-void launch_forward(const DevFamily* fam_dev, const DevFamily& fam, int n, const double* em,
-                    double* loglik, double* forward_out, int32_t* scaler_out, hipStream_t stream);
+// K2: one wave per sample.  site_lik != null: emissions are assembled from K1's output (rate mix, log,
+// naive correction, exp; optionally written to em_out[n][C]); site_lik == null: emissions are taken
+// from em_in[n][C].  Then germline/padding emission products + scaled forward sweep -> loglik[n].
+void launch_forward(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
+                    const double* pi, const double* em_in, double* em_out, double* loglik, double* forward_out,
+                    int32_t* scaler_out, hipStream_t stream);
+size_t forward_lds_bytes(const DevFamily& fam);
 
 }  // namespace lh

@@ -189,24 +189,52 @@ __global__ void __launch_bounds__(64) model_setup_kernel(int n, int R, const dou
 
 // ---- K0b -------------------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) pmatrix_kernel(int n, int R, int T, const double* __restrict__ brlen,
+__global__ void __launch_bounds__(256) pmatrix_kernel(int n, int R, int T, const int32_t* __restrict__ ops,
+                                                      const double* __restrict__ brlen,
                                                       const double* __restrict__ rates,
                                                       const double* __restrict__ eig,
-                                                      double* __restrict__ pmat) {
-  const int I = T - 2, nodes = 2 * T - 2;
+                                                      double* __restrict__ pmat,
+                                                      double* __restrict__ tipvec) {
+  const int I = T - 2, nodes = 2 * T - 2, per = I + T;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)n * R * I;
+  const long long total = (long long)n * R * per;
   if (gid >= total) return;
-  const int inner = (int)(gid % I);
-  const int r = (int)((gid / I) % R);
-  const int s = (int)(gid / ((long long)I * R));
+  const int j = (int)(gid % per);
+  const int r = (int)((gid / per) % R);
+  const int s = (int)(gid / ((long long)per * R));
+  const double* e = eig + (size_t)s * 36;
+  const double rt = rates[(size_t)s * R + r];
+  const double* bl = brlen + (size_t)s * nodes;
   double P[4][4];
-  compute_pmatrix(eig + (size_t)s * 36, brlen[(size_t)s * nodes + T + inner] * rates[(size_t)s * R + r], P);
-  double* o = pmat + (((size_t)s * R + r) * I + inner) * 16;
+  if (j < T) {  // tip branch j: columns of P (+ row sums for N) in the layout of K1's LDS tip table
+    compute_pmatrix(e, bl[j] * rt, P);
+    double* o = tipvec + (((size_t)s * R + r) * T + j) * 20;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
+      o[16 + i] = ((P[i][0] + P[i][1]) + P[i][2]) + P[i][3];
+    }
+    return;
+  }
+  // op k of the schedule: matrices of its inner-node children, stored where K1 will stream them
+  const int k = j - T;
+  const int4 op = reinterpret_cast<const int4*>(ops)[(size_t)s * I + k];
+  const int kind = op.x & 15;
+  if (kind == OP_CHERRY) return;
+  double* o = pmat + (((size_t)s * R + r) * I + k) * 32;
+  compute_pmatrix(e, bl[op.z] * rt, P);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[i * 4 + j] = P[i][j];
+    for (int q = 0; q < 4; ++q) o[i * 4 + q] = P[i][q];
+  if (kind == OP_POP_ACC) {
+    compute_pmatrix(e, bl[op.y] * rt, P);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[16 + i * 4 + q] = P[i][q];
+  }
 }
 
 void launch_model_setup(int n, int R, const double* er, const double* pi, const double* alpha,
@@ -215,11 +243,11 @@ void launch_model_setup(int n, int R, const double* er, const double* pi, const 
                      rates, eig);
 }
 
-void launch_pmatrices(int n, int R, int T, const double* brlen, const double* rates, const double* eig,
-                      double* pmat, hipStream_t stream) {
-  const long long total = (long long)n * R * (T - 2);
-  hipLaunchKernelGGL(pmatrix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, n, R, T,
-                     brlen, rates, eig, pmat);
+void launch_pmatrices(int n, int R, int T, const int32_t* ops, const double* brlen, const double* rates,
+                      const double* eig, double* pmat, double* tipvec, hipStream_t stream) {
+  const long long total = (long long)n * R * (2 * T - 2);
+  hipLaunchKernelGGL(pmatrix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, n, R, T, ops,
+                     brlen, rates, eig, pmat, tipvec);
 }
 
 }  // namespace lh

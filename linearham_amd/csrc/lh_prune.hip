@@ -18,6 +18,8 @@
 //  * Tip children need no mat-vec: P * onehot(state) is a column of P.  Those columns (plus the
 //    row sums for N) are staged once per workgroup in LDS as tiptab[tip][state][4] and gathered
 //    with two ds_read_b128 per lane.
+//  * K0b stores the P-matrices of a (sample, rate) in schedule order, so the scalar loads of the loop
+//    stream through memory and the waves of a workgroup share every fetched line.
 //  * HBM traffic is therefore ~T bytes of tip states per site (L2-resident, shared by all samples)
 //    and 5 doubles out, instead of the 2*I*R*32 bytes per column of a CLV-streaming kernel.
 #include "lh_device.h"
@@ -44,8 +46,7 @@ template <int kDepth>
 __global__ void __launch_bounds__(512)
     prune_kernel(const uint8_t* __restrict__ msa, int L, int T, int n_ops,
                  const int32_t* __restrict__ ops, const double* __restrict__ pmat,
-                 const double* __restrict__ eig, const double* __restrict__ rates,
-                 const double* __restrict__ brlen, const double* __restrict__ pi,
+                 const double* __restrict__ tipvec, const double* __restrict__ pi,
                  double* __restrict__ site_lik, int32_t* __restrict__ site_scal) {
   extern __shared__ double2 smem2[];
   double* tiptab = reinterpret_cast<double*>(smem2);  // [T][5][4]
@@ -57,26 +58,19 @@ __global__ void __launch_bounds__(512)
   const int site_raw = blockIdx.x * blockDim.x + tid;
   const int site = site_raw < L ? site_raw : L - 1;
 
-  {  // tip table of this (sample, rate): columns of P(t_tip * r) and its row sums, straight into LDS
-    const double* __restrict__ e = eig + (size_t)sample * 36;
-    const double rt = rates[(size_t)sample * R + rate];
-    const double* __restrict__ bl = brlen + (size_t)sample * (2 * (size_t)T - 2);
-    for (int tip = tid; tip < T; tip += blockDim.x) {
-      double P[4][4];
-      compute_pmatrix(e, bl[tip] * rt, P);
-      double* o = tiptab + tip * 20;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
-        o[16 + i] = ((P[i][0] + P[i][1]) + P[i][2]) + P[i][3];
-      }
-    }
+  {  // stage this (sample, rate)'s tip table in LDS
+    const double2* src =
+        reinterpret_cast<const double2*>(tipvec + ((size_t)sample * R + rate) * (size_t)T * 20);
+    for (int i = tid; i < T * 10; i += blockDim.x) smem2[i] = src[i];
   }
   __syncthreads();
 
   const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
-  const double* __restrict__ pm = pmat + ((size_t)sample * R + rate) * (size_t)(T - 2) * 16;
+  // P-matrices in schedule order: op k's accumulator-child matrix at [k][0], its popped-child
+  // matrix at [k][1] (written by K0b), so the scalar loads walk memory sequentially and their
+  // addresses do not depend on the op descriptor.
+  const double* __restrict__ pm = pmat + ((size_t)sample * R + rate) * (size_t)(T - 2) * 32;
+  const uint8_t* __restrict__ msa_site = msa + site;
 
   double a0 = 1.0, a1 = 1.0, a2 = 1.0, a3 = 1.0;
   int scal = 0;
@@ -85,25 +79,8 @@ __global__ void __launch_bounds__(512)
   LH_DECL_SLOT(8) LH_DECL_SLOT(9) LH_DECL_SLOT(10) LH_DECL_SLOT(11)
   LH_DECL_SLOT(12) LH_DECL_SLOT(13) LH_DECL_SLOT(14) LH_DECL_SLOT(15)
 
-  // Software pipeline of the cheap part of the dependent chain: the descriptor of op k+1 and the tip
-  // states it needs are requested during iteration k (a handful of registers), so that at the top of
-  // an iteration the P-matrix scalar loads and the LDS tip gathers can issue at once.  (Prefetching
-  // the P-matrices themselves would need 128 SGPRs and spills to VGPR lanes.)
-  int4 op = op_ptr[0];
-  int4 op_next = op_ptr[n_ops > 1 ? 1 : 0];
-  int sa = 0, sb = 0;
-#define LH_FETCH_TIP_STATES()                                                            \
-  {                                                                                      \
-    const int kd = op.x & 15;                                                            \
-    if (kd != OP_POP_ACC) sa = (msa + (size_t)(op.y - 1) * L)[site];                     \
-    if (kd == OP_CHERRY) sb = (msa + (size_t)(op.z - 1) * L)[site];                      \
-  }
-  LH_FETCH_TIP_STATES()
-
   for (int k = 0; k < n_ops; ++k) {
-    // descriptor of op k+2: requested first, so that it has landed by the time the bottom of the
-    // iteration needs it (scalar loads complete out of order: any later lgkmcnt wait covers it)
-    const int4 op_after = op_ptr[k + 2 < n_ops ? k + 2 : n_ops - 1];
+    const int4 op = op_ptr[k];
     const int kind = op.x & 15;
     if (op.x & OP_PUSH_FLAG) {
       switch (op.w) {
@@ -124,6 +101,8 @@ __global__ void __launch_bounds__(512)
       }
     }
     if (kind == OP_CHERRY) {
+      const int sa = msa_site[(size_t)(op.y - 1) * L];
+      const int sb = msa_site[(size_t)(op.z - 1) * L];
       const double2* ta = reinterpret_cast<const double2*>(tiptab + op.y * 20 + sa * 4);
       const double2* tb = reinterpret_cast<const double2*>(tiptab + op.z * 20 + sb * 4);
       const double2 ta0 = ta[0], ta1 = ta[1], tb0 = tb[0], tb1 = tb[1];
@@ -132,12 +111,13 @@ __global__ void __launch_bounds__(512)
       a2 = ta1.x * tb1.x;
       a3 = ta1.y * tb1.y;
     } else {
-      const double* __restrict__ pb = pm + (size_t)(op.z - T) * 16;
+      const double* __restrict__ pb = pm + (size_t)k * 32;
       const double x0 = fma(pb[3], a3, fma(pb[2], a2, fma(pb[1], a1, pb[0] * a0)));
       const double x1 = fma(pb[7], a3, fma(pb[6], a2, fma(pb[5], a1, pb[4] * a0)));
       const double x2 = fma(pb[11], a3, fma(pb[10], a2, fma(pb[9], a1, pb[8] * a0)));
       const double x3 = fma(pb[15], a3, fma(pb[14], a2, fma(pb[13], a1, pb[12] * a0)));
       if (kind == OP_TIP_ACC) {
+        const int sa = msa_site[(size_t)(op.y - 1) * L];
         const double2* ta = reinterpret_cast<const double2*>(tiptab + op.y * 20 + sa * 4);
         const double2 ta0 = ta[0], ta1 = ta[1];
         a0 = ta0.x * x0;
@@ -162,7 +142,7 @@ __global__ void __launch_bounds__(512)
               }
             }
         }
-        const double* __restrict__ pa = pm + (size_t)(op.y - T) * 16;
+        const double* __restrict__ pa = pm + (size_t)k * 32 + 16;
         const double z0 = fma(pa[3], y3, fma(pa[2], y2, fma(pa[1], y1, pa[0] * y0)));
         const double z1 = fma(pa[7], y3, fma(pa[6], y2, fma(pa[5], y1, pa[4] * y0)));
         const double z2 = fma(pa[11], y3, fma(pa[10], y2, fma(pa[9], y1, pa[8] * y0)));
@@ -173,14 +153,13 @@ __global__ void __launch_bounds__(512)
         a3 = z3 * x3;
       }
     }
-    // bottom of the iteration: request the tip states of op k+1 and the descriptor of op k+2
-    op = op_next;
-    op_next = op_after;
-    LH_FETCH_TIP_STATES()
     // per-site, per-rate 2^256 rescaling (libpll PLL_ATTRIB_RATE_SCALERS semantics): the single
     // running counter is valid for the whole tree because scalers are additive along the traversal.
-    const double m = fmax(fmax(a0, a1), fmax(a2, a3));
-    if (m < kScaleThreshold && m > 0.0) {
+    // CLV entries are non-negative, so the largest has the largest high word; it is below 2^-256
+    // exactly when that word is below 0x2FF00000 (integer compares instead of 7 FP64 max/compare).
+    const unsigned hw = max(max((unsigned)__double2hiint(a0), (unsigned)__double2hiint(a1)),
+                            max((unsigned)__double2hiint(a2), (unsigned)__double2hiint(a3)));
+    if (hw < 0x2FF00000u && hw != 0u) {
       a0 *= kScaleFactor;
       a1 *= kScaleFactor;
       a2 *= kScaleFactor;
@@ -188,7 +167,6 @@ __global__ void __launch_bounds__(512)
       ++scal;
     }
   }
-#undef LH_FETCH_TIP_STATES
 
   // epilogue: close the naive branch for each possible naive state b (A,C,G,T,N):
   //   L_b = sum_i pi_i * clv_root[i] * P_naive[i][b]        (N: row sums of P_naive)
@@ -206,8 +184,8 @@ __global__ void __launch_bounds__(512)
 }
 
 void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
-                  const double* pmat, const double* eig, const double* rates, const double* brlen,
-                  const double* pi, double* site_lik, int32_t* site_scal, hipStream_t stream) {
+                  const double* pmat, const double* tipvec, const double* pi, double* site_lik,
+                  int32_t* site_scal, hipStream_t stream) {
   const int L = fam.n_sites;
   int threads = ((L + 63) / 64) * 64;
   if (threads > 512) threads = 512;
@@ -217,13 +195,13 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
   const size_t lds = (size_t)T * 20 * sizeof(double);
   dim3 grid(tiles, R, n), block(threads);
   const int n_ops = T - 2;
-#define LH_LAUNCH(D)                                                                                  \
-  {                                                                                                   \
-    if (lds > 64 * 1024)                                                                              \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(prune_kernel<D>),                             \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
-    hipLaunchKernelGGL(prune_kernel<D>, grid, block, lds, stream, fam.msa, L, T, n_ops, ops, pmat, eig, \
-                       rates, brlen, pi, site_lik, site_scal);                                        \
+#define LH_LAUNCH(D)                                                                                      \
+  {                                                                                                       \
+    if (lds > 64 * 1024)                                                                                  \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(prune_kernel<D>),                                 \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+    hipLaunchKernelGGL(prune_kernel<D>, grid, block, lds, stream, fam.msa, L, T, n_ops, ops, pmat, tipvec, \
+                       pi, site_lik, site_scal);                                                          \
   }
   if (max_depth <= 4)
     LH_LAUNCH(4)
