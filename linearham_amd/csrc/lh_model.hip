@@ -88,27 +88,21 @@ __global__ void __launch_bounds__(64) model_setup_kernel(int n, int R, const dou
                                                          const double* __restrict__ alpha,
                                                          double* __restrict__ rates,
                                                          double* __restrict__ eig) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
+  // R threads per sample, role-major so that a wave is homogeneous: roles 0..R-2 each solve ONE
+  // category boundary of the discrete Gamma, role R-1 does the GTR eigendecomposition.
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)n * R) return;
+  const int role = (int)(gid / n);
+  const int s = (int)(gid % n);
 
   // (a3) discrete-Gamma category means, equal weights: r_k = R [P(a+1, y_k) - P(a+1, y_{k-1})],
-  // y_k = a * (k/R quantile of Gamma(a, rate a)).
-  {
+  // y_k = a * (k/R quantile of Gamma(a, rate a)).  Here only the cumulative P(a+1, y_k) is produced
+  // (into rates[s][k-1]); finalize_rates_kernel turns the cumulatives into category means.
+  if (role < R - 1) {
     const double a = alpha[s];
-    double* r = rates + (size_t)s * R;
-    if (R == 1) {
-      r[0] = 1.0;
-    } else {
-      const double lga1 = lgamma(a + 1.0);
-      double prev = 0.0;
-      for (int k = 1; k < R; ++k) {
-        const double y = gamma_p_inv((double)k / R, a);
-        const double cum = gamma_p(a + 1.0, y, lga1);
-        r[k - 1] = (cum - prev) * R;
-        prev = cum;
-      }
-      r[R - 1] = (1.0 - prev) * R;
-    }
+    const double y = gamma_p_inv((double)(role + 1) / R, a);
+    rates[(size_t)s * R + role] = gamma_p(a + 1.0, y, lgamma(a + 1.0));
+    return;
   }
 
   // (a4) GTR: Q_ij = er_ij pi_j (AC,AG,AT,CG,CT,GT), diagonal = -row sum, scaled to mean rate 1.
@@ -187,6 +181,19 @@ __global__ void __launch_bounds__(64) model_setup_kernel(int n, int R, const dou
     }
 }
 
+__global__ void __launch_bounds__(256) finalize_rates_kernel(int n, int R, double* __restrict__ rates) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  double* r = rates + (size_t)s * R;
+  double prev = 0.0;
+  for (int k = 0; k < R - 1; ++k) {
+    const double cum = r[k];
+    r[k] = (cum - prev) * R;
+    prev = cum;
+  }
+  r[R - 1] = (1.0 - prev) * R;   // R == 1: the single rate is 1
+}
+
 // ---- K0b -------------------------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256) pmatrix_kernel(int n, int R, int T, const int32_t* __restrict__ ops,
@@ -239,8 +246,10 @@ __global__ void __launch_bounds__(256) pmatrix_kernel(int n, int R, int T, const
 
 void launch_model_setup(int n, int R, const double* er, const double* pi, const double* alpha,
                         double* rates, double* eig, hipStream_t stream) {
-  hipLaunchKernelGGL(model_setup_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, R, er, pi, alpha,
-                     rates, eig);
+  const long long total = (long long)n * R;
+  hipLaunchKernelGGL(model_setup_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, stream, n, R, er, pi,
+                     alpha, rates, eig);
+  hipLaunchKernelGGL(finalize_rates_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, R, rates);
 }
 
 void launch_pmatrices(int n, int R, int T, const int32_t* ops, const double* brlen, const double* rates,

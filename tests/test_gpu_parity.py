@@ -166,6 +166,20 @@ def test_synthetic_family(hip, tmp_path, preset):
         assert any(r["jgerm_scaler_count"] > 0 for r in ref)
 
 
+def test_large_tree_family(hip, tmp_path):
+    """BASELINE.json configs[4] shape: 500 leaves x 600 sites (LDS tip table > 64 KB, two site tiles,
+    deeper schedule stack), reduced germline set so that the dense oracle stays fast."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    spec = sf.Spec(n_leaves=500, n_sites=600, n_v=24, n_d=6, n_j=4, n_samples=2, seed=99)
+    sf.generate(spec, out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    desc, ll, res, ref = run_family(hip, h, rows, 4)
+    assert all(np.isfinite(r["loglik"]) for r in ref)
+    compare(h, desc, ll, res, ref)
+
+
 def test_gamma_rates_against_scipy(hip, data_dir):
     """K0a discrete-Gamma means over a grid of shapes (pll_compute_gamma_cats restatement)."""
     import linearham_amd
