@@ -166,6 +166,15 @@ def main():
         launches = max(groups.value, 1)
         prune_ms = ms[1].value / launches                        # average duration of one K1 launch
         achieved = bytes_per_eval * n / (prune_ms * 1e-3) / 1e9
+        # HBM traffic of one K1 launch from the committed PMC passes of this same command (counters need
+        # their own rocprofv3 runs; gfx950 correction: FETCH_SIZE counts wide coalesced reads at half).
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_v2_bench_pmc_per_launch.json")
+        if args.preset == "config2" and n == 4096 and os.path.exists(pmc_file):
+            with open(pmc_file) as f:
+                k1 = json.load(f).get("lh::prune_kernel<4>", {})
+            if "FETCH_SIZE" in k1 and "WRITE_SIZE" in k1:
+                traffic = (2.0 * k1["FETCH_SIZE"] + k1["WRITE_SIZE"]) * 1024.0
         out = {
             "metric": "phylo-HMM log-likelihood evals/sec (100-leaf x 400-site family)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -179,7 +188,7 @@ def main():
                        "G": sizes["g_total"], "sharding": "tree samples over ranks; one RCCL gather of log-likelihoods"},
             "roofline": {"bound": "hbm", "kernel": "prune_kernel (K1, Felsenstein pruning)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "algorithmic_bytes_per_eval": bytes_per_eval, "evals_per_launch": n,
                          "avg_launch_ms": prune_ms,
                          "note": "achieved = CLV-streaming model bytes (SURVEY 8(d)) / measured K1 time; the kernel "
@@ -188,6 +197,22 @@ def main():
             "kernel_ms_per_step": {"model_K0": ms[0].value / launches, "prune_K1": prune_ms,
                                    "forward_K2": ms[2].value / launches},
         }
+        if world == 1:
+            # PCIe-inclusive rate through the host-pointer entry point (never `value`): H2D of the
+            # flattened inputs, the same kernels, D2H of the log-likelihoods, synchronous per call.
+            ll_pcie = np.zeros(n)
+            p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+            h_ops, h_brl = np.ascontiguousarray(flat["ops"]), np.ascontiguousarray(flat["brlen"])
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                lib.check(lib.lib.lh_eval_batch(C.c_void_p(fam_handle), n, T, depth, p(h_ops, C.c_int32),
+                                                p(h_brl, C.c_double), p(flat["er"], C.c_double),
+                                                p(flat["pi"], C.c_double), p(flat["alpha"], C.c_double), R,
+                                                p(ll_pcie, C.c_double), None))
+            out["pcie_inclusive_evals_per_s"] = n * reps / (time.perf_counter() - t1)
+            if not args.no_check and not np.array_equal(ll_pcie, ll_host):
+                raise SystemExit("host-pointer and device-pointer entry points disagree")
         if world == 1 and not args.no_cpu_baseline:
             base, ref_ll = cpu_baseline(fam_dir, 64, args.cpu_budget_s)
             out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
