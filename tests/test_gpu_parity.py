@@ -59,13 +59,17 @@ def expand_forward(h, fam_desc, fwd, sco):
         spos += W
         return F, counts
     fb = h.flexbounds
-    out["vd_junction_forward"], out["vd_junction_scaler_counts"] = junction(
-        h.vd_junction, h.vgerm, h.dgerm, fam_desc.vd, fb["v_r"])
-    out["dgerm_forward"] = take(len(h.dgerm.state_strs))
-    out["dgerm_scaler_count"] = int(sco[spos])
-    spos += 1
-    out["dj_junction_forward"], out["dj_junction_scaler_counts"] = junction(
-        h.dj_junction, h.dgerm, h.jgerm, fam_desc.dj, fb["d_r"])
+    if h.locus == "igh":
+        out["vd_junction_forward"], out["vd_junction_scaler_counts"] = junction(
+            h.vd_junction, h.vgerm, h.dgerm, fam_desc.vd, fb["v_r"])
+        out["dgerm_forward"] = take(len(h.dgerm.state_strs))
+        out["dgerm_scaler_count"] = int(sco[spos])
+        spos += 1
+        out["dj_junction_forward"], out["dj_junction_scaler_counts"] = junction(
+            h.dj_junction, h.dgerm, h.jgerm, fam_desc.dj, fb["d_r"])
+    else:  # igk / igl: the single V-J junction lives in the vd_* members (src/HMM.cpp:276-286)
+        out["vd_junction_forward"], out["vd_junction_scaler_counts"] = junction(
+            h.vd_junction, h.vgerm, h.jgerm, fam_desc.vd, fb["v_r"])
     out["jgerm_forward"] = take(len(h.jgerm.state_strs))
     out["jgerm_scaler_count"] = int(sco[spos])
     return out
@@ -93,9 +97,11 @@ def run_family(hip, h, samples, num_rates):
         h.initialize_phylo_parameters(s["tree"], s["er"], s["pi"], s["alpha"], num_rates, is_path=False)
         h.initialize_phylo_emission()
         r = {"loglik": h.log_likelihood(), "rates": np.array(h.sr), "xmsa_emission": h.xmsa_emission.copy()}
-        for k in ["vgerm_forward", "vd_junction_forward", "dgerm_forward", "dj_junction_forward",
-                  "jgerm_forward", "vgerm_scaler_count", "vd_junction_scaler_counts", "dgerm_scaler_count",
-                  "dj_junction_scaler_counts", "jgerm_scaler_count"]:
+        keys = ["vgerm_forward", "vd_junction_forward", "jgerm_forward", "vgerm_scaler_count",
+                "vd_junction_scaler_counts", "jgerm_scaler_count"]
+        if h.locus == "igh":
+            keys += ["dgerm_forward", "dj_junction_forward", "dgerm_scaler_count", "dj_junction_scaler_counts"]
+        for k in keys:
             v = getattr(h, k)
             r[k] = v.copy() if isinstance(v, np.ndarray) else v
         ref.append(r)
@@ -109,11 +115,9 @@ def compare(h, desc, ll, res, ref, rtol=1e-10):
         np.testing.assert_allclose(res["rates"][i], r["rates"], rtol=1e-9)
         np.testing.assert_allclose(res["xmsa_emission"][i], r["xmsa_emission"], rtol=1e-9)
         ex = expand_forward(h, desc, res["forward"][i], res["scaler_counts"][i])
-        for k in ["vgerm_scaler_count", "vd_junction_scaler_counts", "dgerm_scaler_count",
-                  "dj_junction_scaler_counts", "jgerm_scaler_count"]:
+        for k in [k for k in ex if "scaler" in k]:
             assert ex[k] == r[k], (i, k, ex[k], r[k])
-        for k in ["vgerm_forward", "vd_junction_forward", "dgerm_forward", "dj_junction_forward",
-                  "jgerm_forward"]:
+        for k in [k for k in ex if k.endswith("_forward")]:
             np.testing.assert_allclose(ex[k], r[k], rtol=1e-9, atol=0, err_msg="%d %s" % (i, k))
 
 
@@ -150,13 +154,16 @@ def test_batch_of_varied_models_on_toy_family(hip, data_dir):
     compare(h, desc, ll, res, ref)
 
 
-@pytest.mark.parametrize("preset", ["small", "medium"])
+@pytest.mark.parametrize("preset", ["small", "medium", "igk", "igl"])
 def test_synthetic_family(hip, tmp_path, preset):
     """Multi-allele junctions, NNI-perturbed trees with [&index=..] annotations; the medium family
-    (40 leaves) drives the 2^256 scaler counts above zero."""
+    (40 leaves) drives the 2^256 scaler counts above zero; igk/igl are light-chain families (no D
+    segment, one V-J junction: src/HMM.cpp:124-131,163-170,225-242,276-286)."""
     from tools import synth_family as sf
     out = str(tmp_path / "fam")
-    spec = sf.Spec.small() if preset == "small" else sf.Spec.small(n_leaves=40, n_samples=3, seed=11)
+    spec = {"small": sf.Spec.small(), "medium": sf.Spec.small(n_leaves=40, n_samples=3, seed=11),
+            "igk": sf.Spec.small(locus="igk", n_samples=3, seed=5),
+            "igl": sf.Spec.small(locus="igl", n_leaves=30, n_samples=3, seed=6)}[preset]
     sf.generate(spec, out)
     h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
     rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))

@@ -59,10 +59,11 @@ def test_phylo_hmm_state_space_transitions_xmsa(goldens, data_dir, case):
     assert n >= 65
 
 
-def test_synthetic_family_host_matches_oracle(tmp_path):
+@pytest.mark.parametrize("locus", ["igh", "igk"])
+def test_synthetic_family_host_matches_oracle(tmp_path, locus):
     from tools import synth_family as sf
     out = str(tmp_path / "fam")
-    sf.generate(sf.Spec.small(), out)
+    sf.generate(sf.Spec.small(locus=locus), out)
     yaml_path, pdir = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params")
     o = orc.PhyloHMM(yaml_path, 0, pdir, 0)
     h = host.PhyloHMM(yaml_path, 0, pdir, 0)

@@ -76,12 +76,13 @@ def test_phylo_hmm(goldens, data_dir, case, params, R):
             assert s[k] == want[k], k
 
 
-def test_run_pipeline_matches_oracle(tmp_path):
+@pytest.mark.parametrize("locus", ["igh", "igk"])
+def test_run_pipeline_matches_oracle(tmp_path, locus):
     """PhyloHMM::RunPipeline (src/PhyloHMM.cpp:393-446) on a synthetic RevBayes table: batched GPU
     evaluation + in-order host sampling must reproduce the row-by-row oracle, including the RNG stream."""
     from tools import synth_family as sf
     out = str(tmp_path / "fam")
-    sf.generate(sf.Spec.small(n_samples=9), out)
+    sf.generate(sf.Spec.small(n_samples=9, locus=locus), out)
     yaml_path, pdir, tsv = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params"), os.path.join(out, "trees.tsv")
     h = host.PhyloHMM(yaml_path, 0, pdir, 3)
     res = os.path.join(out, "lh.tsv")
@@ -103,13 +104,18 @@ def test_run_pipeline_matches_oracle(tmp_path):
         assert abs(float(got[col["LogWeight"]]) - (ll - r["likelihood"])) <= 5e-6 * abs(ll - r["likelihood"]) + 1e-9
         assert got[col["NaiveSequence"]] == seq
         assert got[col["VGene"]] == o.sample["vgerm_state_str_samp"]
-        assert got[col["DGene"]] == o.sample["dgerm_state_str_samp"]
         assert got[col["JGene"]] == o.sample["jgerm_state_str_samp"]
-        assert got[col["VDInsertion"]] == o.sample["vd_junction_insertion_samp"]
-        assert got[col["DJInsertion"]] == o.sample["dj_junction_insertion_samp"]
-        for k, c in [("vgerm_left_del_samp", "V5pDel"), ("vgerm_right_del_samp", "V3pDel"),
-                     ("dgerm_left_del_samp", "D5pDel"), ("dgerm_right_del_samp", "D3pDel"),
-                     ("jgerm_left_del_samp", "J5pDel"), ("jgerm_right_del_samp", "J3pDel")]:
+        dels = [("vgerm_left_del_samp", "V5pDel"), ("vgerm_right_del_samp", "V3pDel"),
+                ("jgerm_left_del_samp", "J5pDel"), ("jgerm_right_del_samp", "J3pDel")]
+        if locus == "igh":
+            assert got[col["DGene"]] == o.sample["dgerm_state_str_samp"]
+            assert got[col["VDInsertion"]] == o.sample["vd_junction_insertion_samp"]
+            assert got[col["DJInsertion"]] == o.sample["dj_junction_insertion_samp"]
+            dels += [("dgerm_left_del_samp", "D5pDel"), ("dgerm_right_del_samp", "D3pDel")]
+        else:
+            assert "DGene" not in col
+            assert got[col["VJInsertion"]] == o.sample["vd_junction_insertion_samp"]
+        for k, c in dels:
             assert int(got[col[c]]) == o.sample[k], c
         np.testing.assert_allclose([float(got[col["sr[%d]" % i]]) for i in range(1, 5)], o.sr, rtol=5e-6)
         # the re-exported tree is the same unrooted tree

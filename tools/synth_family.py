@@ -29,15 +29,21 @@ class Spec:
 
     def __init__(self, n_leaves=100, n_sites=400, n_v=200, n_d=30, n_j=12, len_v=296, len_d=(11, 37),
                  len_j=(48, 63), v_l_width=3, v_r_width=10, n_samples=256, n_nni=4, seed=20261004,
-                 v_ancestors=7, d_ancestors=4, j_ancestors=3, divergence=0.05):
+                 v_ancestors=7, d_ancestors=4, j_ancestors=3, divergence=0.05, locus="igh"):
         self.__dict__.update(locals())
         del self.__dict__["self"]
         v_r = (len_v - v_r_width, len_v)
         d_l = (v_r[1] + 3, v_r[1] + 13) if len_v >= 100 else (v_r[1] + 1, v_r[1] + 5)
         d_r = (d_l[1] + 3, d_l[1] + 15) if len_v >= 100 else (d_l[1] + 2, d_l[1] + 6)
         j_l = (d_r[1] + 4, d_r[1] + 18) if len_v >= 100 else (d_r[1] + 2, d_r[1] + 7)
-        self.flexbounds = {"v_l": (0, v_l_width), "v_r": v_r, "d_l": d_l, "d_r": d_r, "j_l": j_l,
-                           "j_r": (n_sites, n_sites)}
+        if locus == "igh":
+            self.flexbounds = {"v_l": (0, v_l_width), "v_r": v_r, "d_l": d_l, "d_r": d_r, "j_l": j_l,
+                               "j_r": (n_sites, n_sites)}
+        else:  # igk / igl: no D segment, a single V-J junction (src/HMM.cpp:124-131,163-170)
+            assert locus in ("igk", "igl")
+            j_l = (v_r[1] + 3, v_r[1] + 13) if len_v >= 100 else (v_r[1] + 1, v_r[1] + 5)
+            self.flexbounds = {"v_l": (0, v_l_width), "v_r": v_r, "j_l": j_l, "j_r": (n_sites, n_sites)}
+            self.n_d = 0
         assert j_l[1] + 4 < n_sites, "n_sites too small for this layout"
 
     @staticmethod
@@ -180,7 +186,7 @@ def make_germline_set(spec, outdir, rng):
             seq = ancestors[anc][relpos + 40:relpos + 40 + ln]
             if k >= n_anc:
                 seq = _mutate(seq, spec.divergence, rng)
-            name = "IGH%s_syn%d_star_%02d" % (gtype, anc + 1, k // n_anc + 1)
+            name = "IG%s%s_syn%d_star_%02d" % (spec.locus[2].upper(), gtype, anc + 1, k // n_anc + 1)
             write_allele(os.path.join(outdir, name + ".yaml"), name, gtype, seq, max(float(probs[k]), 1e-6),
                          rng)
             genes[gtype].append((name.replace("_star_", "*"), seq, relpos))
@@ -306,13 +312,16 @@ def generate(spec, outdir):
     L = spec.n_sites
     # true rearrangement: allele 0 of each segment, placed at its own relpos
     vname, vseq, v_relpos = genes["V"][0]
-    dname, dseq, d_relpos = genes["D"][0]
     jname, jseq, j_relpos = genes["J"][0]
+    if spec.locus == "igh":
+        dname, dseq, d_relpos = genes["D"][0]
+    else:
+        dseq, d_relpos = "", fb["v_r"][1]
     rng_s = np.random.default_rng(spec.seed + 3)
     v_end = fb["v_r"][1] - 2                                # V 3' deletion
     d_del5 = 1
     d_start = d_relpos + d_del5
-    d_end = min(d_relpos + len(dseq), fb["d_r"][1] - 1)
+    d_end = min(d_relpos + len(dseq), fb["d_r"][1] - 1) if spec.locus == "igh" else d_start
     j_del5 = 2
     j_start = j_relpos + j_del5
     j_end = min(j_relpos + len(jseq), L)
@@ -346,7 +355,7 @@ def generate(spec, outdir):
         relpos[name] = rp_
         assert rp_ <= fb["j_l"][1]
     cluster = {
-        "germline-info": {"locus": "igh"},
+        "germline-info": {"locus": spec.locus},
         "events": [{
             "input_seqs": [to_str(seqs[i]) for i in range(1, T)],
             "naive_seq": to_str(naive),
