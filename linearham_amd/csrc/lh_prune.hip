@@ -22,6 +22,8 @@
 //    stream through memory and the waves of a workgroup share every fetched line.
 //  * HBM traffic is therefore ~T bytes of tip states per site (L2-resident, shared by all samples)
 //    and 5 doubles out, instead of the 2*I*R*32 bytes per column of a CLV-streaming kernel.
+#include <cstdlib>
+
 #include "lh_device.h"
 
 namespace lh {
@@ -44,7 +46,7 @@ namespace lh {
 
 template <int kDepth>
 __global__ void __launch_bounds__(512)
-    prune_kernel(const uint8_t* __restrict__ msa, int L, int T, int n_ops,
+    prune_kernel(int compute_threads, int ahead, const uint8_t* __restrict__ msa, int L, int T, int n_ops,
                  const int32_t* __restrict__ ops, const double* __restrict__ pmat,
                  const double* __restrict__ tipvec, const double* __restrict__ pi,
                  double* __restrict__ site_lik, int32_t* __restrict__ site_scal) {
@@ -55,7 +57,7 @@ __global__ void __launch_bounds__(512)
   const int R = gridDim.y;
   const int rate = blockIdx.y;
   const int sample = blockIdx.z;
-  const int site_raw = blockIdx.x * blockDim.x + tid;
+  const int site_raw = blockIdx.x * compute_threads + tid;
   const int site = site_raw < L ? site_raw : L - 1;
 
   {  // stage this (sample, rate)'s tip table in LDS
@@ -63,6 +65,8 @@ __global__ void __launch_bounds__(512)
         reinterpret_cast<const double2*>(tipvec + ((size_t)sample * R + rate) * (size_t)T * 20);
     for (int i = tid; i < T * 10; i += blockDim.x) smem2[i] = src[i];
   }
+  int* progress = reinterpret_cast<int*>(smem2 + T * 10);  // furthest op any compute wave has reached
+  if (tid == 0) *progress = 0;
   __syncthreads();
 
   const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
@@ -71,6 +75,34 @@ __global__ void __launch_bounds__(512)
   // addresses do not depend on the op descriptor.
   const double* __restrict__ pm = pmat + ((size_t)sample * R + rate) * (size_t)(T - 2) * 32;
   const uint8_t* __restrict__ msa_site = msa + site;
+
+  if (tid >= compute_threads) {
+    // Prefetcher wave.  The P-matrix scalar loads of the compute waves miss the 16 KB scalar cache
+    // (four workgroups stream 25 KB each through it); measured, those misses were 27 % of the kernel.
+    // A touch issued by a compute wave would not help -- scalar loads return out of order, so its next
+    // s_waitcnt lgkmcnt(0) would wait for the touch as well -- but this extra wave can take the
+    // misses instead: it walks the same P-matrix stream a few ops ahead of the compute waves (paced by
+    // the progress word in LDS) and pulls every 64-byte line into the scalar cache.  (Plain loads
+    // whose values feed a never-true store: inline asm here doubled the kernel's VGPR allocation.)
+    const int* __restrict__ pwords = reinterpret_cast<const int*>(pm);
+    const int* __restrict__ owords = reinterpret_cast<const int*>(op_ptr);
+    int pf = 0, sink = 0;
+    for (int spins = 0; pf < n_ops && spins < (1 << 24); ++spins) {
+      int target = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(progress)) + ahead;
+      target = target < n_ops ? target : n_ops;
+      if (pf >= target) {
+        __builtin_amdgcn_s_sleep(4);
+        continue;
+      }
+      for (; pf < target; ++pf) {
+        const int* q = pwords + (size_t)pf * 64;  // 256 bytes = four 64-byte lines per op
+        sink ^= q[0] ^ q[16] ^ q[32] ^ q[48];
+        sink ^= owords[(size_t)(pf + 4 < n_ops ? pf + 4 : pf) * 4];
+      }
+    }
+    if (sink == 0x5a17c0de) site_scal[0] = sink;  // practically never; keeps the touches alive
+    return;
+  }
 
   double a0 = 1.0, a1 = 1.0, a2 = 1.0, a3 = 1.0;
   int scal = 0;
@@ -81,6 +113,7 @@ __global__ void __launch_bounds__(512)
 
   for (int k = 0; k < n_ops; ++k) {
     const int4 op = op_ptr[k];
+    if ((tid & 63) == 0) atomicMax(progress, k);  // paces the prefetcher wave
     const int kind = op.x & 15;
     if (op.x & OP_PUSH_FLAG) {
       switch (op.w) {
@@ -187,21 +220,22 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
                   const double* pmat, const double* tipvec, const double* pi, double* site_lik,
                   int32_t* site_scal, hipStream_t stream) {
   const int L = fam.n_sites;
-  int threads = ((L + 63) / 64) * 64;
-  if (threads > 512) threads = 512;
-  const int tiles = (L + threads - 1) / threads;
-  // rebalance so the tiles are equally full
-  threads = (((L + tiles - 1) / tiles) + 63) / 64 * 64;
-  const size_t lds = (size_t)T * 20 * sizeof(double);
-  dim3 grid(tiles, R, n), block(threads);
+  // up to 7 compute waves (448 sites) + 1 prefetcher wave per workgroup
+  int compute = ((L + 63) / 64) * 64;
+  if (compute > 448) compute = 448;
+  const int tiles = (L + compute - 1) / compute;
+  compute = (((L + tiles - 1) / tiles) + 63) / 64 * 64;  // rebalance so the tiles are equally full
+  const size_t lds = (size_t)T * 20 * sizeof(double) + 16;
+  dim3 grid(tiles, R, n), block(compute + 64);
   const int n_ops = T - 2;
+  static const int ahead = getenv("LH_K1_AHEAD") ? atoi(getenv("LH_K1_AHEAD")) : 8;
 #define LH_LAUNCH(D)                                                                                      \
   {                                                                                                       \
     if (lds > 64 * 1024)                                                                                  \
       hipFuncSetAttribute(reinterpret_cast<const void*>(prune_kernel<D>),                                 \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-    hipLaunchKernelGGL(prune_kernel<D>, grid, block, lds, stream, fam.msa, L, T, n_ops, ops, pmat, tipvec, \
-                       pi, site_lik, site_scal);                                                          \
+    hipLaunchKernelGGL(prune_kernel<D>, grid, block, lds, stream, compute, ahead, fam.msa, L, T, n_ops, ops, pmat, \
+                       tipvec, pi, site_lik, site_scal);                                                  \
   }
   if (max_depth <= 4)
     LH_LAUNCH(4)
