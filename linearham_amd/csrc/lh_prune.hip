@@ -111,8 +111,18 @@ __global__ void __launch_bounds__(512)
   LH_DECL_SLOT(8) LH_DECL_SLOT(9) LH_DECL_SLOT(10) LH_DECL_SLOT(11)
   LH_DECL_SLOT(12) LH_DECL_SLOT(13) LH_DECL_SLOT(14) LH_DECL_SLOT(15)
 
+  // Software pipeline across iterations: op k's descriptor and tip states were requested during
+  // iteration k-1, so an iteration starts with everything but its P-matrices at hand (and those come
+  // from addresses that depend on k only).
+  int4 op = op_ptr[0];
+  int sa = 0, sb = 0;
+  {
+    const int kd = op.x & 15;
+    if (kd != OP_POP_ACC) sa = msa_site[(size_t)(op.y - 1) * L];
+    if (kd == OP_CHERRY) sb = msa_site[(size_t)(op.z - 1) * L];
+  }
   for (int k = 0; k < n_ops; ++k) {
-    const int4 op = op_ptr[k];
+    const int4 op_next = op_ptr[k + 1 < n_ops ? k + 1 : k];
     if ((tid & 63) == 0) atomicMax(progress, k);  // paces the prefetcher wave
     const int kind = op.x & 15;
     if (op.x & OP_PUSH_FLAG) {
@@ -134,8 +144,6 @@ __global__ void __launch_bounds__(512)
       }
     }
     if (kind == OP_CHERRY) {
-      const int sa = msa_site[(size_t)(op.y - 1) * L];
-      const int sb = msa_site[(size_t)(op.z - 1) * L];
       const double2* ta = reinterpret_cast<const double2*>(tiptab + op.y * 20 + sa * 4);
       const double2* tb = reinterpret_cast<const double2*>(tiptab + op.z * 20 + sb * 4);
       const double2 ta0 = ta[0], ta1 = ta[1], tb0 = tb[0], tb1 = tb[1];
@@ -150,7 +158,6 @@ __global__ void __launch_bounds__(512)
       const double x2 = fma(pb[11], a3, fma(pb[10], a2, fma(pb[9], a1, pb[8] * a0)));
       const double x3 = fma(pb[15], a3, fma(pb[14], a2, fma(pb[13], a1, pb[12] * a0)));
       if (kind == OP_TIP_ACC) {
-        const int sa = msa_site[(size_t)(op.y - 1) * L];
         const double2* ta = reinterpret_cast<const double2*>(tiptab + op.y * 20 + sa * 4);
         const double2 ta0 = ta[0], ta1 = ta[1];
         a0 = ta0.x * x0;
@@ -188,6 +195,12 @@ __global__ void __launch_bounds__(512)
     }
     // per-site, per-rate 2^256 rescaling (libpll PLL_ATTRIB_RATE_SCALERS semantics): the single
     // running counter is valid for the whole tree because scalers are additive along the traversal.
+    op = op_next;
+    {
+      const int kd = op.x & 15;
+      if (kd != OP_POP_ACC) sa = msa_site[(size_t)(op.y - 1) * L];
+      if (kd == OP_CHERRY) sb = msa_site[(size_t)(op.z - 1) * L];
+    }
     // CLV entries are non-negative, so the largest has the largest high word; it is below 2^-256
     // exactly when that word is below 0x2FF00000 (integer compares instead of 7 FP64 max/compare).
     const unsigned hw = max(max((unsigned)__double2hiint(a0), (unsigned)__double2hiint(a1)),
