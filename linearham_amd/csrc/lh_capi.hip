@@ -30,6 +30,12 @@ struct Workspace {
   int32_t* site_scal = nullptr;
 };
 
+struct ForwardWs {  // K2a -> K2b hand-off, sized by the largest batch seen
+  int n_cap = 0;
+  double *gem = nullptr, *jem = nullptr;
+  int32_t* gcnt = nullptr;
+};
+
 struct Staging {  // device copies of host inputs/outputs for the host-pointer entry points
   size_t cap[10] = {0};
   void* ptr[10] = {nullptr};
@@ -49,6 +55,7 @@ struct lh_family {
   char* arena_ptr = nullptr;
   size_t arena_left = 0;
   Workspace ws;
+  ForwardWs fws;
   Staging st;
   bool profile = false;
   std::vector<EventSet> events;
@@ -123,27 +130,48 @@ int check_idx(const int32_t* a, size_t n, int n_xmsa, bool allow_neg, const char
   return 0;
 }
 
-int upload_junction(lh_family* f, const lh_junction& j, int n_xmsa, lh::DevJunction* d) {
+// Validates a junction's emission-column indices and marks the columns it uses.
+int collect_junction_cols(const lh_junction& j, int n_xmsa, std::vector<int32_t>* used) {
   const size_t W = j.n_rows, nL = j.n_left, nR = j.n_right;
   if (j.n_rows < 1 || j.n_left < 0 || j.n_right < 0) return fail("junction: bad dimensions");
-  d->n_rows = j.n_rows;
-  d->n_left = j.n_left;
-  d->n_right = j.n_right;
   if (check_idx(j.left_xmsa, W * nL, n_xmsa, true, "left_xmsa")) return 1;
   if (check_idx(j.right_xmsa, W * nR, n_xmsa, true, "right_xmsa")) return 1;
   if (check_idx(j.nti_xmsa, W * nR * 4, n_xmsa, false, "nti_xmsa")) return 1;
+  auto mark = [&](const int32_t* p, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+      if (p[i] >= 0) (*used)[p[i]] = 1;
+  };
+  mark(j.left_xmsa, W * nL);
+  mark(j.right_xmsa, W * nR);
+  mark(j.nti_xmsa, W * nR * 4);
+  return 0;
+}
+
+// Uploads xMSA indices translated to positions in the compact junction-column list.
+int upload_remapped(lh_family* f, const int32_t* src, size_t n, const std::vector<int32_t>& remap,
+                    const int32_t** out) {
+  std::vector<int32_t> t(n);
+  for (size_t i = 0; i < n; ++i) t[i] = src[i] >= 0 ? remap[src[i]] : -1;
+  return upload(f, t.data(), n, out);
+}
+
+int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_t>& remap, lh::DevJunction* d) {
+  const size_t W = j.n_rows, nL = j.n_left, nR = j.n_right;
+  d->n_rows = j.n_rows;
+  d->n_left = j.n_left;
+  d->n_right = j.n_right;
   if (upload(f, j.enter_trans, nL, &d->enter_trans)) return 1;
   if (upload(f, j.enter_lo, nL, &d->enter_lo)) return 1;
   if (upload(f, j.left_trans, W * nL, &d->left_trans)) return 1;
   if (upload(f, j.left_lo, W * nL, &d->left_lo)) return 1;
-  if (upload(f, j.left_xmsa, W * nL, &d->left_xmsa)) return 1;
+  if (upload_remapped(f, j.left_xmsa, W * nL, remap, &d->left_xmsa)) return 1;
   if (upload(f, j.right_gp_nli, nR * 4, &d->right_gp_nli)) return 1;
   if (upload(f, j.right_ntt, nR * 16, &d->right_ntt)) return 1;
   if (upload(f, j.right_nlo, W * nR * 4, &d->right_nlo)) return 1;
   if (upload(f, j.right_trans, W * nR, &d->right_trans)) return 1;
   if (upload(f, j.right_gp_li, W * nR, &d->right_gp_li)) return 1;
-  if (upload(f, j.right_xmsa, W * nR, &d->right_xmsa)) return 1;
-  if (upload(f, j.nti_xmsa, W * nR * 4, &d->nti_xmsa)) return 1;
+  if (upload_remapped(f, j.right_xmsa, W * nR, remap, &d->right_xmsa)) return 1;
+  if (upload_remapped(f, j.nti_xmsa, W * nR * 4, remap, &d->nti_xmsa)) return 1;
   if (upload(f, j.exit_nlo, nR * 4, &d->exit_nlo)) return 1;
   if (upload(f, j.exit_trans, nR, &d->exit_trans)) return 1;
   if (upload(f, j.exit_gp_li, nR, &d->exit_gp_li)) return 1;
@@ -195,7 +223,23 @@ int run_forward(lh_family* f, int n, int R, const double* site_lik, const int32_
   double* fwd = (outs && outs->forward) ? outs->forward + sample_offset * f->host.forward_size : nullptr;
   int32_t* sco =
       (outs && outs->scaler_counts) ? outs->scaler_counts + sample_offset * f->host.scaler_size : nullptr;
-  lh::launch_forward(f->host, n, R, site_lik, site_scal, pi, em_in, em_out, loglik_dev, fwd, sco, stream);
+  ForwardWs& w = f->fws;
+  if (n > w.n_cap) {
+    // growing the hand-off buffers: earlier launches on other streams may still be using them
+    LH_HIP(hipDeviceSynchronize());
+    void** bufs[] = {(void**)&w.gem, (void**)&w.jem, (void**)&w.gcnt};
+    for (void** b : bufs) {
+      if (*b) LH_HIP(hipFree(*b));
+      *b = nullptr;
+    }
+    w.n_cap = 0;
+    LH_HIP(hipMalloc((void**)&w.gem, sizeof(double) * (size_t)n * std::max<int64_t>(f->host.gem_size, 1)));
+    LH_HIP(hipMalloc((void**)&w.jem, sizeof(double) * (size_t)n * std::max(f->host.n_jcols, 1)));
+    LH_HIP(hipMalloc((void**)&w.gcnt, sizeof(int32_t) * (size_t)n * 3));
+    w.n_cap = n;
+  }
+  lh::launch_forward(f->host, n, R, site_lik, site_scal, pi, em_in, em_out, w.gem, w.gcnt, w.jem, loglik_dev, fwd,
+                     sco, stream);
   LH_HIP(hipGetLastError());
   return 0;
 }
@@ -257,11 +301,27 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
   rc = rc || upload(f, desc->vpadding_transition, nV, &h.vpadding_transition);
   rc = rc || upload(f, desc->vgerm_trans_prod, nV, &h.vgerm_trans_prod);
   rc = rc || upload(f, desc->jpadding_transition, nJ, &h.jpadding_transition);
-  rc = rc || upload_junction(f, desc->vd, desc->n_xmsa, &h.vd);
+  std::vector<int32_t> remap(desc->n_xmsa, 0);  // first "used" flags, then compact positions
+  rc = rc || collect_junction_cols(desc->vd, desc->n_xmsa, &remap);
+  if (h.has_d) rc = rc || collect_junction_cols(desc->dj, desc->n_xmsa, &remap);
+  if (!rc) {
+    std::vector<int32_t> jcols;
+    for (int c = 0; c < desc->n_xmsa; ++c) {
+      if (remap[c]) {
+        remap[c] = (int32_t)jcols.size();
+        jcols.push_back(c);
+      } else {
+        remap[c] = -1;
+      }
+    }
+    h.n_jcols = (int32_t)jcols.size();
+    rc = upload(f, jcols.data(), jcols.size(), &h.jcols);
+  }
+  rc = rc || upload_junction(f, desc->vd, remap, &h.vd);
   if (!rc && desc->vd.n_left != (int)nV) rc = fail("lh_family_create: vd.n_left != number of V genes");
   if (h.has_d) {
     rc = rc || upload_segments(f, desc->dgerm, desc->n_xmsa, &h.dgerm);
-    rc = rc || upload_junction(f, desc->dj, desc->n_xmsa, &h.dj);
+    rc = rc || upload_junction(f, desc->dj, remap, &h.dj);
     if (!rc && (desc->vd.n_right != desc->dgerm.n_genes || desc->dj.n_left != desc->dgerm.n_genes ||
                 desc->dj.n_right != (int)nJ))
       rc = fail("lh_family_create: junction gene counts do not match the germline regions");
@@ -279,8 +339,11 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
       h.forward_size += h.dgerm.n_genes + (int64_t)h.dj.n_rows * (h.dj.n_left + 5 * (int64_t)h.dj.n_right);
       h.scaler_size += h.dj.n_rows + 1;
     }
-    if (lh::forward_lds_bytes(h) > 160 * 1024 || h.max_genes > 1024)
-      rc = fail("lh_family_create: family too large for the forward kernel's LDS working set");
+    h.gem_size = 2 * (int64_t)nV + h.dgerm.n_genes + 2 * (int64_t)nJ;
+    if (lh::forward_lds_bytes(h) > 160 * 1024)
+      rc = fail("lh_family_create: family too large for the forward kernels' LDS working set");
+    else if (nV > 1024 || h.dgerm.n_genes > 256 || nJ > 256)
+      rc = fail("lh_family_create: more than 1024 V genes or 256 D/J genes");
   }
   if (!rc) {
     void* p = nullptr;
@@ -306,7 +369,7 @@ void lh_family_destroy(lh_family* f) {
   if (!f) return;
   for (void* p : f->allocs) (void)hipFree(p);
   Workspace& w = f->ws;
-  void* bufs[] = {w.rates, w.eig, w.pmat, w.tipvec, w.site_lik, w.site_scal};
+  void* bufs[] = {w.rates, w.eig, w.pmat, w.tipvec, w.site_lik, w.site_scal, f->fws.gem, f->fws.jem, f->fws.gcnt};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* p : f->st.ptr)

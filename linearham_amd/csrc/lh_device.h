@@ -25,7 +25,7 @@ struct DevSegments {
 struct DevJunction {
   int32_t n_rows, n_left, n_right;
   const double *enter_trans, *enter_lo, *left_trans, *left_lo;
-  const int32_t* left_xmsa;
+  const int32_t* left_xmsa;  // the three *_xmsa tables hold indices into DevFamily::jcols (compact), or -1
   const double *right_gp_nli, *right_ntt, *right_nlo, *right_trans, *right_gp_li;
   const int32_t *right_xmsa, *nti_xmsa;
   const double *exit_nlo, *exit_trans, *exit_gp_li;
@@ -39,7 +39,10 @@ struct DevFamily {
   DevSegments vpadding, vgerm, dgerm, jgerm, jpadding;
   const double *vgerm_gene_prob, *vpadding_transition, *vgerm_trans_prod, *jpadding_transition;
   DevJunction vd, dj;
-  int32_t max_genes;      // max over regions of the gene count (LDS sizing)
+  int32_t max_genes;      // max over regions of the gene count
+  int32_t n_jcols;        // distinct xMSA columns referenced by the junction tables
+  const int32_t* jcols;   // [n_jcols] their xMSA indices, ascending
+  int64_t gem_size;       // doubles per sample of germline/padding emission products (2nV + nD + 2nJ)
   int64_t forward_size;   // doubles per sample in the compact forward output
   int64_t scaler_size;    // ints per sample in the scaler-count output
 };
@@ -81,12 +84,14 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
                   const double* pmat, const double* tipvec, const double* pi, double* site_lik,
                   int32_t* site_scal, hipStream_t stream);
 
-// K2: one wave per sample.  site_lik != null: emissions are assembled from K1's output (rate mix, log,
-// naive correction, exp; optionally written to em_out[n][C]); site_lik == null: emissions are taken
-// from em_in[n][C].  Then germline/padding emission products + scaled forward sweep -> loglik[n].
+// K2a + K2b.  site_lik != null: emissions are assembled from K1's output (rate mix and naive
+// correction; optionally written to em_out[n][C]); site_lik == null: emissions are taken from
+// em_in[n][C].  K2a leaves the germline/padding emission products in gem[n][gem_size], their scaler
+// counts in gcnt[n][3] and the junction columns' emissions in jem[n][n_jcols]; K2b runs the scaled
+// forward sweep over them -> loglik[n] (+ optional forward rows and scaler counts).
 void launch_forward(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
-                    const double* pi, const double* em_in, double* em_out, double* loglik, double* forward_out,
-                    int32_t* scaler_out, hipStream_t stream);
+                    const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt, double* jem,
+                    double* loglik, double* forward_out, int32_t* scaler_out, hipStream_t stream);
 size_t forward_lds_bytes(const DevFamily& fam);
 
 }  // namespace lh
