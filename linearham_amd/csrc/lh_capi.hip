@@ -110,15 +110,23 @@ int upload_segments(lh_family* f, const lh_segments& s, int n_xmsa, lh::DevSegme
       if (s.xmsa_inds[j] < 0 || s.xmsa_inds[j] >= n_xmsa) return fail("segments: xMSA index out of range");
     int longest = 0;
     for (int g = 0; g < s.n_genes; ++g) longest = std::max(longest, s.offsets[g + 1] - s.offsets[g]);
-    d->n_rows = (longest + 7) / 8 * 8;
-    std::vector<int32_t> t((size_t)d->n_rows * s.n_genes, n_xmsa);  // sentinel = column C (em = 1)
+    d->n_chunks = (longest + 7) / 8;
+    if (n_xmsa > 0xfffe) return fail("segments: more than 65534 xMSA columns");
+    // [chunk][gene][8] 16-bit indices, sentinel = column C (em = 1)
+    std::vector<uint16_t> t((size_t)d->n_chunks * s.n_genes * 8, (uint16_t)n_xmsa);
     for (int g = 0; g < s.n_genes; ++g)
-      for (int j = s.offsets[g]; j < s.offsets[g + 1]; ++j)
-        t[(size_t)(j - s.offsets[g]) * s.n_genes + g] = s.xmsa_inds[j];
-    if (upload(f, t.data(), t.size(), &d->inds_t)) return 1;
+      for (int j = s.offsets[g]; j < s.offsets[g + 1]; ++j) {
+        const int k = j - s.offsets[g];
+        t[((size_t)(k / 8) * s.n_genes + g) * 8 + (k % 8)] = (uint16_t)s.xmsa_inds[j];
+      }
+    const uint16_t* dev = nullptr;
+    if (upload(f, t.data(), t.size(), &dev)) return 1;
+    d->inds_c = reinterpret_cast<const uint4*>(dev);
   } else {
-    d->n_rows = 0;
-    if (upload<int32_t>(f, nullptr, 0, &d->inds_t)) return 1;
+    d->n_chunks = 0;
+    const uint16_t* dev = nullptr;
+    if (upload<uint16_t>(f, nullptr, 0, &dev)) return 1;
+    d->inds_c = reinterpret_cast<const uint4*>(dev);
   }
   return 0;
 }
@@ -133,7 +141,8 @@ int check_idx(const int32_t* a, size_t n, int n_xmsa, bool allow_neg, const char
 // Validates a junction's emission-column indices and marks the columns it uses.
 int collect_junction_cols(const lh_junction& j, int n_xmsa, std::vector<int32_t>* used) {
   const size_t W = j.n_rows, nL = j.n_left, nR = j.n_right;
-  if (j.n_rows < 1 || j.n_left < 0 || j.n_right < 0) return fail("junction: bad dimensions");
+  if (j.n_rows < 1 || j.n_left < 1 || j.n_right < 1) return fail("junction: bad dimensions");
+  if (!j.left_xmsa || !j.right_xmsa || !j.nti_xmsa) return fail("lh_family_create: null array in junction descriptor");
   if (check_idx(j.left_xmsa, W * nL, n_xmsa, true, "left_xmsa")) return 1;
   if (check_idx(j.right_xmsa, W * nR, n_xmsa, true, "right_xmsa")) return 1;
   if (check_idx(j.nti_xmsa, W * nR * 4, n_xmsa, false, "nti_xmsa")) return 1;
@@ -147,34 +156,60 @@ int collect_junction_cols(const lh_junction& j, int n_xmsa, std::vector<int32_t>
   return 0;
 }
 
-// Uploads xMSA indices translated to positions in the compact junction-column list.
-int upload_remapped(lh_family* f, const int32_t* src, size_t n, const std::vector<int32_t>& remap,
-                    const int32_t** out) {
-  std::vector<int32_t> t(n);
-  for (size_t i = 0; i < n; ++i) t[i] = src[i] >= 0 ? remap[src[i]] : -1;
-  return upload(f, t.data(), n, out);
+// Copies a [rows][n][inner] table into [rows][n_pad][inner], filling the padding with `fill`.
+template <typename T>
+std::vector<T> pad_genes(const T* src, size_t rows, size_t n, size_t n_pad, size_t inner, T fill) {
+  std::vector<T> t(rows * n_pad * inner, fill);
+  for (size_t i = 0; i < rows; ++i)
+    for (size_t g = 0; g < n; ++g)
+      for (size_t u = 0; u < inner; ++u) t[(i * n_pad + g) * inner + u] = src[(i * n + g) * inner + u];
+  return t;
 }
 
-int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_t>& remap, lh::DevJunction* d) {
+template <typename T>
+int upload_vec(lh_family* f, const std::vector<T>& v, const T** out) {
+  return upload(f, v.data(), v.size(), out);
+}
+
+// `remap` translates xMSA column indices into positions of the compact junction-column list; -1 (the
+// state does not emit at this site) and padding become the zero sentinel at position n_jcols.
+int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_t>& remap, int n_jcols,
+                    lh::DevJunction* d) {
   const size_t W = j.n_rows, nL = j.n_left, nR = j.n_right;
+  const size_t pL = (nL + 63) / 64 * 64, pR = (nR + 63) / 64 * 64;
   d->n_rows = j.n_rows;
   d->n_left = j.n_left;
   d->n_right = j.n_right;
-  if (upload(f, j.enter_trans, nL, &d->enter_trans)) return 1;
-  if (upload(f, j.enter_lo, nL, &d->enter_lo)) return 1;
-  if (upload(f, j.left_trans, W * nL, &d->left_trans)) return 1;
-  if (upload(f, j.left_lo, W * nL, &d->left_lo)) return 1;
-  if (upload_remapped(f, j.left_xmsa, W * nL, remap, &d->left_xmsa)) return 1;
-  if (upload(f, j.right_gp_nli, nR * 4, &d->right_gp_nli)) return 1;
-  if (upload(f, j.right_ntt, nR * 16, &d->right_ntt)) return 1;
-  if (upload(f, j.right_nlo, W * nR * 4, &d->right_nlo)) return 1;
-  if (upload(f, j.right_trans, W * nR, &d->right_trans)) return 1;
-  if (upload(f, j.right_gp_li, W * nR, &d->right_gp_li)) return 1;
-  if (upload_remapped(f, j.right_xmsa, W * nR, remap, &d->right_xmsa)) return 1;
-  if (upload_remapped(f, j.nti_xmsa, W * nR * 4, remap, &d->nti_xmsa)) return 1;
-  if (upload(f, j.exit_nlo, nR * 4, &d->exit_nlo)) return 1;
-  if (upload(f, j.exit_trans, nR, &d->exit_trans)) return 1;
-  if (upload(f, j.exit_gp_li, nR, &d->exit_gp_li)) return 1;
+  d->left_pad = (int32_t)pL;
+  d->right_pad = (int32_t)pR;
+  if (!j.enter_trans || !j.enter_lo || !j.left_trans || !j.left_lo || !j.right_gp_nli || !j.right_ntt ||
+      !j.right_nlo || !j.right_trans || !j.right_gp_li || !j.exit_nlo || !j.exit_trans || !j.exit_gp_li)
+    return fail("lh_family_create: null array in junction descriptor");
+  auto cols = [&](const int32_t* src, size_t rows, size_t n, size_t n_pad, size_t inner) {
+    std::vector<int32_t> t = pad_genes<int32_t>(src, rows, n, n_pad, inner, -1);
+    for (int32_t& x : t) x = x >= 0 ? remap[x] : n_jcols;
+    return t;
+  };
+  std::vector<double> ltr = pad_genes<double>(j.left_trans, W, nL, pL, 1, 0.0);
+  for (size_t l = 0; l < nL; ++l) ltr[l] = j.enter_trans[l];  // row 0 is entered from the germline region
+  std::vector<double> ntt(pR * 16, 0.0);
+  for (size_t r = 0; r < nR; ++r)
+    for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < 4; ++b) ntt[r * 16 + b * 4 + a] = j.right_ntt[r * 16 + a * 4 + b];
+  if (upload_vec(f, pad_genes<double>(j.enter_lo, 1, nL, pL, 1, 0.0), &d->enter_lo)) return 1;
+  if (upload_vec(f, ltr, &d->left_trans)) return 1;
+  if (upload_vec(f, pad_genes<double>(j.left_lo, W, nL, pL, 1, 0.0), &d->left_lo)) return 1;
+  if (upload_vec(f, cols(j.left_xmsa, W, nL, pL, 1), &d->left_xmsa)) return 1;
+  if (upload_vec(f, pad_genes<double>(j.right_gp_nli, 1, nR, pR, 4, 0.0), &d->right_gp_nli)) return 1;
+  if (upload_vec(f, ntt, &d->right_ntt)) return 1;
+  if (upload_vec(f, pad_genes<double>(j.right_nlo, W, nR, pR, 4, 0.0), &d->right_nlo)) return 1;
+  if (upload_vec(f, pad_genes<double>(j.right_trans, W, nR, pR, 1, 0.0), &d->right_trans)) return 1;
+  if (upload_vec(f, pad_genes<double>(j.right_gp_li, W, nR, pR, 1, 0.0), &d->right_gp_li)) return 1;
+  if (upload_vec(f, cols(j.right_xmsa, W, nR, pR, 1), &d->right_xmsa)) return 1;
+  if (upload_vec(f, cols(j.nti_xmsa, W, nR, pR, 4), &d->nti_xmsa)) return 1;
+  if (upload_vec(f, pad_genes<double>(j.exit_nlo, 1, nR, pR, 4, 0.0), &d->exit_nlo)) return 1;
+  if (upload_vec(f, pad_genes<double>(j.exit_trans, 1, nR, pR, 1, 0.0), &d->exit_trans)) return 1;
+  if (upload_vec(f, pad_genes<double>(j.exit_gp_li, 1, nR, pR, 1, 0.0), &d->exit_gp_li)) return 1;
   return 0;
 }
 
@@ -283,9 +318,28 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
       if (desc->xmsa_site[c] < 0 || desc->xmsa_site[c] >= desc->n_sites || desc->xmsa_naive_base[c] > 4)
         rc = fail("lh_family_create: xMSA column descriptor out of range");
     rc = rc || upload(f, desc->msa, (size_t)desc->n_seqs * desc->n_sites, &h.msa);
-    rc = rc || upload(f, desc->xmsa_site, C, &h.xmsa_site);
-    rc = rc || upload(f, desc->xmsa_naive_base, C, &h.xmsa_naive_base);
+    if (!rc) {
+      // K2a walks the columns sorted by (naive base, site) so that neighbouring lanes read neighbouring
+      // entries of K1's site_lik[rate][base][site] planes.
+      std::vector<int32_t> order(C), site(C);
+      std::vector<uint8_t> base(C);
+      for (size_t c = 0; c < C; ++c) order[c] = (int32_t)c;
+      std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        if (desc->xmsa_naive_base[a] != desc->xmsa_naive_base[b])
+          return desc->xmsa_naive_base[a] < desc->xmsa_naive_base[b];
+        if (desc->xmsa_site[a] != desc->xmsa_site[b]) return desc->xmsa_site[a] < desc->xmsa_site[b];
+        return a < b;
+      });
+      for (size_t t = 0; t < C; ++t) {
+        site[t] = desc->xmsa_site[order[t]];
+        base[t] = desc->xmsa_naive_base[order[t]];
+      }
+      rc = rc || upload(f, order.data(), C, &h.xmsa_col);
+      rc = rc || upload(f, site.data(), C, &h.xmsa_site);
+      rc = rc || upload(f, base.data(), C, &h.xmsa_naive_base);
+    }
   } else {
+    rc = rc || upload<int32_t>(f, nullptr, 0, &h.xmsa_col);
     rc = rc || upload<uint8_t>(f, nullptr, 0, &h.msa);
     rc = rc || upload<int32_t>(f, nullptr, 0, &h.xmsa_site);
     rc = rc || upload<uint8_t>(f, nullptr, 0, &h.xmsa_naive_base);
@@ -317,11 +371,11 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
     h.n_jcols = (int32_t)jcols.size();
     rc = upload(f, jcols.data(), jcols.size(), &h.jcols);
   }
-  rc = rc || upload_junction(f, desc->vd, remap, &h.vd);
+  rc = rc || upload_junction(f, desc->vd, remap, h.n_jcols, &h.vd);
   if (!rc && desc->vd.n_left != (int)nV) rc = fail("lh_family_create: vd.n_left != number of V genes");
   if (h.has_d) {
     rc = rc || upload_segments(f, desc->dgerm, desc->n_xmsa, &h.dgerm);
-    rc = rc || upload_junction(f, desc->dj, remap, &h.dj);
+    rc = rc || upload_junction(f, desc->dj, remap, h.n_jcols, &h.dj);
     if (!rc && (desc->vd.n_right != desc->dgerm.n_genes || desc->dj.n_left != desc->dgerm.n_genes ||
                 desc->dj.n_right != (int)nJ))
       rc = fail("lh_family_create: junction gene counts do not match the germline regions");

@@ -17,23 +17,38 @@ enum : int { OP_CHERRY = 0, OP_TIP_ACC = 1, OP_POP_ACC = 2, OP_PUSH_FLAG = 16 };
 // Device copy of lh_segments / lh_junction / family constants (all pointers are device pointers).
 struct DevSegments {
   int32_t n_genes;
-  int32_t n_rows;            // longest segment, rounded up to a multiple of 8
-  const int32_t* inds_t;     // [n_rows][n_genes] transposed + padded with the sentinel column C
-                             // (em[C] = 1.0), so that lane g's j-th factor is a coalesced load
+  int32_t n_chunks;      // ceil(longest segment / 8)
+  const uint4* inds_c;   // [n_chunks][n_genes] eight 16-bit xMSA column indices per entry (lane g's next
+                         // eight factors in one coalesced 16-byte load), padded with the sentinel
+                         // column C whose emission is 1.0
 };
 
+// Junction tables as K2b reads them: gene dimensions padded to a multiple of 64 with entries that
+// contribute nothing (zero transitions, emission index = the zero sentinel), so that every lane of a
+// wave loads and computes unconditionally.  Emission indices point into the compact junction-column
+// vector (DevFamily::jcols); position n_jcols is the sentinel holding 0.0.
 struct DevJunction {
   int32_t n_rows, n_left, n_right;
-  const double *enter_trans, *enter_lo, *left_trans, *left_lo;
-  const int32_t* left_xmsa;  // the three *_xmsa tables hold indices into DevFamily::jcols (compact), or -1
-  const double *right_gp_nli, *right_ntt, *right_nlo, *right_trans, *right_gp_li;
-  const int32_t *right_xmsa, *nti_xmsa;
-  const double *exit_nlo, *exit_trans, *exit_gp_li;
+  int32_t left_pad, right_pad;  // padded gene counts (row strides)
+  const double *enter_lo;       // [left_pad]
+  const double *left_trans;     // [n_rows][left_pad], row 0 = enter_trans
+  const double *left_lo;        // [n_rows][left_pad]
+  const int32_t* left_xmsa;     // [n_rows][left_pad]
+  const double *right_gp_nli;   // [right_pad][4]
+  const double *right_ntt;      // [right_pad][4][4] stored transposed: [r][b][a] = transition a -> b
+  const double *right_nlo;      // [n_rows][right_pad][4]
+  const double *right_trans, *right_gp_li;  // [n_rows][right_pad]
+  const int32_t *right_xmsa;    // [n_rows][right_pad]
+  const int32_t *nti_xmsa;      // [n_rows][right_pad][4]
+  const double *exit_nlo;       // [right_pad][4]
+  const double *exit_trans, *exit_gp_li;  // [right_pad]
 };
 
 struct DevFamily {
   int32_t has_d, n_seqs, n_sites, n_xmsa;
   const uint8_t* msa;
+  // xMSA columns in (naive base, site) order: position t describes column xmsa_col[t]
+  const int32_t* xmsa_col;
   const int32_t* xmsa_site;
   const uint8_t* xmsa_naive_base;
   DevSegments vpadding, vgerm, dgerm, jgerm, jpadding;
