@@ -38,89 +38,39 @@ constexpr int kFwdThreads = 256;
 constexpr int kFwdWaves = kFwdThreads / 64;
 constexpr int kJunctionWaves = 4;  // samples per K2b workgroup
 
-// Block-wide maximum of kS counters at once: shuffles inside the wave, one LDS exchange, one barrier
-// (red holds 2 * kFwdWaves * kS ints; `phase` alternates its halves so that a reduction never
-// overwrites values another wave is still reading).
-template <int kS>
-__device__ static inline void block_max_ints(int (&v)[kS], int* red, int phase) {
+// Block-wide maximum: shuffles inside the wave, one LDS exchange, one barrier (red holds
+// 2 * kFwdWaves ints; `phase` alternates its halves so that a reduction never overwrites values
+// another wave is still reading).
+__device__ static inline int block_max_int(int v, int* red, int phase) {
 #pragma unroll
-  for (int i = 0; i < kS; ++i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[i] = max(v[i], __shfl_xor(v[i], off, 64));
-  }
-  int* r = red + phase * kFwdWaves * kS;
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int i = 0; i < kS; ++i) r[(threadIdx.x >> 6) * kS + i] = v[i];
-  }
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  int* r = red + phase * kFwdWaves;
+  if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = v;
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < kS; ++i) v[i] = max(max(r[i], r[kS + i]), max(r[2 * kS + i], r[3 * kS + i]));
+  return max(max(r[0], r[1]), max(r[2], r[3]));
 }
-
-// ScaleMatrix (src/utils.cpp:135-144) on a vector spread over lanes: the loop
-// "while any 0 < m < 2^-256: m *= 2^256" runs exactly as often as it takes the smallest positive
-// entry to reach the threshold (multiplication by 2^256 is exact).
-__device__ static inline int scale_count(double minpos) {
-  int k = 0;
-  while (minpos < kScaleThreshold) {  // minpos = +inf when there is no positive entry
-    minpos *= kScaleFactor;
-    ++k;
-  }
-  return k;
-}
-
-__device__ static inline double posmin(double a, double v) { return (v > 0.0) ? fmin(a, v) : a; }
 
 __device__ static inline double pow_scale(int d) {  // std::pow(SCALE_FACTOR, d), src/PhyloHMM.cpp:191
   return d <= 0 ? 1.0 : d == 1 ? 0x1p256 : d == 2 ? 0x1p512 : d == 3 ? 0x1p768 : __builtin_inf();
-}
-
-__device__ static inline double scale_by(double v, int k) {  // v * (2^256)^k, exactly as k multiplications
-  for (int t = 0; t < k; ++t) v *= kScaleFactor;
-  return v;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // K2a
 // ---------------------------------------------------------------------------------------------------
 
-// The emission vectors of the kS samples a workgroup handles are interleaved in LDS: em[c * kS + i].
-template <int kS>
-__device__ static inline void load_em(const double* em, int idx, double (&e)[kS]) {
-  if constexpr (kS == 4) {
-    const double2* p = reinterpret_cast<const double2*>(em + (size_t)idx * 4);
-    const double2 a = p[0], b = p[1];
-    e[0] = a.x;
-    e[1] = a.y;
-    e[2] = b.x;
-    e[3] = b.y;
-  } else if constexpr (kS == 2) {
-    const double2 a = *reinterpret_cast<const double2*>(em + (size_t)idx * 2);
-    e[0] = a.x;
-    e[1] = a.y;
-  } else {
-    e[0] = em[idx];
-  }
-}
-
 // FillGermlinePaddingEmission (src/PhyloHMM.cpp:158-193): per gene the running product of its
 // columns' emissions with ScaleMatrix after every factor, then the 2^(256*d) equalisation to the
-// region's largest scaler count (added to cnt[i]).  Thread `tid` owns genes tid + 256*q; the products of
-// sample i go to out[i][gene].  The index stream (one 16-byte load = eight factors of one gene) is
-// shared by the kS samples: it is the dominant L2 traffic of this kernel.
-template <int kG, int kS>
-__device__ static void fill_segments(const DevSegments& seg, const double* em, int tid, double* const (&out)[kS],
-                                     int* redi, int phase, int (&cnt)[kS]) {
-  double v[kG][kS];
-  int c[kG][kS];
+// region's largest scaler count (returned).  Thread `tid` owns genes tid + 256*q; the products go to
+// out[gene].  One 16-byte load brings a gene's next eight column indices.
+template <int kG>
+__device__ static int fill_segments(const DevSegments& seg, const double* em, int tid, double* __restrict__ out,
+                                    int* redi, int phase) {
+  double v[kG];
+  int c[kG];
 #pragma unroll
   for (int q = 0; q < kG; ++q) {
-#pragma unroll
-    for (int i = 0; i < kS; ++i) {
-      v[q][i] = 1.0;
-      c[q][i] = 0;
-    }
+    v[q] = 1.0;
+    c[q] = 0;
   }
   const int n = seg.n_genes;
   if (n > 0) {
@@ -134,160 +84,122 @@ __device__ static void fill_segments(const DevSegments& seg, const double* em, i
       for (int j = 0; j < seg.n_chunks; ++j) {
         const uint4 w = chunk[(size_t)j * n];
         const unsigned packed[4] = {w.x, w.y, w.z, w.w};
-        double e[8][kS];
+        double e[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) load_em<kS>(em, (packed[u >> 1] >> (16 * (u & 1))) & 0xffffu, e[u]);
+        for (int u = 0; u < 8; ++u) e[u] = em[(packed[u >> 1] >> (16 * (u & 1))) & 0xffffu];
+        // The eight factors are applied without looking at the threshold, tracking the smallest prefix
+        // product m.  ScaleMatrix multiplies by 2^256 (exact) until the value is back above 2^-256, so
+        // after the chunk the reference holds p * 2^(256 k) with k = the number of rescalings the
+        // smallest prefix needs -- provided no unscaled prefix came near the subnormal range, which m
+        // also tells.
+        const double v0 = v[q];
+        double p = v0, m = v0;
 #pragma unroll
-        for (int i = 0; i < kS; ++i) {
-          // The eight factors are applied without looking at the threshold, tracking the smallest
-          // prefix product m.  ScaleMatrix multiplies by 2^256 (exact) until the value is back above
-          // 2^-256, so after the chunk the reference holds p * 2^(256 k) with k = the number of
-          // rescalings the smallest prefix needs -- provided no unscaled prefix came near the
-          // subnormal range, which m also tells.
-          const double v0 = v[q][i];
-          double p = v0, m = v0;
+        for (int u = 0; u < 8; ++u) {  // padded factors are exactly 1.0: no effect on (v, c)
+          p *= e[u];
+          m = fmin(m, p);
+        }
+        if (m >= 0x1p-768) {
+          const int k = (m < kScaleThreshold) + (m < 0x1p-512);
+          v[q] = p * (k == 0 ? 1.0 : k == 1 ? 0x1p256 : 0x1p512);
+          c[q] += k;
+        } else {  // a zero, or a drop of more than 2^-512 inside one chunk: step by step
+          double x = v0;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {  // padded factors are exactly 1.0: no effect on (v, c)
-            p *= e[u][i];
-            m = fmin(m, p);
-          }
-          if (m >= 0x1p-768) {
-            const int k = (m < kScaleThreshold) + (m < 0x1p-512);
-            v[q][i] = p * (k == 0 ? 1.0 : k == 1 ? 0x1p256 : 0x1p512);
-            c[q][i] += k;
-          } else {  // a zero, or a drop of more than 2^-512 inside one chunk: step by step
-            double x = v0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              x *= e[u][i];
-              while (x > 0.0 && x < kScaleThreshold) {
-                x *= kScaleFactor;
-                ++c[q][i];
-              }
+          for (int u = 0; u < 8; ++u) {
+            x *= e[u];
+            while (x > 0.0 && x < kScaleThreshold) {
+              x *= kScaleFactor;
+              ++c[q];
             }
-            v[q][i] = x;
           }
+          v[q] = x;
         }
       }
     }
   }
-  int mx[kS];
+  int local_max = 0;
 #pragma unroll
-  for (int i = 0; i < kS; ++i) {
-    mx[i] = 0;
+  for (int q = 0; q < kG; ++q)
+    if (tid + kFwdThreads * q < n) local_max = max(local_max, c[q]);
+  const int mx = block_max_int(local_max, redi, phase);
 #pragma unroll
-    for (int q = 0; q < kG; ++q)
-      if (tid + kFwdThreads * q < n) mx[i] = max(mx[i], c[q][i]);
+  for (int q = 0; q < kG; ++q) {
+    const int g = tid + kFwdThreads * q;
+    if (g < n) out[g] = v[q] * pow_scale(mx - c[q]);
   }
-  block_max_ints<kS>(mx, redi, phase);
-#pragma unroll
-  for (int i = 0; i < kS; ++i) {
-#pragma unroll
-    for (int q = 0; q < kG; ++q) {
-      const int g = tid + kFwdThreads * q;
-      if (g < n) out[i][g] = v[q][i] * pow_scale(mx[i] - c[q][i]);
-    }
-    cnt[i] += mx[i];
-  }
+  return mx;
 }
 
-// kS consecutive samples per workgroup (the last workgroup repeats sample n-1 and rewrites identical
-// values).
-template <int kG, int kS, bool kFromSiteLik>
+template <int kG, bool kFromSiteLik>
 __global__ void __launch_bounds__(kFwdThreads)
-    emission_kernel(const DevFamily fam, int n, int R, const double* __restrict__ site_lik,
+    emission_kernel(const DevFamily fam, int R, const double* __restrict__ site_lik,
                     const int32_t* __restrict__ site_scal, const double* __restrict__ pi,
                     const double* __restrict__ em_in, double* __restrict__ em_out, double* __restrict__ gem_all,
                     int32_t* __restrict__ gcnt_all, double* __restrict__ jem_all) {
-  extern __shared__ double em[];  // [(C + 1) * kS] interleaved emissions (column C = 1.0) | reduction scratch
+  extern __shared__ double em[];  // [C + 1] emissions (em[C] = 1.0 sentinel) | reduction scratch
+  const size_t s = blockIdx.x;
   const int tid = threadIdx.x;
   const int C = fam.n_xmsa;
-  int* redi = reinterpret_cast<int*>(em + (size_t)(C + 1) * kS);  // 2 * kFwdWaves * kS ints
-  size_t smp[kS];
-#pragma unroll
-  for (int i = 0; i < kS; ++i) smp[i] = (size_t)min(blockIdx.x * kS + i, n - 1);
+  int* redi = reinterpret_cast<int*>(em + ((C + 2) & ~1));  // 2 * kFwdWaves ints
 
   if constexpr (kFromSiteLik) {
     // PhyloHMM::FillXmsaEmission tail: mix the rate categories (equal weights, scalers aligned to the
-    // smallest one) and apply the naive correction.
+    // smallest one) and apply the naive correction.  Columns are visited in (naive base, site) order.
     const int L = fam.n_sites;
     const double w = 1.0 / R;
     for (int t = tid; t < C; t += kFwdThreads) {
       const int c = fam.xmsa_col[t];
       const int site = fam.xmsa_site[t];
       const int b = fam.xmsa_naive_base[t];
-#pragma unroll
-      for (int i = 0; i < kS; ++i) {
-        const size_t s = smp[i];
-        int smin = 0x7fffffff;
-        for (int r = 0; r < R; ++r) smin = min(smin, site_scal[(s * R + r) * L + site]);
-        double acc = 0.0;
-        for (int r = 0; r < R; ++r) {
-          double v = site_lik[((s * R + r) * 5 + b) * (size_t)L + site];
-          const int d = site_scal[(s * R + r) * L + site] - smin;
-          for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
-          acc += w * v;
-        }
-        // The reference forms exp(log(site_lik) - smin*log(2^256) - log(pi_b)) (src/PhyloHMM.cpp:226-237);
-        // the same quantity is computed here without the log/exp round trip (two FP64 transcendentals
-        // per column): site_lik / pi_b scaled down by 2^(256*smin), which also underflows to 0 like exp().
-        double e = acc;
-        if (b != 4) e /= pi[s * 4 + b];
-        for (int q = 0; q < smin && e != 0.0; ++q) e *= kScaleThreshold;
-        em[(size_t)c * kS + i] = e;
-        if (em_out) em_out[s * C + c] = e;
+      int smin = 0x7fffffff;
+      for (int r = 0; r < R; ++r) smin = min(smin, site_scal[(s * R + r) * L + site]);
+      double acc = 0.0;
+      for (int r = 0; r < R; ++r) {
+        double v = site_lik[((s * R + r) * 5 + b) * (size_t)L + site];
+        const int d = site_scal[(s * R + r) * L + site] - smin;
+        for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
+        acc += w * v;
       }
+      // The reference forms exp(log(site_lik) - smin*log(2^256) - log(pi_b)) (src/PhyloHMM.cpp:226-237);
+      // the same quantity is computed here without the log/exp round trip (two FP64 transcendentals
+      // per column): site_lik / pi_b scaled down by 2^(256*smin), which also underflows to 0 like exp().
+      double e = acc;
+      if (b != 4) e /= pi[s * 4 + b];
+      for (int q = 0; q < smin && e != 0.0; ++q) e *= kScaleThreshold;
+      em[c] = e;
+      if (em_out) em_out[s * C + c] = e;
     }
   } else {
-#pragma unroll
-    for (int i = 0; i < kS; ++i)
-      for (int c = tid; c < C; c += kFwdThreads) em[(size_t)c * kS + i] = em_in[smp[i] * C + c];
+    for (int c = tid; c < C; c += kFwdThreads) em[c] = em_in[s * C + c];
   }
-  if (tid < kS) em[(size_t)C * kS + tid] = 1.0;
+  if (tid == 0) em[C] = 1.0;
   __syncthreads();
 
   // emissions of the columns the junction rows touch, compacted for K2b
-  for (int j = tid; j < fam.n_jcols; j += kFwdThreads) {
-    const int c = fam.jcols[j];
-#pragma unroll
-    for (int i = 0; i < kS; ++i) jem_all[smp[i] * fam.n_jcols + j] = em[(size_t)c * kS + i];
+  {
+    double* jem = jem_all + s * fam.n_jcols;
+    for (int j = tid; j < fam.n_jcols; j += kFwdThreads) jem[j] = em[fam.jcols[j]];
   }
 
   // [vpadding nV | vgerm nV | dgerm nD | jgerm nJ | jpadding nJ]
   const int nV = fam.vgerm.n_genes, nD = fam.dgerm.n_genes, nJ = fam.jgerm.n_genes;
-  double* o[kS];
-  int cv[kS], cd[kS], cj[kS];
-#pragma unroll
-  for (int i = 0; i < kS; ++i) {
-    o[i] = gem_all + smp[i] * fam.gem_size;
-    cv[i] = cd[i] = cj[i] = 0;
-  }
-  auto advance = [&](int by) {
-#pragma unroll
-    for (int i = 0; i < kS; ++i) o[i] += by;
-  };
-  fill_segments<kG, kS>(fam.vpadding, em, tid, o, redi, 0, cv);
-  advance(nV);
-  fill_segments<kG, kS>(fam.vgerm, em, tid, o, redi, 1, cv);
-  advance(nV);
+  double* gem = gem_all + s * fam.gem_size;
+  int cv = fill_segments<kG>(fam.vpadding, em, tid, gem, redi, 0);
+  cv += fill_segments<kG>(fam.vgerm, em, tid, gem + nV, redi, 1);
+  int cd = 0, cj;
   if (fam.has_d) {
-    fill_segments<kG, kS>(fam.dgerm, em, tid, o, redi, 0, cd);
-    advance(nD);
-    fill_segments<kG, kS>(fam.jgerm, em, tid, o, redi, 1, cj);
-    advance(nJ);
-    fill_segments<kG, kS>(fam.jpadding, em, tid, o, redi, 0, cj);
+    cd = fill_segments<kG>(fam.dgerm, em, tid, gem + 2 * (size_t)nV, redi, 0);
+    cj = fill_segments<kG>(fam.jgerm, em, tid, gem + 2 * (size_t)nV + nD, redi, 1);
+    cj += fill_segments<kG>(fam.jpadding, em, tid, gem + 2 * (size_t)nV + nD + nJ, redi, 0);
   } else {
-    fill_segments<kG, kS>(fam.jgerm, em, tid, o, redi, 0, cj);
-    advance(nJ);
-    fill_segments<kG, kS>(fam.jpadding, em, tid, o, redi, 1, cj);
+    cj = fill_segments<kG>(fam.jgerm, em, tid, gem + 2 * (size_t)nV, redi, 0);
+    cj += fill_segments<kG>(fam.jpadding, em, tid, gem + 2 * (size_t)nV + nJ, redi, 1);
   }
   if (tid == 0) {
-#pragma unroll
-    for (int i = 0; i < kS; ++i) {
-      gcnt_all[smp[i] * 3 + 0] = cv[i];
-      gcnt_all[smp[i] * 3 + 1] = cd[i];
-      gcnt_all[smp[i] * 3 + 2] = cj[i];
-    }
+    gcnt_all[s * 3 + 0] = cv;
+    gcnt_all[s * 3 + 1] = cd;
+    gcnt_all[s * 3 + 2] = cj;
   }
 }
 
@@ -295,32 +207,61 @@ __global__ void __launch_bounds__(kFwdThreads)
 // K2b
 // ---------------------------------------------------------------------------------------------------
 
-// Wave-wide (sum, smallest positive) by butterfly: every lane ends with both results.
-__device__ static inline void wave_sum_min(double& sum, double& mn) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    sum += __shfl_xor(sum, off, 64);
-    mn = fmin(mn, __shfl_xor(mn, off, 64));
-  }
+// Wave-wide reductions without LDS traffic: four DPP steps fold each row of 16 lanes (quad swaps, then
+// the two mirror patterns), four v_readlane pick the row totals.  A __shfl_xor butterfly costs six
+// dependent ds_bpermute round trips per value, which was the longest single item of a junction row.
+template <int kCtrl>
+__device__ static inline double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
 }
 
-__device__ static inline double wave_sum(double sum) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-  return sum;
+__device__ static inline double read_lane(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
-__device__ static inline double wave_min(double mn) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off, 64));
-  return mn;
+constexpr int kDppQuadSwap1 = 0xB1;    // quad_perm [1,0,3,2]
+constexpr int kDppQuadSwap2 = 0x4E;    // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // lane i <-> 7 - i within each 8
+constexpr int kDppMirror = 0x140;      // lane i <-> 15 - i within each 16
+
+__device__ static inline double wave_sum(double v) {
+  v += dpp_move<kDppQuadSwap1>(v);
+  v += dpp_move<kDppQuadSwap2>(v);
+  v += dpp_move<kDppHalfMirror>(v);
+  v += dpp_move<kDppMirror>(v);
+  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
 }
 
-// ScaleMatrix on a wave-uniform basis.  `minpos` (identical in all lanes, +inf if nothing is positive)
-// is the smallest positive entry of the vector; the reference multiplies the whole vector by 2^256
-// until that entry reaches 2^-256, i.e. k = #{j in 1..4 : minpos < 2^(-256 j)} times (a double is never
-// below 2^-1074, so k <= 4).  k is derived from the exponent field with scalar instructions, and the
-// k multiplications -- each exact -- collapse into one by 2^(256 min(k,3)) plus, for k = 4 only
+// ScaleMatrix needs, per vector, only the binade of its smallest positive entry.  Every entry is >= 0,
+// so the high word of a double orders like the value; key(v) = high word - 1 sends zeros to the far
+// end, and the smallest key over the wave identifies that binade with 32-bit integer minima (one VALU
+// op per step, DPP-fused) instead of 64-bit compare/select/min chains.  (A positive entry below
+// 2^-1042 has a zero high word and is skipped like a zero -- a value no forward sweep produces next to
+// normal-range neighbours without the reference overflowing itself.)
+__device__ static inline unsigned scale_key(double v) { return (unsigned)__double2hiint(v) - 1u; }
+
+template <int kCtrl>
+__device__ static inline unsigned dpp_min_u32(unsigned v) {
+  return min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, 0xf, 0xf, true));
+}
+
+__device__ static inline unsigned wave_min_key(unsigned v) {
+  v = dpp_min_u32<kDppQuadSwap1>(v);
+  v = dpp_min_u32<kDppQuadSwap2>(v);
+  v = dpp_min_u32<kDppHalfMirror>(v);
+  v = dpp_min_u32<kDppMirror>(v);
+  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+  return min(min(a, b), min(c, d));
+}
+
+// ScaleMatrix on a wave-uniform basis: the reference multiplies the whole vector by 2^256 until its
+// smallest positive entry reaches 2^-256, i.e. k = #{j in 1..4 : minpos < 2^(-256 j)} times (a double
+// is never below 2^-1074, so k <= 4).  k follows from the exponent field with scalar instructions, and
+// the k multiplications -- each exact -- collapse into one by 2^(256 min(k,3)) plus, for k = 4 only
 // (subnormal minpos), one more by 2^256.
 struct RowScale {
   int k;
@@ -333,29 +274,61 @@ struct RowScale {
   }
 };
 
-__device__ static inline RowScale row_scale(double minpos) {
-  const unsigned hw = __builtin_amdgcn_readfirstlane(__double2hiint(minpos));
+__device__ static inline RowScale row_scale(unsigned min_key) {  // min_key: wave-uniform
+  const unsigned hw = min_key + 1u;  // high word of the smallest positive entry; 0 = there is none
   const unsigned e = (hw >> 20) & 0x7ffu;
   RowScale s;
-  s.extra = (e == 0) && ((hw & 0xfffffu) < (1u << 18));  // minpos < 2^-1024
-  const int k3 = (e < 767u) + (e < 511u) + (e < 255u);
+  s.extra = hw != 0 && e == 0 && (hw & 0xfffffu) < (1u << 18);  // minpos < 2^-1024
+  const int k3 = hw == 0 ? 0 : (e < 767u) + (e < 511u) + (e < 255u);
   s.k = k3 + (s.extra ? 1 : 0);
   s.factor = __hiloint2double((1023 + 256 * k3) << 20, 0);
   return s;
 }
 
-// One junction region + the germline region to its right; all state in registers of one wave.
-//   f_in[q]   forward of the left germline region (genes lane + 64q; zero beyond the last gene)
-//   g_out[q]  forward of the right germline region (likewise)
-//   germ_em   emission products of the right germline region (per sample, global),
-//   pad_trans / pad_em   padding transition (family) and padding emission products (sample); null = ones
-// Returns count_in plus every ScaleMatrix count taken inside (junction rows and the hand-off).
-//
-// Row i is first computed "raw" (without its own ScaleMatrix factor); one combined reduction then
-// yields k_i (from the smallest positive raw entry) and the raw rank-one sum for row i+1.  Every
-// later use multiplies by 2^(256*k_i), which is exact, so all values equal the reference's.
-// The tables are padded to whole waves with entries that produce zeros (see DevJunction), so the row
-// body has no per-lane predicates.
+// One junction row's table entries for the genes a lane owns (family constants, independent of the
+// sample and of the HMM state -- so the next row's are fetched while this row computes).
+template <int GL, int GR>
+struct RowTables {
+  double ltr[GL], llo[GL];
+  int lidx[GL];
+  double nlo[GR][4], rtr[GR], rli[GR];
+  int ridx[GR];
+  int4 nx[GR];
+};
+
+template <int GL, int GR>
+__device__ static inline void load_row(const DevJunction& J, int i, unsigned lane, RowTables<GL, GR>& t) {
+  // wave-uniform row bases + a lane offset that fits the instruction's immediate: no vector address math
+  const size_t ol = (size_t)i * J.left_pad, orr = (size_t)i * J.right_pad;
+  const double* lt = J.left_trans + ol;
+  const double* ll = J.left_lo + ol;
+  const int32_t* lx = J.left_xmsa + ol;
+#pragma unroll
+  for (int q = 0; q < GL; ++q) {
+    t.ltr[q] = lt[lane + 64u * q];
+    t.llo[q] = ll[lane + 64u * q];
+    t.lidx[q] = lx[lane + 64u * q];
+  }
+  const double2* pn = reinterpret_cast<const double2*>(J.right_nlo) + 2 * orr;
+  const int4* px = reinterpret_cast<const int4*>(J.nti_xmsa) + orr;
+  const double* rt = J.right_trans + orr;
+  const double* rl = J.right_gp_li + orr;
+  const int32_t* rx = J.right_xmsa + orr;
+#pragma unroll
+  for (int q = 0; q < GR; ++q) {
+    const unsigned r = lane + 64u * q;
+    const double2 a = pn[2u * r], b = pn[2u * r + 1u];
+    t.nlo[q][0] = a.x;
+    t.nlo[q][1] = a.y;
+    t.nlo[q][2] = b.x;
+    t.nlo[q][3] = b.y;
+    t.nx[q] = px[r];
+    t.rtr[q] = rt[r];
+    t.rli[q] = rl[r];
+    t.ridx[q] = rx[r];
+  }
+}
+
 template <int GL, int GR>
 __device__ static int junction_wave(const DevJunction& J, const double* jem, const double* ntt_lds, int lane,
                                     const double (&f_in)[GL], int count_in, const double* __restrict__ germ_em,
@@ -363,9 +336,8 @@ __device__ static int junction_wave(const DevJunction& J, const double* jem, con
                                     double (&g_out)[GR], double* __restrict__ fwd_out,
                                     int32_t* __restrict__ scal_out) {
   const int W = J.n_rows, nL = J.n_left, nR = J.n_right;
-  const unsigned pL = J.left_pad, pR = J.right_pad;
   int count = count_in;
-  double fL[GL], fN[GR][4], fR[GR];  // raw values of the previous row
+  double fL[GL], fN[GR][4], fR[GR];  // the previous row, ScaleMatrix already applied
   double nli[GR][4];                 // row-invariant NTI landing table of the right genes this lane owns
 #pragma unroll
   for (int q = 0; q < GL; ++q) fL[q] = f_in[q];
@@ -389,53 +361,25 @@ __device__ static int junction_wave(const DevJunction& J, const double* jem, con
     for (int q = 0; q < GL; ++q) part += f_in[q] * J.enter_lo[lane + 64u * q];
     A = wave_sum(part);
   }
-  RowScale prev{0, 1.0, false};  // ScaleMatrix factor of the previous row, not yet applied to fL/fN/fR
-  for (int i = 0; i < W; ++i) {
-    // this row's table entries for the genes the lane owns (family constants)
-    double ltr[GL], llo[GL];
-    int lidx[GL];
+
+  // Row i: compute every live state from row i-1, one reduction for (rank-one sum, smallest binade),
+  // then -- only on the rows where ScaleMatrix fires -- rescale the row in place.
+  auto step = [&](int i, const RowTables<GL, GR>& t) __attribute__((always_inline)) {
+    unsigned key = 0xffffffffu;
+    double part = 0.0;
 #pragma unroll
     for (int q = 0; q < GL; ++q) {
-      const unsigned o = (unsigned)i * pL + lane + 64u * q;
-      ltr[q] = J.left_trans[o];
-      llo[q] = J.left_lo[o];
-      lidx[q] = J.left_xmsa[o];
-    }
-    double nlo[GR][4], rtr[GR], rli[GR];
-    int ridx[GR];
-    int4 nx[GR];
-#pragma unroll
-    for (int q = 0; q < GR; ++q) {
-      const unsigned o = (unsigned)i * pR + lane + 64u * q;
-      const double2* pn = reinterpret_cast<const double2*>(J.right_nlo) + 2u * o;
-      const double2 a = pn[0], b = pn[1];
-      nlo[q][0] = a.x;
-      nlo[q][1] = a.y;
-      nlo[q][2] = b.x;
-      nlo[q][3] = b.y;
-      nx[q] = reinterpret_cast<const int4*>(J.nti_xmsa)[o];
-      rtr[q] = J.right_trans[o];
-      rli[q] = J.right_gp_li[o];
-      ridx[q] = J.right_xmsa[o];
-    }
-    double mp = __builtin_inf(), part = 0.0;
-#pragma unroll
-    for (int q = 0; q < GL; ++q) {
-      const double f = prev.apply(fL[q]);  // factor 1 on row 0: the germline forward itself
-      const double v = (f * ltr[q]) * jem[lidx[q]];
+      const double v = (fL[q] * t.ltr[q]) * jem[t.lidx[q]];
       fL[q] = v;
-      mp = posmin(mp, v);
-      part += v * llo[q];  // raw contribution to the next row's rank-one term
+      key = min(key, scale_key(v));
+      part += v * t.llo[q];  // contribution to the next row's rank-one term
     }
 #pragma unroll
     for (int q = 0; q < GR; ++q) {
-      // previous row (zeros at i == 0), with its scaling applied now
-      const double n0 = prev.apply(fN[q][0]), n1 = prev.apply(fN[q][1]);
-      const double n2 = prev.apply(fN[q][2]), n3 = prev.apply(fN[q][3]);
-      const double fr = prev.apply(fR[q]);
+      const double n0 = fN[q][0], n1 = fN[q][1], n2 = fN[q][2], n3 = fN[q][3];
       // NTI->NTI block of gene r, transposed in LDS: [b * 4 + a] = transition a -> b
       const double2* tt = reinterpret_cast<const double2*>(ntt_lds) + 8u * (lane + 64u * q);
-      const int nxs[4] = {nx[q].x, nx[q].y, nx[q].z, nx[q].w};
+      const int nxs[4] = {t.nx[q].x, t.nx[q].y, t.nx[q].z, t.nx[q].w};
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const double2 t01 = tt[2 * b], t23 = tt[2 * b + 1];
@@ -443,52 +387,82 @@ __device__ static int junction_wave(const DevJunction& J, const double* jem, con
         s += A * nli[q][b];
         const double v = s * jem[nxs[b]];
         fN[q][b] = v;
-        mp = posmin(mp, v);
+        key = min(key, scale_key(v));
       }
-      double s = ((n0 * nlo[q][0] + n1 * nlo[q][1]) + n2 * nlo[q][2]) + n3 * nlo[q][3];
-      s += fr * rtr[q];
-      s += A * rli[q];
-      const double v = s * jem[ridx[q]];
+      double s = ((n0 * t.nlo[q][0] + n1 * t.nlo[q][1]) + n2 * t.nlo[q][2]) + n3 * t.nlo[q][3];
+      s += fR[q] * t.rtr[q];
+      s += A * t.rli[q];
+      const double v = s * jem[t.ridx[q]];
       fR[q] = v;
-      mp = posmin(mp, v);
+      key = min(key, scale_key(v));
     }
-    wave_sum_min(part, mp);
-    const RowScale cur = row_scale(mp);
-    A = cur.apply(part);  // = sum_l (row i scaled)[l] * landing_out_l
-    count += cur.k;
-    prev = cur;
+    A = wave_sum(part);
+    const RowScale sc = row_scale(wave_min_key(key));
+    if (sc.k != 0) {  // wave-uniform, a few rows per junction
+      A = sc.apply(A);
+#pragma unroll
+      for (int q = 0; q < GL; ++q) fL[q] = sc.apply(fL[q]);
+#pragma unroll
+      for (int q = 0; q < GR; ++q) {
+        fR[q] = sc.apply(fR[q]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fN[q][b] = sc.apply(fN[q][b]);
+      }
+      count += sc.k;
+    }
     if (fwd_out) {
       double* o = fwd_out + (size_t)i * row_stride;
 #pragma unroll
       for (int q = 0; q < GL; ++q) {
-        const int t = lane + 64 * q;
-        if (t < nL) o[t] = cur.apply(fL[q]);
+        const int g = lane + 64 * q;
+        if (g < nL) o[g] = fL[q];
       }
 #pragma unroll
       for (int q = 0; q < GR; ++q) {
-        const int t = lane + 64 * q;
-        if (t < nR) {
-          o[nL + 4 * (size_t)t + 0] = cur.apply(fN[q][0]);
-          o[nL + 4 * (size_t)t + 1] = cur.apply(fN[q][1]);
-          o[nL + 4 * (size_t)t + 2] = cur.apply(fN[q][2]);
-          o[nL + 4 * (size_t)t + 3] = cur.apply(fN[q][3]);
-          o[nL + 4 * (size_t)nR + t] = cur.apply(fR[q]);
+        const int g = lane + 64 * q;
+        if (g < nR) {
+          o[nL + 4 * (size_t)g + 0] = fN[q][0];
+          o[nL + 4 * (size_t)g + 1] = fN[q][1];
+          o[nL + 4 * (size_t)g + 2] = fN[q][2];
+          o[nL + 4 * (size_t)g + 3] = fN[q][3];
+          o[nL + 4 * (size_t)nR + g] = fR[q];
         }
       }
     }
     if (scal_out && lane == 0) scal_out[i] = count;
+  };
+
+  // Two table sets in flight: while one row computes, the next row's entries are on their way.  The
+  // widest instantiations (rare allele counts) have no registers to spare for that and fetch in place.
+  constexpr bool kPrefetch = 5 * GL + 17 * GR <= 60;
+  if constexpr (kPrefetch) {
+    RowTables<GL, GR> ta, tb;
+    load_row<GL, GR>(J, 0, lane, ta);
+    for (int i = 0; i < W; i += 2) {
+      load_row<GL, GR>(J, min(i + 1, W - 1), lane, tb);
+      step(i, ta);
+      if (i + 1 < W) {
+        load_row<GL, GR>(J, min(i + 2, W - 1), lane, ta);
+        step(i + 1, tb);
+      }
+    }
+  } else {
+    for (int i = 0; i < W; ++i) {
+      RowTables<GL, GR> t;
+      load_row<GL, GR>(J, i, lane, t);
+      step(i, t);
+    }
   }
+
   // hand-off into the right germline region (A already holds the last row's rank-one sum)
-  double mp = __builtin_inf();
+  unsigned key = 0xffffffffu;
 #pragma unroll
   for (int q = 0; q < GR; ++q) {
     const unsigned r = lane + 64u * q;
     const double2* xn = reinterpret_cast<const double2*>(J.exit_nlo) + 2u * r;
     const double2 x01 = xn[0], x23 = xn[1];
-    const double n0 = prev.apply(fN[q][0]), n1 = prev.apply(fN[q][1]);
-    const double n2 = prev.apply(fN[q][2]), n3 = prev.apply(fN[q][3]);
-    double s = ((n0 * x01.x + n1 * x01.y) + n2 * x23.x) + n3 * x23.y;
-    s += prev.apply(fR[q]) * J.exit_trans[r];
+    double s = ((fN[q][0] * x01.x + fN[q][1] * x01.y) + fN[q][2] * x23.x) + fN[q][3] * x23.y;
+    s += fR[q] * J.exit_trans[r];
     s += A * J.exit_gp_li[r];
     double v = 0.0;
     if ((int)r < nR) {
@@ -496,10 +470,10 @@ __device__ static int junction_wave(const DevJunction& J, const double* jem, con
       if (pad_trans) v *= pad_trans[r];
       if (pad_em) v *= pad_em[r];
     }
-    mp = posmin(mp, v);
+    key = min(key, scale_key(v));
     g_out[q] = v;
   }
-  const RowScale last = row_scale(wave_min(mp));
+  const RowScale last = row_scale(wave_min_key(key));
 #pragma unroll
   for (int q = 0; q < GR; ++q) g_out[q] = last.apply(g_out[q]);
   return count + last.k;
@@ -541,7 +515,7 @@ __global__ void __launch_bounds__(64 * kJunctionWaves)
 
   // initial forward over the V germline region (src/HMM.cpp:291-319)
   double gV[GA];
-  double mp = __builtin_inf();
+  unsigned key = 0xffffffffu;
 #pragma unroll
   for (int q = 0; q < GA; ++q) {
     const int t = lane + 64 * q;
@@ -552,13 +526,13 @@ __global__ void __launch_bounds__(64 * kJunctionWaves)
       v *= gem[t];
       v *= fam.vgerm_trans_prod[t];
       v *= gem[nV + t];
-      mp = posmin(mp, v);
     }
+    key = min(key, scale_key(v));
     gV[q] = v;
   }
   int vcount = cv;
   {
-    const RowScale sc = row_scale(wave_min(mp));
+    const RowScale sc = row_scale(wave_min_key(key));
 #pragma unroll
     for (int q = 0; q < GA; ++q) gV[q] = sc.apply(gV[q]);
     vcount += sc.k;
@@ -628,59 +602,33 @@ static size_t junction_lds_bytes(const DevFamily& fam) {
          sizeof(double);
 }
 
-static size_t emission_lds_bytes(const DevFamily& fam, int ks) {
-  return ((size_t)fam.n_xmsa + 1) * ks * sizeof(double) + 2 * kFwdWaves * ks * sizeof(int);
-}
-
-// Samples per K2a workgroup: as many (4, 2, 1) as keep three workgroups resident per CU.
-static int emission_samples_per_group(const DevFamily& fam) {
-  constexpr size_t kBudget = 52 * 1024;
-  return emission_lds_bytes(fam, 4) <= kBudget ? 4 : emission_lds_bytes(fam, 2) <= kBudget ? 2 : 1;
+static size_t emission_lds_bytes(const DevFamily& fam) {
+  return (((size_t)fam.n_xmsa + 2) & ~(size_t)1) * sizeof(double) + 2 * kFwdWaves * sizeof(int);
 }
 
 size_t forward_lds_bytes(const DevFamily& fam) {
-  const size_t a = emission_lds_bytes(fam, emission_samples_per_group(fam));
-  const size_t b = junction_lds_bytes(fam);
+  const size_t a = emission_lds_bytes(fam), b = junction_lds_bytes(fam);
   return a > b ? a : b;
-}
-
-template <int kG, int kS>
-static void launch_emission_gs(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
-                               const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt,
-                               double* jem, hipStream_t stream) {
-  const size_t lds = emission_lds_bytes(fam, kS);
-  const dim3 grid((n + kS - 1) / kS);
-  if (site_lik) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emission_kernel<kG, kS, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((emission_kernel<kG, kS, true>), grid, dim3(kFwdThreads), lds, stream, fam, n, R, site_lik,
-                       site_scal, pi, em_in, em_out, gem, gcnt, jem);
-  } else {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emission_kernel<kG, kS, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((emission_kernel<kG, kS, false>), grid, dim3(kFwdThreads), lds, stream, fam, n, R, site_lik,
-                       site_scal, pi, em_in, em_out, gem, gcnt, jem);
-  }
 }
 
 template <int kG>
 static void launch_emission_g(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
                               const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt,
                               double* jem, hipStream_t stream) {
-  // more gene slots per lane leave fewer registers for samples (kG * kS chains are live at once)
-  int ks = std::min(emission_samples_per_group(fam), kG == 1 ? 4 : kG == 2 ? 2 : 1);
-  if (getenv("LH_K2A_KS")) ks = std::min(ks, atoi(getenv("LH_K2A_KS")));
-#define LH_ARGS fam, n, R, site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, stream
-  if constexpr (kG == 1) {
-    if (ks == 4) return launch_emission_gs<kG, 4>(LH_ARGS);
+  const size_t lds = emission_lds_bytes(fam);
+  if (site_lik) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emission_kernel<kG, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((emission_kernel<kG, true>), dim3(n), dim3(kFwdThreads), lds, stream, fam, R, site_lik,
+                       site_scal, pi, em_in, em_out, gem, gcnt, jem);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emission_kernel<kG, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((emission_kernel<kG, false>), dim3(n), dim3(kFwdThreads), lds, stream, fam, R, site_lik,
+                       site_scal, pi, em_in, em_out, gem, gcnt, jem);
   }
-  if constexpr (kG <= 2) {
-    if (ks >= 2) return launch_emission_gs<kG, 2>(LH_ARGS);
-  }
-  launch_emission_gs<kG, 1>(LH_ARGS);
-#undef LH_ARGS
 }
 
 template <int GA, int GB>

@@ -154,16 +154,19 @@ def test_batch_of_varied_models_on_toy_family(hip, data_dir):
     compare(h, desc, ll, res, ref)
 
 
-@pytest.mark.parametrize("preset", ["small", "medium", "igk", "igl"])
+@pytest.mark.parametrize("preset", ["small", "medium", "igk", "igl", "many_alleles", "many_alleles_igk"])
 def test_synthetic_family(hip, tmp_path, preset):
     """Multi-allele junctions, NNI-perturbed trees with [&index=..] annotations; the medium family
     (40 leaves) drives the 2^256 scaler counts above zero; igk/igl are light-chain families (no D
-    segment, one V-J junction: src/HMM.cpp:124-131,163-170,225-242,276-286)."""
+    segment, one V-J junction: src/HMM.cpp:124-131,163-170,225-242,276-286); the many-allele families
+    (300 V, 70 D or J) run the kernels' multi-slot instantiations (several genes per lane)."""
     from tools import synth_family as sf
     out = str(tmp_path / "fam")
     spec = {"small": sf.Spec.small(), "medium": sf.Spec.small(n_leaves=40, n_samples=3, seed=11),
             "igk": sf.Spec.small(locus="igk", n_samples=3, seed=5),
-            "igl": sf.Spec.small(locus="igl", n_leaves=30, n_samples=3, seed=6)}[preset]
+            "igl": sf.Spec.small(locus="igl", n_leaves=30, n_samples=3, seed=6),
+            "many_alleles": sf.Spec.small(n_v=300, n_d=70, n_j=5, n_samples=2, seed=21),
+            "many_alleles_igk": sf.Spec.small(locus="igk", n_v=150, n_j=70, n_samples=2, seed=22)}[preset]
     sf.generate(spec, out)
     h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
     rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
