@@ -25,6 +25,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 peak (MI355X_MICROARCH.md)
+DEFAULT_BATCH = 8192           # tree samples per GPU per step (= one launch group of the C ABI)
+PMC_PROFILE = "r01_v3_bench_pmc_per_launch.json"   # committed PMC passes of the default command
 
 
 def log(*a):
@@ -71,7 +74,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="tree samples per GPU per step")
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="tree samples per GPU per step")
     ap.add_argument("--preset", default="config2", choices=["config2", "config4", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="kernel timing experiments only")
@@ -169,12 +172,20 @@ def main():
         # HBM traffic of one K1 launch from the committed PMC passes of this same command (counters need
         # their own rocprofv3 runs; gfx950 correction: FETCH_SIZE counts wide coalesced reads at half).
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_v2_bench_pmc_per_launch.json")
-        if args.preset == "config2" and n == 4096 and os.path.exists(pmc_file):
+        pmc_file = os.path.join(ROOT, "profiles", PMC_PROFILE)
+        if args.preset == "config2" and n == DEFAULT_BATCH and os.path.exists(pmc_file):
             with open(pmc_file) as f:
-                k1 = json.load(f).get("lh::prune_kernel<4>", {})
+                pmc = json.load(f)
+            k1 = next((v for k, v in pmc.items() if "prune_kernel" in k), {})
             if "FETCH_SIZE" in k1 and "WRITE_SIZE" in k1:
                 traffic = (2.0 * k1["FETCH_SIZE"] + k1["WRITE_SIZE"]) * 1024.0
+        # FP64 operations K1 has to do for this batch (the bound that actually applies): per site and rate
+        # a cherry costs 4 multiplies, a tip-into-accumulator op 16 FMA + 4 mul, a pop-and-merge op
+        # 32 FMA + 4 mul, the five-state close at the root 5 * (4 mul + 4 FMA).
+        kinds = np.bincount((flat["ops"].reshape(-1, 4)[:, 0] & 15).astype(np.int64), minlength=3)[:3]
+        flop_per_site_rate = (4 * kinds[0] + 36 * kinds[1] + 68 * kinds[2]) / float(flat["ops"].shape[0]) + 60
+        k1_flops = flop_per_site_rate * sizes["n_sites"] * R * n
+        k1_tflops = k1_flops / (prune_ms * 1e-3) / 1e12
         out = {
             "metric": "phylo-HMM log-likelihood evals/sec (100-leaf x 400-site family)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -191,6 +202,8 @@ def main():
                          "traffic": traffic,
                          "algorithmic_bytes_per_eval": bytes_per_eval, "evals_per_launch": n,
                          "avg_launch_ms": prune_ms,
+                         "fp64_valu": {"achieved": k1_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": k1_tflops / FP64_VALU_PEAK_TFLOPS},
                          "note": "achieved = CLV-streaming model bytes (SURVEY 8(d)) / measured K1 time; the kernel "
                                  "keeps CLVs in registers and shares the tree across the naive states of a site, so it "
                                  "moves far fewer HBM bytes than the model and is FP64-VALU bound, see DESIGN.md"},

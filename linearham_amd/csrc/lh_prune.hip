@@ -45,8 +45,7 @@ namespace lh {
 #define LH_DECL_SLOT(d) double s##d##_0 = 0, s##d##_1 = 0, s##d##_2 = 0, s##d##_3 = 0;
 
 template <int kDepth>
-__global__ void __launch_bounds__(512)
-    prune_kernel(int compute_threads, int ahead, const uint8_t* __restrict__ msa, int L, int T, int n_ops,
+__device__ __forceinline__ void prune_body(int compute_threads, int ahead, const uint8_t* __restrict__ msa, int L, int T, int n_ops,
                  const int32_t* __restrict__ ops, const double* __restrict__ pmat,
                  const double* __restrict__ tipvec, const double* __restrict__ pi,
                  double* __restrict__ site_lik, int32_t* __restrict__ site_scal) {
@@ -74,7 +73,7 @@ __global__ void __launch_bounds__(512)
   // matrix at [k][1] (written by K0b), so the scalar loads walk memory sequentially and their
   // addresses do not depend on the op descriptor.
   const double* __restrict__ pm = pmat + ((size_t)sample * R + rate) * (size_t)(T - 2) * 32;
-  const uint8_t* __restrict__ msa_site = msa + site;
+  const unsigned usite = (unsigned)site;  // lane offset for loads from wave-uniform MSA row bases
 
   if (tid >= compute_threads) {
     // Prefetcher wave.  The P-matrix scalar loads of the compute waves miss the 16 KB scalar cache
@@ -104,6 +103,7 @@ __global__ void __launch_bounds__(512)
     return;
   }
 
+  const bool lane0 = (tid & 63) == 0;
   double a0 = 1.0, a1 = 1.0, a2 = 1.0, a3 = 1.0;
   int scal = 0;
   LH_DECL_SLOT(0) LH_DECL_SLOT(1) LH_DECL_SLOT(2) LH_DECL_SLOT(3)
@@ -118,16 +118,25 @@ __global__ void __launch_bounds__(512)
   int sa = 0, sb = 0;
   {
     const int kd = op.x & 15;
-    if (kd != OP_POP_ACC) sa = msa_site[(size_t)(op.y - 1) * L];
-    if (kd == OP_CHERRY) sb = msa_site[(size_t)(op.z - 1) * L];
+    if (kd != OP_POP_ACC) sa = (msa + (size_t)(op.y - 1) * L)[usite];
+    if (kd == OP_CHERRY) sb = (msa + (size_t)(op.z - 1) * L)[usite];
   }
   for (int k = 0; k < n_ops; ++k) {
     const int4 op_next = op_ptr[k + 1 < n_ops ? k + 1 : k];
-    if ((tid & 63) == 0) atomicMax(progress, k);  // paces the prefetcher wave
+    if (lane0) *reinterpret_cast<volatile int*>(progress) = k;  // paces the prefetcher wave (no atomic: the
+                                                                // waves of a workgroup run within an op or two)
     const int kind = op.x & 15;
     if (op.x & OP_PUSH_FLAG) {
       switch (op.w) {
-        LH_STACK_CASE(0) LH_STACK_CASE(1) LH_STACK_CASE(2) LH_STACK_CASE(3)
+        LH_STACK_CASE(0) LH_STACK_CASE(1) LH_STACK_CASE(2)
+        case 3:
+          if constexpr (kDepth > 3) {
+            s3_0 = a0;
+            s3_1 = a1;
+            s3_2 = a2;
+            s3_3 = a3;
+          }
+          break;
         default:
           if constexpr (kDepth > 4) {
             switch (op.w) {
@@ -165,10 +174,22 @@ __global__ void __launch_bounds__(512)
         a2 = ta1.x * x2;
         a3 = ta1.y * x3;
       } else {  // OP_POP_ACC
-        double y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+        double y0, y1, y2, y3;
         switch (op.w) {
-          LH_POP_CASE(0) LH_POP_CASE(1) LH_POP_CASE(2) LH_POP_CASE(3)
+          LH_POP_CASE(1) LH_POP_CASE(2)
+          case 3:
+            if constexpr (kDepth > 3) {
+              y0 = s3_0;
+              y1 = s3_1;
+              y2 = s3_2;
+              y3 = s3_3;
+              break;
+            }
           default:
+            y0 = s0_0;  // slot 0, unless one of the deeper variants' cases below matches
+            y1 = s0_1;
+            y2 = s0_2;
+            y3 = s0_3;
             if constexpr (kDepth > 4) {
               switch (op.w) {
                 LH_POP_CASE(4) LH_POP_CASE(5) LH_POP_CASE(6) LH_POP_CASE(7)
@@ -198,14 +219,15 @@ __global__ void __launch_bounds__(512)
     op = op_next;
     {
       const int kd = op.x & 15;
-      if (kd != OP_POP_ACC) sa = msa_site[(size_t)(op.y - 1) * L];
-      if (kd == OP_CHERRY) sb = msa_site[(size_t)(op.z - 1) * L];
+      if (kd != OP_POP_ACC) sa = (msa + (size_t)(op.y - 1) * L)[usite];
+      if (kd == OP_CHERRY) sb = (msa + (size_t)(op.z - 1) * L)[usite];
     }
     // CLV entries are non-negative, so the largest has the largest high word; it is below 2^-256
     // exactly when that word is below 0x2FF00000 (integer compares instead of 7 FP64 max/compare).
     const unsigned hw = max(max((unsigned)__double2hiint(a0), (unsigned)__double2hiint(a1)),
                             max((unsigned)__double2hiint(a2), (unsigned)__double2hiint(a3)));
-    if (hw < 0x2FF00000u && hw != 0u) {
+    const bool tiny = hw < 0x2FF00000u && hw != 0u;
+    if (__builtin_expect(__ballot(tiny) != 0, 0) && tiny) {  // rare: skip the whole block wave-wide
       a0 *= kScaleFactor;
       a1 *= kScaleFactor;
       a2 *= kScaleFactor;
@@ -229,6 +251,26 @@ __global__ void __launch_bounds__(512)
   }
 }
 
+#define LH_PRUNE_PARAMS                                                                                       \
+  int compute_threads, int ahead, const uint8_t *__restrict__ msa, int L, int T, int n_ops,                  \
+      const int32_t *__restrict__ ops, const double *__restrict__ pmat, const double *__restrict__ tipvec,   \
+      const double *__restrict__ pi, double *__restrict__ site_lik, int32_t *__restrict__ site_scal
+#define LH_PRUNE_ARGS compute_threads, ahead, msa, L, T, n_ops, ops, pmat, tipvec, pi, site_lik, site_scal
+
+// Shallow stacks (the common case): 64 VGPRs allow 8 waves per SIMD, but only if the wave also stays
+// within 96 SGPRs (the two P-matrices of an op alone are 64) -- the cap trades a few scalar spills for
+// a fourth resident workgroup per CU.
+template <int kDepth>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_num_sgpr(96))) prune_kernel(LH_PRUNE_PARAMS) {
+  prune_body<kDepth>(LH_PRUNE_ARGS);
+}
+
+// Deep stacks are VGPR-limited anyway: no SGPR cap.
+template <int kDepth>
+__global__ void __launch_bounds__(512) prune_kernel_deep(LH_PRUNE_PARAMS) {
+  prune_body<kDepth>(LH_PRUNE_ARGS);
+}
+
 void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
                   const double* pmat, const double* tipvec, const double* pi, double* site_lik,
                   int32_t* site_scal, hipStream_t stream) {
@@ -242,21 +284,23 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
   dim3 grid(tiles, R, n), block(compute + 64);
   const int n_ops = T - 2;
   static const int ahead = getenv("LH_K1_AHEAD") ? atoi(getenv("LH_K1_AHEAD")) : 8;
-#define LH_LAUNCH(D)                                                                                      \
+#define LH_LAUNCH_K(K)                                                                                    \
   {                                                                                                       \
     if (lds > 64 * 1024)                                                                                  \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(prune_kernel<D>),                                 \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
-    hipLaunchKernelGGL(prune_kernel<D>, grid, block, lds, stream, compute, ahead, fam.msa, L, T, n_ops, ops, pmat, \
-                       tipvec, pi, site_lik, site_scal);                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                \
+    hipLaunchKernelGGL(K, grid, block, lds, stream, compute, ahead, fam.msa, L, T, n_ops, ops, pmat, tipvec, pi, \
+                       site_lik, site_scal);                                                              \
   }
-  if (max_depth <= 4)
-    LH_LAUNCH(4)
+  if (max_depth <= 3)
+    LH_LAUNCH_K(prune_kernel<3>)
+  else if (max_depth <= 4)
+    LH_LAUNCH_K(prune_kernel<4>)
   else if (max_depth <= 8)
-    LH_LAUNCH(8)
+    LH_LAUNCH_K(prune_kernel_deep<8>)
   else
-    LH_LAUNCH(16)
-#undef LH_LAUNCH
+    LH_LAUNCH_K(prune_kernel_deep<16>)
+#undef LH_LAUNCH_K
 }
 
 }  // namespace lh

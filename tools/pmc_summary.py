@@ -1,32 +1,56 @@
 #!/usr/bin/env python3
 """Average rocprofv3 --pmc counter values per kernel dispatch.
 
-usage: pmc_summary.py <dir with *counter_collection.csv> [name-filter]
+usage: pmc_summary.py [--json OUT] [--note TEXT] DIR [DIR ...] [--filter NAME]
+
+Each DIR is the output directory of one `rocprofv3 --pmc ... --output-format csv` pass (counters that
+cannot share a pass are collected in separate passes and merged here).
 """
+import argparse
 import csv
 import glob
+import json
 import os
-import sys
 from collections import defaultdict
 
 
-def main():
-    root = sys.argv[1]
-    flt = sys.argv[2] if len(sys.argv) > 2 else ""
+def short(name):
+    name = name.split("(")[0]
+    return name[5:] if name.startswith("void ") else name
+
+
+def collect(dirs, flt):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
-    for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
-        with open(path) as f:
-            for r in csv.DictReader(f):
-                name = r["Kernel_Name"]
-                if flt and flt not in name:
-                    continue
-                a = acc[name.split("(")[0][-44:]][r["Counter_Name"]]
-                a[0] += float(r["Counter_Value"])
-                a[1] += 1
-    for k, ctrs in sorted(acc.items()):
+    for root in dirs:
+        for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for r in csv.DictReader(f):
+                    name = short(r["Kernel_Name"])
+                    if flt and flt not in name:
+                        continue
+                    a = acc[name][r["Counter_Name"]]
+                    a[0] += float(r["Counter_Value"])
+                    a[1] += 1
+    return {k: {c: tot / cnt for c, (tot, cnt) in sorted(v.items())} for k, v in sorted(acc.items())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dirs", nargs="+")
+    ap.add_argument("--filter", default="")
+    ap.add_argument("--json")
+    ap.add_argument("--note", default="")
+    args = ap.parse_args()
+    res = collect(args.dirs, args.filter)
+    if args.json:
+        out = {"_note": args.note}
+        out.update(res)
+        with open(args.json, "w") as f:
+            json.dump(out, f, indent=1)
+    for k, ctrs in res.items():
         print(k)
-        for c, (tot, cnt) in sorted(ctrs.items()):
-            print(f"   {c:28s} {tot / cnt:16.1f}  (n={cnt})")
+        for c, v in ctrs.items():
+            print("   %-28s %16.1f" % (c, v))
 
 
 if __name__ == "__main__":
