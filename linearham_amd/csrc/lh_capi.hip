@@ -299,6 +299,8 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
     return fail("lh_family_create: no HIP device available (this library has no CPU path)");
   if (desc->n_xmsa < 1) return fail("lh_family_create: n_xmsa must be >= 1");
   if (desc->n_seqs < 0 || desc->n_sites < 0) return fail("lh_family_create: negative dimension");
+  if ((int64_t)desc->n_seqs * desc->n_sites >= ((int64_t)1 << 31))
+    return fail("lh_family_create: MSA larger than 2^31 bytes (K1 addresses it with 32-bit offsets)");
   lh_family* f = new lh_family();
   if (hipGetDevice(&f->device) != hipSuccess) {
     delete f;

@@ -73,7 +73,7 @@ __device__ __forceinline__ void prune_body(int compute_threads, int ahead, const
   // matrix at [k][1] (written by K0b), so the scalar loads walk memory sequentially and their
   // addresses do not depend on the op descriptor.
   const double* __restrict__ pm = pmat + ((size_t)sample * R + rate) * (size_t)(T - 2) * 32;
-  const unsigned usite = (unsigned)site;  // lane offset for loads from wave-uniform MSA row bases
+  const unsigned usite = (unsigned)site;  // MSA byte offsets are 32-bit: (tip row) * L + site
 
   if (tid >= compute_threads) {
     // Prefetcher wave.  The P-matrix scalar loads of the compute waves miss the 16 KB scalar cache
@@ -87,7 +87,8 @@ __device__ __forceinline__ void prune_body(int compute_threads, int ahead, const
     const int* __restrict__ owords = reinterpret_cast<const int*>(op_ptr);
     int pf = 0, sink = 0;
     for (int spins = 0; pf < n_ops && spins < (1 << 24); ++spins) {
-      int target = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(progress)) + ahead;
+      int target = __builtin_amdgcn_readfirstlane(
+                       __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + ahead;
       target = target < n_ops ? target : n_ops;
       if (pf >= target) {
         __builtin_amdgcn_s_sleep(4);
@@ -118,39 +119,36 @@ __device__ __forceinline__ void prune_body(int compute_threads, int ahead, const
   int sa = 0, sb = 0;
   {
     const int kd = op.x & 15;
-    if (kd != OP_POP_ACC) sa = (msa + (size_t)(op.y - 1) * L)[usite];
-    if (kd == OP_CHERRY) sb = (msa + (size_t)(op.z - 1) * L)[usite];
+    if (kd != OP_POP_ACC) sa = msa[(unsigned)((op.y - 1) * L) + usite];
+    if (kd == OP_CHERRY) sb = msa[(unsigned)((op.z - 1) * L) + usite];
   }
   for (int k = 0; k < n_ops; ++k) {
     const int4 op_next = op_ptr[k + 1 < n_ops ? k + 1 : k];
-    if (lane0) *reinterpret_cast<volatile int*>(progress) = k;  // paces the prefetcher wave (no atomic: the
-                                                                // waves of a workgroup run within an op or two)
+    // paces the prefetcher wave (a relaxed LDS store, no atomic max: the waves of a workgroup run within
+    // an op or two of each other)
+    if (lane0) __hip_atomic_store(progress, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const int kind = op.x & 15;
     if (op.x & OP_PUSH_FLAG) {
-      switch (op.w) {
-        LH_STACK_CASE(0) LH_STACK_CASE(1) LH_STACK_CASE(2)
-        case 3:
-          if constexpr (kDepth > 3) {
-            s3_0 = a0;
-            s3_1 = a1;
-            s3_2 = a2;
-            s3_3 = a3;
-          }
-          break;
-        default:
-          if constexpr (kDepth > 4) {
-            switch (op.w) {
-              LH_STACK_CASE(4) LH_STACK_CASE(5) LH_STACK_CASE(6) LH_STACK_CASE(7)
-              default:
-                if constexpr (kDepth > 8) {
-                  switch (op.w) {
-                    LH_STACK_CASE(8) LH_STACK_CASE(9) LH_STACK_CASE(10) LH_STACK_CASE(11)
-                    LH_STACK_CASE(12) LH_STACK_CASE(13) LH_STACK_CASE(14) LH_STACK_CASE(15)
-                  }
-                }
-            }
-          }
+      // Independent wave-uniform branches, one per slot: each leaves every other slot's registers alone
+      // (a single switch made the compiler shuffle whole slots through temporaries at its merge points).
+#define LH_PUSH_IF(d)             \
+  if constexpr (kDepth > d) {     \
+    if (op.w == d) {              \
+      s##d##_0 = a0;              \
+      s##d##_1 = a1;              \
+      s##d##_2 = a2;              \
+      s##d##_3 = a3;              \
+    }                             \
+  }
+      LH_PUSH_IF(0) LH_PUSH_IF(1) LH_PUSH_IF(2) LH_PUSH_IF(3)
+      if constexpr (kDepth > 4) {
+        if (op.w >= 4) {
+          LH_PUSH_IF(4) LH_PUSH_IF(5) LH_PUSH_IF(6) LH_PUSH_IF(7)
+          LH_PUSH_IF(8) LH_PUSH_IF(9) LH_PUSH_IF(10) LH_PUSH_IF(11)
+          LH_PUSH_IF(12) LH_PUSH_IF(13) LH_PUSH_IF(14) LH_PUSH_IF(15)
+        }
       }
+#undef LH_PUSH_IF
     }
     if (kind == OP_CHERRY) {
       const double2* ta = reinterpret_cast<const double2*>(tiptab + op.y * 20 + sa * 4);
@@ -174,40 +172,42 @@ __device__ __forceinline__ void prune_body(int compute_threads, int ahead, const
         a2 = ta1.x * x2;
         a3 = ta1.y * x3;
       } else {  // OP_POP_ACC
-        double y0, y1, y2, y3;
-        switch (op.w) {
-          LH_POP_CASE(1) LH_POP_CASE(2)
-          case 3:
-            if constexpr (kDepth > 3) {
-              y0 = s3_0;
-              y1 = s3_1;
-              y2 = s3_2;
-              y3 = s3_3;
-              break;
-            }
-          default:
-            y0 = s0_0;  // slot 0, unless one of the deeper variants' cases below matches
-            y1 = s0_1;
-            y2 = s0_2;
-            y3 = s0_3;
-            if constexpr (kDepth > 4) {
-              switch (op.w) {
-                LH_POP_CASE(4) LH_POP_CASE(5) LH_POP_CASE(6) LH_POP_CASE(7)
-                default:
-                  if constexpr (kDepth > 8) {
-                    switch (op.w) {
-                      LH_POP_CASE(8) LH_POP_CASE(9) LH_POP_CASE(10) LH_POP_CASE(11)
-                      LH_POP_CASE(12) LH_POP_CASE(13) LH_POP_CASE(14) LH_POP_CASE(15)
-                    }
-                  }
-              }
-            }
-        }
+        // The popped sibling is multiplied straight out of its slot (one copy of the mat-vec per shallow
+        // slot) instead of being copied into common registers first.
         const double* __restrict__ pa = pm + (size_t)k * 32 + 16;
-        const double z0 = fma(pa[3], y3, fma(pa[2], y2, fma(pa[1], y1, pa[0] * y0)));
-        const double z1 = fma(pa[7], y3, fma(pa[6], y2, fma(pa[5], y1, pa[4] * y0)));
-        const double z2 = fma(pa[11], y3, fma(pa[10], y2, fma(pa[9], y1, pa[8] * y0)));
-        const double z3 = fma(pa[15], y3, fma(pa[14], y2, fma(pa[13], y1, pa[12] * y0)));
+        double z0, z1, z2, z3;
+#define LH_POP_MATVEC(y0, y1, y2, y3)                                      \
+  z0 = fma(pa[3], y3, fma(pa[2], y2, fma(pa[1], y1, pa[0] * y0)));         \
+  z1 = fma(pa[7], y3, fma(pa[6], y2, fma(pa[5], y1, pa[4] * y0)));         \
+  z2 = fma(pa[11], y3, fma(pa[10], y2, fma(pa[9], y1, pa[8] * y0)));       \
+  z3 = fma(pa[15], y3, fma(pa[14], y2, fma(pa[13], y1, pa[12] * y0)));
+#define LH_POP_SLOT(d) LH_POP_MATVEC(s##d##_0, s##d##_1, s##d##_2, s##d##_3)
+        if (op.w == 0) {
+          LH_POP_SLOT(0)
+        } else if (op.w == 1) {
+          LH_POP_SLOT(1)
+        } else if (kDepth > 2 && op.w == 2) {
+          LH_POP_SLOT(2)
+        } else if (kDepth > 3 && op.w == 3) {
+          LH_POP_SLOT(3)
+        } else {
+          double y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+          if constexpr (kDepth > 4) {
+            switch (op.w) {
+              LH_POP_CASE(4) LH_POP_CASE(5) LH_POP_CASE(6) LH_POP_CASE(7)
+              default:
+                if constexpr (kDepth > 8) {
+                  switch (op.w) {
+                    LH_POP_CASE(8) LH_POP_CASE(9) LH_POP_CASE(10) LH_POP_CASE(11)
+                    LH_POP_CASE(12) LH_POP_CASE(13) LH_POP_CASE(14) LH_POP_CASE(15)
+                  }
+                }
+            }
+          }
+          LH_POP_MATVEC(y0, y1, y2, y3)
+        }
+#undef LH_POP_SLOT
+#undef LH_POP_MATVEC
         a0 = z0 * x0;
         a1 = z1 * x1;
         a2 = z2 * x2;
@@ -219,8 +219,8 @@ __device__ __forceinline__ void prune_body(int compute_threads, int ahead, const
     op = op_next;
     {
       const int kd = op.x & 15;
-      if (kd != OP_POP_ACC) sa = (msa + (size_t)(op.y - 1) * L)[usite];
-      if (kd == OP_CHERRY) sb = (msa + (size_t)(op.z - 1) * L)[usite];
+      if (kd != OP_POP_ACC) sa = msa[(unsigned)((op.y - 1) * L) + usite];
+      if (kd == OP_CHERRY) sb = msa[(unsigned)((op.z - 1) * L) + usite];
     }
     // CLV entries are non-negative, so the largest has the largest high word; it is below 2^-256
     // exactly when that word is below 0x2FF00000 (integer compares instead of 7 FP64 max/compare).
