@@ -26,7 +26,7 @@ int fail(const std::string& msg) {
 
 struct Workspace {
   int n_cap = 0, R = 0, T = 0;
-  double *rates = nullptr, *eig = nullptr, *pmat = nullptr, *tipvec = nullptr, *site_lik = nullptr;
+  double *rates = nullptr, *eig = nullptr, *pmat = nullptr, *site_lik = nullptr;
   int32_t* site_scal = nullptr;
 };
 
@@ -216,8 +216,7 @@ int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_
 int ensure_workspace(lh_family* f, int n, int R, int T) {
   Workspace& w = f->ws;
   if (n <= w.n_cap && R == w.R && T == w.T) return 0;
-  void** bufs[] = {(void**)&w.rates, (void**)&w.eig,       (void**)&w.pmat, (void**)&w.tipvec,
-                   (void**)&w.site_lik, (void**)&w.site_scal};
+  void** bufs[] = {(void**)&w.rates, (void**)&w.eig, (void**)&w.pmat, (void**)&w.site_lik, (void**)&w.site_scal};
   for (void** b : bufs) {
     if (*b) LH_HIP(hipFree(*b));
     *b = nullptr;
@@ -228,7 +227,6 @@ int ensure_workspace(lh_family* f, int n, int R, int T) {
   LH_HIP(hipMalloc((void**)&w.rates, sizeof(double) * cap * R));
   LH_HIP(hipMalloc((void**)&w.eig, sizeof(double) * cap * 36));
   LH_HIP(hipMalloc((void**)&w.pmat, sizeof(double) * cap * R * (size_t)std::max(T - 2, 1) * 32));
-  LH_HIP(hipMalloc((void**)&w.tipvec, sizeof(double) * cap * R * (size_t)T * 20));
   LH_HIP(hipMalloc((void**)&w.site_lik, sizeof(double) * cap * R * 5 * std::max(L, (size_t)1)));
   LH_HIP(hipMalloc((void**)&w.site_scal, sizeof(int32_t) * cap * R * std::max(L, (size_t)1)));
   w.n_cap = cap;
@@ -425,7 +423,7 @@ void lh_family_destroy(lh_family* f) {
   if (!f) return;
   for (void* p : f->allocs) (void)hipFree(p);
   Workspace& w = f->ws;
-  void* bufs[] = {w.rates, w.eig, w.pmat, w.tipvec, w.site_lik, w.site_scal, f->fws.gem, f->fws.jem, f->fws.gcnt};
+  void* bufs[] = {w.rates, w.eig, w.pmat, w.site_lik, w.site_scal, f->fws.gem, f->fws.jem, f->fws.gcnt};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* p : f->st.ptr)
@@ -605,11 +603,9 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
     double* em_out = (outs && outs->xmsa_emission) ? outs->xmsa_emission + (size_t)off * C : nullptr;
     lh::launch_model_setup(m, R, er + (size_t)off * 6, pi + (size_t)off * 4, alpha + off, rates, w.eig,
                            stream);
-    lh::launch_pmatrices(m, R, T, ops + (size_t)off * n_ops * 4, brlen + (size_t)off * nodes, rates, w.eig, w.pmat,
-                         w.tipvec, stream);
     if (f->profile) LH_HIP(hipEventRecord(es.e[1], stream));
-    lh::launch_prune(f->host, m, R, T, max_depth, ops + (size_t)off * n_ops * 4, w.pmat, w.tipvec,
-                     pi + (size_t)off * 4, w.site_lik, w.site_scal, stream);
+    lh::launch_prune(f->host, m, R, T, max_depth, ops + (size_t)off * n_ops * 4, brlen + (size_t)off * nodes, rates,
+                     w.eig, w.pmat, pi + (size_t)off * 4, w.site_lik, w.site_scal, stream);
     if (f->profile) LH_HIP(hipEventRecord(es.e[2], stream));
     if (run_forward(f, m, R, w.site_lik, w.site_scal, pi + (size_t)off * 4, nullptr, em_out, loglik + off, outs, off,
                     stream))

@@ -62,8 +62,7 @@ struct DevFamily {
   int64_t scaler_size;    // ints per sample in the scaler-count output
 };
 
-// P = I + U expm1(lambda * t*r) Uinv, clamped at 0 (shared by K0b for inner-node branches and by
-// K1's prologue for the tip tables, so both see bit-identical matrices).
+// P = I + U expm1(lambda * t*r) Uinv, clamped at 0 (K1's prologue).
 // e: lambda[4] | U[4][4] | Uinv[4][4]
 __device__ static inline void compute_pmatrix(const double* __restrict__ e, double tr, double P[4][4]) {
   double ex[4];
@@ -87,17 +86,15 @@ __device__ static inline void compute_pmatrix(const double* __restrict__ e, doub
 void launch_model_setup(int n, int R, const double* er, const double* pi, const double* alpha,
                         double* rates, double* eig, hipStream_t stream);
 
-// K0b: P-matrices in schedule order: pmat[n][R][T-2][2][16] (op k: [0] = matrix of the child whose CLV is
-// in the accumulator, [1] = matrix of the popped child; unused slots are left untouched) and the tip
-// tables tipvec[n][R][T][5][4] (columns of P for A,C,G,T and the row sums for N).
-void launch_pmatrices(int n, int R, int T, const int32_t* ops, const double* brlen, const double* rates,
-                      const double* eig, double* pmat, double* tipvec, hipStream_t stream);
-
-// K1: Felsenstein pruning over the MSA sites with the naive tip factored out.
+// K1: Felsenstein pruning over the MSA sites with the naive tip factored out; each workgroup first
+// computes the P-matrices of its (sample, rate): P = I + U expm1(lambda t r) U^-1 for every branch,
+// inner-branch matrices in schedule order into the scratch area pmat[n][R][T-2][2][16] (op k: [0] =
+// matrix of the child whose CLV is in the accumulator, [1] = matrix of the popped child), tip-branch
+// matrices into its LDS tip table.
 // site_lik[n][R][5][L], site_scal[n][R][L]
 void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
-                  const double* pmat, const double* tipvec, const double* pi, double* site_lik,
-                  int32_t* site_scal, hipStream_t stream);
+                  const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
+                  double* site_lik, int32_t* site_scal, hipStream_t stream);
 
 // K2a + K2b.  site_lik != null: emissions are assembled from K1's output (rate mix and naive
 // correction; optionally written to em_out[n][C]); site_lik == null: emissions are taken from

@@ -3,10 +3,9 @@
 // Replaces, per tree sample (citations into matsengrp/linearham; [3P] = libpll via libptpll):
 //   pll_compute_gamma_cats(alpha, R, rates, PLL_GAMMA_RATES_MEAN)        src/PhyloHMM.cpp:425-426 [3P]
 //   pt::pll::Model{"GTR", pi, er, sr} + eigendecomposition in Partition   src/PhyloHMM.cpp:368-370 [3P]
-//   pll_update_prob_matrices inside Partition::TraversalUpdate            src/PhyloHMM.cpp:225     [3P]
 //
-// These are tiny (36 + B*R*16 doubles per sample) compared with the pruning kernel; they run as
-// one thread per sample (K0a) and one thread per (sample, rate, branch) (K0b).
+// Tiny next to the pruning kernel (36 + R doubles per sample); the P-matrices themselves are computed
+// by K1's prologue (compute_pmatrix, lh_device.h).
 #include "lh_device.h"
 
 namespace lh {
@@ -194,69 +193,12 @@ __global__ void __launch_bounds__(256) finalize_rates_kernel(int n, int R, doubl
   r[R - 1] = (1.0 - prev) * R;   // R == 1: the single rate is 1
 }
 
-// ---- K0b -------------------------------------------------------------------------------------------
-
-__global__ void __launch_bounds__(256) pmatrix_kernel(int n, int R, int T, const int32_t* __restrict__ ops,
-                                                      const double* __restrict__ brlen,
-                                                      const double* __restrict__ rates,
-                                                      const double* __restrict__ eig,
-                                                      double* __restrict__ pmat,
-                                                      double* __restrict__ tipvec) {
-  const int I = T - 2, nodes = 2 * T - 2, per = I + T;
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)n * R * per;
-  if (gid >= total) return;
-  const int j = (int)(gid % per);
-  const int r = (int)((gid / per) % R);
-  const int s = (int)(gid / ((long long)per * R));
-  const double* e = eig + (size_t)s * 36;
-  const double rt = rates[(size_t)s * R + r];
-  const double* bl = brlen + (size_t)s * nodes;
-  double P[4][4];
-  if (j < T) {  // tip branch j: columns of P (+ row sums for N) in the layout of K1's LDS tip table
-    compute_pmatrix(e, bl[j] * rt, P);
-    double* o = tipvec + (((size_t)s * R + r) * T + j) * 20;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
-      o[16 + i] = ((P[i][0] + P[i][1]) + P[i][2]) + P[i][3];
-    }
-    return;
-  }
-  // op k of the schedule: matrices of its inner-node children, stored where K1 will stream them
-  const int k = j - T;
-  const int4 op = reinterpret_cast<const int4*>(ops)[(size_t)s * I + k];
-  const int kind = op.x & 15;
-  if (kind == OP_CHERRY) return;
-  double* o = pmat + (((size_t)s * R + r) * I + k) * 32;
-  compute_pmatrix(e, bl[op.z] * rt, P);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o[i * 4 + q] = P[i][q];
-  if (kind == OP_POP_ACC) {
-    compute_pmatrix(e, bl[op.y] * rt, P);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) o[16 + i * 4 + q] = P[i][q];
-  }
-}
-
 void launch_model_setup(int n, int R, const double* er, const double* pi, const double* alpha,
                         double* rates, double* eig, hipStream_t stream) {
   const long long total = (long long)n * R;
   hipLaunchKernelGGL(model_setup_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, stream, n, R, er, pi,
                      alpha, rates, eig);
   hipLaunchKernelGGL(finalize_rates_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, R, rates);
-}
-
-void launch_pmatrices(int n, int R, int T, const int32_t* ops, const double* brlen, const double* rates,
-                      const double* eig, double* pmat, double* tipvec, hipStream_t stream) {
-  const long long total = (long long)n * R * (2 * T - 2);
-  hipLaunchKernelGGL(pmatrix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, n, R, T, ops,
-                     brlen, rates, eig, pmat, tipvec);
 }
 
 }  // namespace lh

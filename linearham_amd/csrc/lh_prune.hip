@@ -24,8 +24,9 @@
 //  * Tip children need no mat-vec: P * onehot(state) is a column of P.  Those columns (plus the
 //    row sums for N) are staged once per workgroup in LDS as tiptab[tip][state][4] and gathered
 //    with two ds_read_b128 per lane and site.
-//  * K0b stores the P-matrices of a (sample, rate) in schedule order, so the scalar loads of the loop
-//    stream through memory and the waves of a workgroup share every fetched line.
+//  * The workgroup first computes its (sample, rate)'s P-matrices itself (no separate kernel, no HBM
+//    round trip): inner-branch matrices in schedule order into a global scratch area that its own
+//    scalar loads read back from L2, tip-branch matrices straight into the LDS tip table.
 //  * HBM traffic is therefore ~T bytes of tip states per site (L2-resident, shared by all samples)
 //    and 5 doubles out, instead of the 2*I*R*32 bytes per column of a CLV-streaming kernel.
 #include <cstdlib>
@@ -239,9 +240,11 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
 // blockIdx.x * tile .. +tile-1 (clipped to L).
 template <int kDepth, bool kTwo>
 __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __restrict__ msa, int L, int T, int n_ops,
-                                           const int32_t* __restrict__ ops, const double* __restrict__ pmat,
-                                           const double* __restrict__ tipvec, const double* __restrict__ pi,
-                                           double* __restrict__ site_lik, int32_t* __restrict__ site_scal) {
+                                           const int32_t* __restrict__ ops, const double* __restrict__ brlen,
+                                           const double* __restrict__ rates, const double* __restrict__ eig,
+                                           double* pmat_w, const double* __restrict__ pmat,
+                                           const double* __restrict__ pi, double* __restrict__ site_lik,
+                                           int32_t* __restrict__ site_scal) {
   extern __shared__ double2 smem2[];
   double* tiptab = reinterpret_cast<double*>(smem2);  // [T][5][4]
 
@@ -249,19 +252,69 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
   const int R = gridDim.y;
   const int rate = blockIdx.y;
   const int sample = blockIdx.z;
+  const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
+  const size_t pm_off = ((size_t)sample * R + rate) * (size_t)(T - 2) * 32;
 
-  {  // stage this (sample, rate)'s tip table in LDS
-    const double2* src =
-        reinterpret_cast<const double2*>(tipvec + ((size_t)sample * R + rate) * (size_t)T * 20);
-    for (int i = tid; i < T * 10; i += blockDim.x) smem2[i] = src[i];
+  // Prologue (formerly a kernel of its own): the P-matrices of this (sample, rate).
+  //   P = I + U expm1(lambda t r) U^-1   (pll_update_prob_matrices [3P])
+  // One thread per matrix.  The first half of the block takes the schedule's ops: op k's
+  // accumulator-child matrix goes to pmat[k][0], its popped-child matrix to pmat[k][1] -- global memory,
+  // because the walk below wants them as SCALAR operands and scalar loads only read memory; the lines
+  // are written and, a barrier later, read back on the same CU, so they are served by its L2.  The
+  // second half takes the tip branches: a tip child needs no mat-vec, P * onehot(state) is a column of
+  // P, and those columns (plus the row sums for N) go straight into the LDS table
+  // tiptab[tip][state][4].
+  {
+    const double* __restrict__ e = eig + (size_t)sample * 36;
+    const double rt = rates[(size_t)sample * R + rate];
+    const double* __restrict__ bl = brlen + (size_t)sample * (2 * (size_t)T - 2);
+    double* pw = pmat_w + pm_off;
+    const int nthr = blockDim.x;
+    const int half = nthr >= 128 ? (nthr / 128) * 64 : 0;  // whole waves on either side
+    const bool do_ops = half == 0 || tid < half;
+    const bool do_tips = half == 0 || tid >= half;
+    double P[4][4];
+    if (do_ops) {
+      const int stride = half ? half : nthr;
+      for (int k = tid; k < n_ops; k += stride) {
+        const int4 op = op_ptr[k];
+        const int kind = op.x & 15;
+        if (kind == OP_CHERRY) continue;
+        double* o = pw + (size_t)k * 32;
+        compute_pmatrix(e, bl[op.z] * rt, P);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[i * 4 + q] = P[i][q];
+        if (kind == OP_POP_ACC) {
+          compute_pmatrix(e, bl[op.y] * rt, P);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[16 + i * 4 + q] = P[i][q];
+        }
+      }
+    }
+    if (do_tips) {
+      const int stride = half ? nthr - half : nthr;
+      for (int j = half ? tid - half : tid; j < T; j += stride) {
+        compute_pmatrix(e, bl[j] * rt, P);
+        double* o = tiptab + j * 20;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
+          o[16 + i] = ((P[i][0] + P[i][1]) + P[i][2]) + P[i][3];
+        }
+      }
+    }
   }
+  __threadfence_block();  // the stores above have reached L2 before any wave passes the barrier
   __syncthreads();
 
-  const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
-  // P-matrices in schedule order: op k's accumulator-child matrix at [k][0], its popped-child
-  // matrix at [k][1] (written by K0b), so the scalar loads walk memory sequentially and their
-  // addresses do not depend on the op descriptor.
-  const double* __restrict__ pm = pmat + ((size_t)sample * R + rate) * (size_t)(T - 2) * 32;
+  // P-matrices in schedule order, now through the read-only alias: the scalar loads of the walk stream
+  // through memory and their addresses do not depend on the op descriptor.
+  const double* __restrict__ pm = pmat + pm_off;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int tile0 = blockIdx.x * tile;
@@ -280,11 +333,15 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
                         lik_out, scal_out);
 }
 
+// pmat_w and pmat are the same buffer: written through the first in the prologue, read through the
+// second (declared read-only and unaliased, which is what lets the compiler keep the walk's P-matrix
+// loads on the scalar unit) after the barrier.
 #define LH_PRUNE_PARAMS                                                                                     \
   int n2, int tile, const uint8_t *__restrict__ msa, int L, int T, int n_ops, const int32_t *__restrict__ ops, \
-      const double *__restrict__ pmat, const double *__restrict__ tipvec, const double *__restrict__ pi,   \
+      const double *__restrict__ brlen, const double *__restrict__ rates, const double *__restrict__ eig,  \
+      double *pmat_w, const double *__restrict__ pmat, const double *__restrict__ pi,                      \
       double *__restrict__ site_lik, int32_t *__restrict__ site_scal
-#define LH_PRUNE_ARGS n2, tile, msa, L, T, n_ops, ops, pmat, tipvec, pi, site_lik, site_scal
+#define LH_PRUNE_ARGS n2, tile, msa, L, T, n_ops, ops, brlen, rates, eig, pmat_w, pmat, pi, site_lik, site_scal
 
 // Shallow stacks (depth <= 4, any tree up to a few hundred tips): two sites per lane.  The kernel is bound
 // by the latency of its compulsory scalar-cache misses (every P-matrix line is new to the CU), so
@@ -302,8 +359,8 @@ __global__ void __launch_bounds__(512) prune_kernel_deep(LH_PRUNE_PARAMS) {
 }
 
 void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
-                  const double* pmat, const double* tipvec, const double* pi, double* site_lik,
-                  int32_t* site_scal, hipStream_t stream) {
+                  const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
+                  double* site_lik, int32_t* site_scal, hipStream_t stream) {
   const int L = fam.n_sites;
   const bool two = max_depth <= 4;
   // tile: up to 512 sites as two-site waves plus at most one one-site wave for a remainder below 64
@@ -331,8 +388,8 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
     if (lds > 64 * 1024)                                                                                      \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                    \
-    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, fam.msa, L, T, n_ops, ops, pmat, tipvec, pi,    \
-                       site_lik, site_scal);                                                                  \
+    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, fam.msa, L, T, n_ops, ops, brlen, rates, eig,   \
+                       pmat, (const double*)pmat, pi, site_lik, site_scal);                                   \
   }
   if (max_depth <= 3)
     LH_LAUNCH_K(prune_kernel<3>)
