@@ -50,9 +50,12 @@ namespace {
     dst[s_][2] = src[s_][2];                         \
     dst[s_][3] = src[s_][3];                         \
   }
-#define LH_PUSH_IF(d)                         \
-  if constexpr (kDepth > d) {                 \
-    if (op.w == d) { LH_SLOT_COPY(st##d, a) } \
+// The push tests one bit of a one-hot slot mask that is opaque to the optimiser (it comes through
+// v_readfirstlane): equality tests on the slot number get merged back into one compare tree whose joins
+// route whole slots through temporaries and scratch memory (57 v_mov_b64 in the loop body).
+#define LH_PUSH_IF(d)                                   \
+  if constexpr (kDepth > d) {                           \
+    if (push_mask & (1u << d)) { LH_SLOT_COPY(st##d, a) } \
   }
 #define LH_POP_CASE(d)          \
   case d:                       \
@@ -115,6 +118,7 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
     const int4 op_next = op_ptr[k + 1 < n_ops ? k + 1 : k];
     const int kind = op.x & 15;
     if (op.x & OP_PUSH_FLAG) {
+      const unsigned push_mask = __builtin_amdgcn_readfirstlane(1u << op.w);
       LH_PUSH_IF(0) LH_PUSH_IF(1) LH_PUSH_IF(2) LH_PUSH_IF(3)
       if constexpr (kDepth > 4) {
         if (op.w >= 4) {
