@@ -158,8 +158,13 @@ def main():
                                       C.byref(groups)))
     lib.check(lib.lib.lh_profile_enable(C.c_void_p(fam_handle), 0))
     ll_host = loglik.cpu().numpy()
-    if not args.no_check and not np.all(np.isfinite(ll_host)):
-        raise SystemExit("non-finite log-likelihoods in the benchmark batch")
+    n_bad = int(np.sum(~np.isfinite(ll_host)))
+    if n_bad and not args.no_check:
+        # configs[2] (the benchmark family) must be clean; the 500-leaf family has tree samples on which the
+        # reference's own 2^(256*delta) equalisation overflows -- reported, not fatal
+        if args.preset == "config2":
+            raise SystemExit("non-finite log-likelihoods in the benchmark batch")
+        log("[rank %d] %d of %d evaluations are non-finite (reference overflow behaviour)" % (rank, n_bad, n))
 
     if rank == 0:
         total_evals = world * n * args.steps
@@ -224,12 +229,15 @@ def main():
                                                 p(flat["pi"], C.c_double), p(flat["alpha"], C.c_double), R,
                                                 p(ll_pcie, C.c_double), None))
             out["pcie_inclusive_evals_per_s"] = n * reps / (time.perf_counter() - t1)
-            if not args.no_check and not np.array_equal(ll_pcie, ll_host):
+            if not args.no_check and not np.array_equal(ll_pcie, ll_host, equal_nan=True):
                 raise SystemExit("host-pointer and device-pointer entry points disagree")
         if world == 1 and not args.no_cpu_baseline:
             base, ref_ll = cpu_baseline(fam_dir, 64, args.cpu_budget_s)
             out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
-            rel = max(abs(ll_host[i] - v) / abs(v) for i, v in ref_ll.items() if i < n)
+            both = [(ll_host[i], v) for i, v in ref_ll.items() if i < n]
+            if any(np.isfinite(g) != np.isfinite(v) for g, v in both):
+                raise SystemExit("parity failure: GPU and CPU oracle disagree on which evaluations are finite")
+            rel = max([abs(g - v) / abs(v) for g, v in both if np.isfinite(v)] or [0.0])
             out["delta_logl_vs_cpu_max_rel"] = rel
             out["speedup_vs_cpu_all_cores"] = value / base["value"]
             if rel > 1e-6:

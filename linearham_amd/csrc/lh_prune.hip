@@ -367,9 +367,12 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
                   double* site_lik, int32_t* site_scal, hipStream_t stream) {
   const int L = fam.n_sites;
   const bool two = max_depth <= 4;
-  // tile: up to 512 sites as two-site waves plus at most one one-site wave for a remainder below 64
-  // (deep variant: up to 8 one-site waves); tiles rebalanced so that they are equally full
-  const int tiles = (L + 511) / 512;
+  // tile: up to 1024 sites as two-site waves plus at most one one-site wave for a remainder below 64
+  // (deep variant: up to 8 one-site waves = 512 sites); tiles rebalanced so that they are equally full.
+  // Large tiles matter for large trees: every workgroup of a (sample, rate) repeats the P-matrix
+  // prologue and holds its own T x 160-byte tip table in LDS.
+  const int cap = two ? 1024 : 512;
+  const int tiles = (L + cap - 1) / cap;
   const int tile = (L + tiles - 1) / tiles;
   int n2 = 0, n1;
   if (two) {

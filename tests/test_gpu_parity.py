@@ -154,6 +154,43 @@ def test_batch_of_varied_models_on_toy_family(hip, data_dir):
     compare(h, desc, ll, res, ref)
 
 
+def test_more_samples_than_one_launch_group(hip, data_dir):
+    """n > 8192 samples run as several launch groups over the same workspace: the P-matrix scratch area is
+    rewritten with different matrices at the same addresses and read back through the scalar cache, the
+    K2a -> K2b hand-off buffers are reused."""
+    import linearham_amd
+    h = orc.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input_extra.yaml"), 0,
+                     os.path.join(data_dir, "hmm_params"), 0)
+    rng = np.random.default_rng(5)
+    sets = []
+    for _ in range(23):
+        bl = rng.exponential(0.2, size=5) + 1e-6
+        sets.append(dict(tree="((0:%g,1:%g):%g,naive:%g,2:%g);" % tuple(bl),
+                         er=rng.dirichlet(np.ones(6)).tolist(), pi=rng.dirichlet(np.ones(4) * 2).tolist(),
+                         alpha=float(max(rng.exponential(1.0), 0.05))))
+    ref = []
+    for s in sets:
+        h.initialize_phylo_parameters(s["tree"], s["er"], s["pi"], s["alpha"], 4, is_path=False)
+        h.initialize_phylo_emission()
+        ref.append(h.log_likelihood())
+    desc = db.build_family_desc(h)
+    fam = linearham_amd.Family(desc, hip)
+    T = h.msa.shape[0] + 1
+    sched = []
+    for s in sets:
+        children, root, brlen = db.tree_arrays(orc.parse_newick(s["tree"]), h.xmsa_labels)
+        o, d = hip.schedule_tree(T, children, root)
+        sched.append((o, brlen, d))
+    n = 2 * 8192 + 7
+    pick = [(i * 7 + i // 8192) % len(sets) for i in range(n)]   # position p differs between the groups
+    ll, _ = fam.eval_batch(T, max(x[2] for x in sched), np.stack([sched[j][0] for j in pick]),
+                           np.stack([sched[j][1] for j in pick]), [sets[j]["er"] for j in pick],
+                           [sets[j]["pi"] for j in pick], [sets[j]["alpha"] for j in pick], 4, want=())
+    fam.close()
+    want = np.array([ref[j] for j in pick])
+    np.testing.assert_allclose(ll, want, rtol=1e-10)
+
+
 @pytest.mark.parametrize("preset", ["small", "medium", "igk", "igl", "many_alleles", "many_alleles_igk"])
 def test_synthetic_family(hip, tmp_path, preset):
     """Multi-allele junctions, NNI-perturbed trees with [&index=..] annotations; the medium family
