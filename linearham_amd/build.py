@@ -48,12 +48,12 @@ def build_host(verbose=False, force=False):
     out = os.path.join(LIB, "liblinearham_host.so")
     deps = srcs + hdrs + [os.path.join(ROOT, "include", "linearham_amd.h")]
     if force or _stale(out, deps):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"),
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-I", os.path.join(ROOT, "include"),
               "-I", hostdir] + lib_srcs + ["-o", out, "-L", LIB, "-llinearham_hip", "-Wl,-rpath,$ORIGIN"], verbose)
     exe = os.path.join(LIB, "linearham")
     main = os.path.join(hostdir, "linearham_main.cpp")
     if os.path.exists(main) and (force or _stale(exe, deps)):
-        _run(["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", hostdir, main,
+        _run(["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", hostdir, main,
               "-o", exe, "-L", LIB, "-llinearham_host", "-llinearham_hip", "-Wl,-rpath,$ORIGIN"], verbose)
     return out
 

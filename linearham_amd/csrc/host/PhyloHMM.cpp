@@ -2,7 +2,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <exception>
 #include <sstream>
+#include <thread>
 
 namespace linearham {
 
@@ -155,18 +157,45 @@ PhyloHMM::DeviceBatch PhyloHMM::FlattenBatch(const std::vector<TreeSample>& samp
   b.er.resize((std::size_t)b.n * 6);
   b.pi.resize((std::size_t)b.n * 4);
   b.alpha.resize(b.n);
-  for (int s = 0; s < b.n; ++s) {
-    const TreeSample& ts = samples[s];
-    Require(ts.er.size() == 6 && ts.pi.size() == 4, "er must have 6 and pi 4 entries");
-    const TreeArrays tr = ParseNewick(ts.newick, xmsa_labels_, EPS);
-    int32_t depth = 0;
-    CheckHip(lh_schedule_tree(T, tr.children.data(), tr.root, b.ops.data() + (std::size_t)s * (T - 2) * 4, &depth),
-             "lh_schedule_tree");
-    b.max_depth = std::max(b.max_depth, (int)depth);
-    std::copy(tr.brlen.begin(), tr.brlen.end(), b.brlen.begin() + (std::size_t)s * (2 * T - 2));
-    std::copy(ts.er.begin(), ts.er.end(), b.er.begin() + (std::size_t)s * 6);
-    std::copy(ts.pi.begin(), ts.pi.end(), b.pi.begin() + (std::size_t)s * 4);
-    b.alpha[s] = ts.alpha;
+  // Rows are independent (parse, unroot at naive's neighbour, schedule): the GPU evaluates a few million
+  // trees per second, one host core flattens a few ten thousand, so the rows are spread over the cores.
+  auto flatten_rows = [&](int lo, int hi, int* max_depth) {
+    for (int s = lo; s < hi; ++s) {
+      const TreeSample& ts = samples[s];
+      Require(ts.er.size() == 6 && ts.pi.size() == 4, "er must have 6 and pi 4 entries");
+      const TreeArrays tr = ParseNewick(ts.newick, xmsa_labels_, EPS);
+      int32_t depth = 0;
+      CheckHip(lh_schedule_tree(T, tr.children.data(), tr.root, b.ops.data() + (std::size_t)s * (T - 2) * 4, &depth),
+               "lh_schedule_tree");
+      *max_depth = std::max(*max_depth, (int)depth);
+      std::copy(tr.brlen.begin(), tr.brlen.end(), b.brlen.begin() + (std::size_t)s * (2 * T - 2));
+      std::copy(ts.er.begin(), ts.er.end(), b.er.begin() + (std::size_t)s * 6);
+      std::copy(ts.pi.begin(), ts.pi.end(), b.pi.begin() + (std::size_t)s * 4);
+      b.alpha[s] = ts.alpha;
+    }
+  };
+  const int hw = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+  const int n_threads = std::max(1, std::min(hw, b.n / 64));
+  if (n_threads == 1) {
+    flatten_rows(0, b.n, &b.max_depth);
+  } else {
+    std::vector<std::thread> pool;
+    std::vector<int> depths(n_threads, 0);
+    std::vector<std::exception_ptr> errors(n_threads);
+    for (int t = 0; t < n_threads; ++t) {
+      const int lo = (int)((long long)b.n * t / n_threads), hi = (int)((long long)b.n * (t + 1) / n_threads);
+      pool.emplace_back([&, t, lo, hi] {
+        try {
+          flatten_rows(lo, hi, &depths[t]);
+        } catch (...) {
+          errors[t] = std::current_exception();
+        }
+      });
+    }
+    for (std::thread& th : pool) th.join();
+    for (const std::exception_ptr& e : errors)
+      if (e) std::rethrow_exception(e);  // the first failing row range, in file order
+    for (int d : depths) b.max_depth = std::max(b.max_depth, d);
   }
   return b;
 }
