@@ -189,7 +189,9 @@ def main():
         # 32 FMA + 4 mul, the five-state close at the root 5 * (4 mul + 4 FMA).
         kinds = np.bincount((flat["ops"].reshape(-1, 4)[:, 0] & 15).astype(np.int64), minlength=3)[:3]
         flop_per_site_rate = (4 * kinds[0] + 36 * kinds[1] + 68 * kinds[2]) / float(flat["ops"].shape[0]) + 60
-        k1_flops = flop_per_site_rate * sizes["n_sites"] * R * n
+        n_pat, n_ucol = C.c_int32(), C.c_int32()
+        lib.check(lib.lib.lh_family_info(C.c_void_p(fam_handle), C.byref(n_pat), C.byref(n_ucol)))
+        k1_flops = flop_per_site_rate * n_pat.value * R * n   # executed: identical columns are pruned once
         k1_tflops = k1_flops / (prune_ms * 1e-3) / 1e12
         out = {
             "metric": "phylo-HMM log-likelihood evals/sec (100-leaf x 400-site family)",
@@ -199,7 +201,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: synthetic 100-leaf random tree, 400-site MSA, full "
                                    "V/D/J germline set (200 V / 30 D / 12 J alleles), R=4 rate categories",
                        "preset": args.preset, "tree_samples_per_gpu_per_step": n, "n_tips": T,
-                       "n_sites": sizes["n_sites"], "xmsa_columns": Cx, "S_vd": sizes["s_vd"],
+                       "n_sites": sizes["n_sites"], "xmsa_columns": Cx, "site_patterns": n_pat.value,
+                       "distinct_xmsa_columns": n_ucol.value, "S_vd": sizes["s_vd"],
                        "S_dj": sizes["s_dj"], "W_vd": sizes["w_vd"], "W_dj": sizes["w_dj"],
                        "G": sizes["g_total"], "sharding": "tree samples over ranks; one RCCL gather of log-likelihoods"},
             "roofline": {"bound": "hbm", "kernel": "prune_kernel (K1, Felsenstein pruning)",

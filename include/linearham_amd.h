@@ -113,6 +113,12 @@ void lh_family_destroy(lh_family* fam);
 int64_t lh_forward_size(const lh_family* fam);
 int64_t lh_scaler_size(const lh_family* fam);
 
+/* What lh_family_create reduced the family to: the number of distinct alignment columns (site patterns;
+ * the pruning kernel evaluates each once) and of distinct (naive base, pattern) pairs among the xMSA
+ * columns (the emission kernels evaluate each once).  Either pointer may be NULL.  Results are per
+ * xMSA column / per site all the same. */
+int lh_family_info(const lh_family* fam, int32_t* n_patterns, int32_t* n_unique_columns);
+
 /* Tree in rooted-at-naive form: tips are nodes 0..T-1 (0 = `naive`, i = MSA row i-1), inner nodes
  * T..2T-3.  children[2*(v-T)+{0,1}] are the two children of inner node v when the tree is rooted at
  * `root`, the inner node adjacent to `naive`.  Writes the kernel's post-order schedule:

@@ -41,7 +41,7 @@ class _EvalOutputs(C.Structure):
 
 
 EXPORTS = ["lh_last_error", "lh_device_count", "lh_family_create", "lh_family_destroy",
-           "lh_forward_size", "lh_scaler_size", "lh_schedule_tree", "lh_eval_batch",
+           "lh_forward_size", "lh_scaler_size", "lh_family_info", "lh_schedule_tree", "lh_eval_batch",
            "lh_eval_batch_device", "lh_forward_batch", "lh_profile_enable", "lh_profile_read"]
 
 
@@ -65,6 +65,8 @@ class HipLibrary:
         lib.lh_forward_size.restype = C.c_int64
         lib.lh_scaler_size.argtypes = [C.c_void_p]
         lib.lh_scaler_size.restype = C.c_int64
+        lib.lh_family_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.lh_family_info.restype = C.c_int
         lib.lh_schedule_tree.argtypes = [C.c_int32, c_i32p, C.c_int32, c_i32p, c_i32p]
         lib.lh_eval_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f64p, c_f64p,
                                       c_f64p, c_f64p, C.c_int32, c_f64p, C.POINTER(_EvalOutputs)]

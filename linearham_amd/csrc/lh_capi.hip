@@ -1,6 +1,7 @@
 // C ABI of liblinearham_hip.so (see include/linearham_amd.h): family upload, tree scheduling,
 // batched evaluation.  Host-side code only; the kernels live in lh_model/lh_prune/lh_forward.hip.
 #include <algorithm>
+#include <map>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -97,7 +98,10 @@ int upload(lh_family* f, const T* src, size_t count, const T** dst) {
   return 0;
 }
 
-int upload_segments(lh_family* f, const lh_segments& s, int n_xmsa, lh::DevSegments* d) {
+// `ucol` translates the caller's xMSA column indices into u-columns (lh_device.h); the sentinel column
+// whose emission is 1.0 sits at position n_ucol.
+int upload_segments(lh_family* f, const lh_segments& s, int n_xmsa, const std::vector<int32_t>& ucol, int n_ucol,
+                    lh::DevSegments* d) {
   if (s.n_genes < 0) return fail("segments: negative gene count");
   d->n_genes = s.n_genes;
   if (s.n_genes > 0) {
@@ -111,13 +115,13 @@ int upload_segments(lh_family* f, const lh_segments& s, int n_xmsa, lh::DevSegme
     int longest = 0;
     for (int g = 0; g < s.n_genes; ++g) longest = std::max(longest, s.offsets[g + 1] - s.offsets[g]);
     d->n_chunks = (longest + 7) / 8;
-    if (n_xmsa > 0xfffe) return fail("segments: more than 65534 xMSA columns");
-    // [chunk][gene][8] 16-bit indices, sentinel = column C (em = 1)
-    std::vector<uint16_t> t((size_t)d->n_chunks * s.n_genes * 8, (uint16_t)n_xmsa);
+    if (n_ucol > 0xfffe) return fail("segments: more than 65534 distinct xMSA columns");
+    // [chunk][gene][8] 16-bit indices, sentinel = column n_ucol (em = 1)
+    std::vector<uint16_t> t((size_t)d->n_chunks * s.n_genes * 8, (uint16_t)n_ucol);
     for (int g = 0; g < s.n_genes; ++g)
       for (int j = s.offsets[g]; j < s.offsets[g + 1]; ++j) {
         const int k = j - s.offsets[g];
-        t[((size_t)(k / 8) * s.n_genes + g) * 8 + (k % 8)] = (uint16_t)s.xmsa_inds[j];
+        t[((size_t)(k / 8) * s.n_genes + g) * 8 + (k % 8)] = (uint16_t)ucol[s.xmsa_inds[j]];
       }
     const uint16_t* dev = nullptr;
     if (upload(f, t.data(), t.size(), &dev)) return 1;
@@ -222,7 +226,7 @@ int ensure_workspace(lh_family* f, int n, int R, int T) {
     *b = nullptr;
   }
   w.n_cap = 0;
-  const size_t L = f->host.n_sites, C = f->host.n_xmsa;
+  const size_t L = f->host.n_pat;
   const int cap = std::max(n, 1);
   LH_HIP(hipMalloc((void**)&w.rates, sizeof(double) * cap * R));
   LH_HIP(hipMalloc((void**)&w.eig, sizeof(double) * cap * 36));
@@ -311,43 +315,67 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
   h.n_xmsa = desc->n_xmsa;
   int rc = 0;
   const size_t C = desc->n_xmsa;
+  std::vector<int32_t> ucol(C);  // caller's column -> u-column
   if (desc->n_seqs > 0) {
-    for (size_t i = 0; i < (size_t)desc->n_seqs * desc->n_sites && !rc; ++i)
+    if (!desc->msa || !desc->xmsa_site || !desc->xmsa_naive_base) rc = fail("lh_family_create: null array in descriptor");
+    const size_t N = desc->n_seqs, L = desc->n_sites;
+    for (size_t i = 0; i < N * L && !rc; ++i)
       if (desc->msa[i] > 4) rc = fail("lh_family_create: msa value out of range");
     for (size_t c = 0; c < C && !rc; ++c)
       if (desc->xmsa_site[c] < 0 || desc->xmsa_site[c] >= desc->n_sites || desc->xmsa_naive_base[c] > 4)
         rc = fail("lh_family_create: xMSA column descriptor out of range");
-    rc = rc || upload(f, desc->msa, (size_t)desc->n_seqs * desc->n_sites, &h.msa);
     if (!rc) {
-      // K2a walks the columns sorted by (naive base, site) so that neighbouring lanes read neighbouring
-      // entries of K1's site_lik[rate][base][site] planes.
-      std::vector<int32_t> order(C), site(C);
-      std::vector<uint8_t> base(C);
-      for (size_t c = 0; c < C; ++c) order[c] = (int32_t)c;
-      std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        if (desc->xmsa_naive_base[a] != desc->xmsa_naive_base[b])
-          return desc->xmsa_naive_base[a] < desc->xmsa_naive_base[b];
-        if (desc->xmsa_site[a] != desc->xmsa_site[b]) return desc->xmsa_site[a] < desc->xmsa_site[b];
-        return a < b;
-      });
-      for (size_t t = 0; t < C; ++t) {
-        site[t] = desc->xmsa_site[order[t]];
-        base[t] = desc->xmsa_naive_base[order[t]];
+      // site patterns: identical alignment columns are pruned once (first-appearance order)
+      std::map<std::string, int32_t> seen;
+      std::vector<int32_t> pat_of_site(L);
+      std::vector<size_t> first_site;
+      std::string key(N, '\0');
+      for (size_t j = 0; j < L; ++j) {
+        for (size_t i = 0; i < N; ++i) key[i] = (char)desc->msa[i * L + j];
+        auto it = seen.emplace(key, (int32_t)first_site.size());
+        if (it.second) first_site.push_back(j);
+        pat_of_site[j] = it.first->second;
       }
-      rc = rc || upload(f, order.data(), C, &h.xmsa_col);
-      rc = rc || upload(f, site.data(), C, &h.xmsa_site);
-      rc = rc || upload(f, base.data(), C, &h.xmsa_naive_base);
+      const size_t NP = first_site.size();
+      h.n_pat = (int32_t)NP;
+      std::vector<uint8_t> pmsa(N * NP);
+      for (size_t i = 0; i < N; ++i)
+        for (size_t p = 0; p < NP; ++p) pmsa[i * NP + p] = desc->msa[i * L + first_site[p]];
+      // u-columns: distinct (naive base, pattern) pairs, sorted by base then pattern
+      std::map<std::pair<int, int32_t>, int32_t> pairs;
+      for (size_t c = 0; c < C; ++c) pairs.emplace(std::make_pair((int)desc->xmsa_naive_base[c], pat_of_site[desc->xmsa_site[c]]), 0);
+      std::vector<int32_t> u_pat, col_of_ucol(pairs.size(), -1);
+      std::vector<uint8_t> u_base;
+      for (auto& kv : pairs) {
+        kv.second = (int32_t)u_pat.size();
+        u_base.push_back((uint8_t)kv.first.first);
+        u_pat.push_back(kv.first.second);
+      }
+      for (size_t c = 0; c < C; ++c) {
+        ucol[c] = pairs[std::make_pair((int)desc->xmsa_naive_base[c], pat_of_site[desc->xmsa_site[c]])];
+        if (col_of_ucol[ucol[c]] < 0) col_of_ucol[ucol[c]] = (int32_t)c;
+      }
+      h.n_ucol = (int32_t)u_pat.size();
+      rc = rc || upload(f, pmsa.data(), pmsa.size(), &h.msa);
+      rc = rc || upload(f, u_pat.data(), u_pat.size(), &h.u_pat);
+      rc = rc || upload(f, u_base.data(), u_base.size(), &h.u_base);
+      rc = rc || upload(f, ucol.data(), C, &h.ucol_of_col);
+      rc = rc || upload(f, col_of_ucol.data(), col_of_ucol.size(), &h.col_of_ucol);
     }
   } else {
-    rc = rc || upload<int32_t>(f, nullptr, 0, &h.xmsa_col);
+    for (size_t c = 0; c < C; ++c) ucol[c] = (int32_t)c;
+    h.n_pat = 0;
+    h.n_ucol = (int32_t)C;
     rc = rc || upload<uint8_t>(f, nullptr, 0, &h.msa);
-    rc = rc || upload<int32_t>(f, nullptr, 0, &h.xmsa_site);
-    rc = rc || upload<uint8_t>(f, nullptr, 0, &h.xmsa_naive_base);
+    rc = rc || upload<int32_t>(f, nullptr, 0, &h.u_pat);
+    rc = rc || upload<uint8_t>(f, nullptr, 0, &h.u_base);
+    rc = rc || upload(f, ucol.data(), C, &h.ucol_of_col);
+    rc = rc || upload(f, ucol.data(), C, &h.col_of_ucol);
   }
-  rc = rc || upload_segments(f, desc->vpadding, desc->n_xmsa, &h.vpadding);
-  rc = rc || upload_segments(f, desc->vgerm, desc->n_xmsa, &h.vgerm);
-  rc = rc || upload_segments(f, desc->jgerm, desc->n_xmsa, &h.jgerm);
-  rc = rc || upload_segments(f, desc->jpadding, desc->n_xmsa, &h.jpadding);
+  rc = rc || upload_segments(f, desc->vpadding, desc->n_xmsa, ucol, h.n_ucol, &h.vpadding);
+  rc = rc || upload_segments(f, desc->vgerm, desc->n_xmsa, ucol, h.n_ucol, &h.vgerm);
+  rc = rc || upload_segments(f, desc->jgerm, desc->n_xmsa, ucol, h.n_ucol, &h.jgerm);
+  rc = rc || upload_segments(f, desc->jpadding, desc->n_xmsa, ucol, h.n_ucol, &h.jpadding);
   const size_t nV = desc->vgerm.n_genes, nJ = desc->jgerm.n_genes;
   if (!rc && (desc->vpadding.n_genes != (int)nV || desc->jpadding.n_genes != (int)nJ))
     rc = fail("lh_family_create: padding/germline gene counts differ");
@@ -355,33 +383,34 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
   rc = rc || upload(f, desc->vpadding_transition, nV, &h.vpadding_transition);
   rc = rc || upload(f, desc->vgerm_trans_prod, nV, &h.vgerm_trans_prod);
   rc = rc || upload(f, desc->jpadding_transition, nJ, &h.jpadding_transition);
-  std::vector<int32_t> remap(desc->n_xmsa, 0);  // first "used" flags, then compact positions
+  std::vector<int32_t> remap(desc->n_xmsa, 0);  // first "used" flags, then positions in the compact junction list
   rc = rc || collect_junction_cols(desc->vd, desc->n_xmsa, &remap);
   if (h.has_d) rc = rc || collect_junction_cols(desc->dj, desc->n_xmsa, &remap);
   if (!rc) {
-    std::vector<int32_t> jcols;
-    for (int c = 0; c < desc->n_xmsa; ++c) {
-      if (remap[c]) {
-        remap[c] = (int32_t)jcols.size();
-        jcols.push_back(c);
-      } else {
-        remap[c] = -1;
+    std::vector<int32_t> jpos(h.n_ucol, -1), jcols;  // junction list = the u-columns the junction rows touch
+    std::vector<char> used_u(h.n_ucol, 0);
+    for (int c = 0; c < desc->n_xmsa; ++c)
+      if (remap[c]) used_u[ucol[c]] = 1;
+    for (int u = 0; u < h.n_ucol; ++u)
+      if (used_u[u]) {
+        jpos[u] = (int32_t)jcols.size();
+        jcols.push_back(u);
       }
-    }
+    for (int c = 0; c < desc->n_xmsa; ++c) remap[c] = remap[c] ? jpos[ucol[c]] : -1;
     h.n_jcols = (int32_t)jcols.size();
     rc = upload(f, jcols.data(), jcols.size(), &h.jcols);
   }
   rc = rc || upload_junction(f, desc->vd, remap, h.n_jcols, &h.vd);
   if (!rc && desc->vd.n_left != (int)nV) rc = fail("lh_family_create: vd.n_left != number of V genes");
   if (h.has_d) {
-    rc = rc || upload_segments(f, desc->dgerm, desc->n_xmsa, &h.dgerm);
+    rc = rc || upload_segments(f, desc->dgerm, desc->n_xmsa, ucol, h.n_ucol, &h.dgerm);
     rc = rc || upload_junction(f, desc->dj, remap, h.n_jcols, &h.dj);
     if (!rc && (desc->vd.n_right != desc->dgerm.n_genes || desc->dj.n_left != desc->dgerm.n_genes ||
                 desc->dj.n_right != (int)nJ))
       rc = fail("lh_family_create: junction gene counts do not match the germline regions");
   } else {
     lh_segments empty{0, nullptr, nullptr};
-    rc = rc || upload_segments(f, empty, desc->n_xmsa, &h.dgerm);
+    rc = rc || upload_segments(f, empty, desc->n_xmsa, ucol, h.n_ucol, &h.dgerm);
     memset(&h.dj, 0, sizeof(h.dj));
     if (!rc && desc->vd.n_right != (int)nJ) rc = fail("lh_family_create: vd.n_right != number of J genes");
   }
@@ -434,6 +463,13 @@ void lh_family_destroy(lh_family* f) {
 }
 
 int64_t lh_forward_size(const lh_family* f) { return f ? f->host.forward_size : 0; }
+
+int lh_family_info(const lh_family* f, int32_t* n_patterns, int32_t* n_unique_columns) {
+  if (!f) return fail("lh_family_info: null family");
+  if (n_patterns) *n_patterns = f->host.n_pat;
+  if (n_unique_columns) *n_unique_columns = f->host.n_ucol;
+  return 0;
+}
 int64_t lh_scaler_size(const lh_family* f) { return f ? f->host.scaler_size : 0; }
 
 int lh_schedule_tree(int32_t T, const int32_t* children, int32_t root, int32_t* ops, int32_t* max_depth) {

@@ -44,19 +44,28 @@ struct DevJunction {
   const double *exit_trans, *exit_gp_li;  // [right_pad]
 };
 
+// Two reductions happen once per family, on the host (lh_family_create):
+//  * identical alignment columns (site patterns) are pruned once: K1 runs over the n_pat distinct
+//    columns of the MSA, msa is stored pattern-major;
+//  * xMSA columns that pair the same naive base with the same pattern have the same emission: K2 works
+//    on the n_ucol distinct (naive base, pattern) pairs ("u-columns", sorted by base then pattern so that
+//    neighbouring lanes read neighbouring entries of K1's output planes); every index table below is in
+//    u-column space.  Families without an alignment (n_seqs == 0) keep their columns one to one.
 struct DevFamily {
-  int32_t has_d, n_seqs, n_sites, n_xmsa;
-  const uint8_t* msa;
-  // xMSA columns in (naive base, site) order: position t describes column xmsa_col[t]
-  const int32_t* xmsa_col;
-  const int32_t* xmsa_site;
-  const uint8_t* xmsa_naive_base;
+  int32_t has_d, n_seqs, n_sites, n_xmsa;  // as described by the caller
+  int32_t n_pat;                           // distinct alignment columns (K1's site dimension)
+  int32_t n_ucol;                          // distinct (naive base, pattern) pairs (K2's column dimension)
+  const uint8_t* msa;                      // [n_seqs][n_pat]
+  const int32_t* u_pat;                    // [n_ucol] pattern of u-column u
+  const uint8_t* u_base;                   // [n_ucol] its naive base (4 = N)
+  const int32_t* ucol_of_col;              // [n_xmsa] u-column of the caller's column c
+  const int32_t* col_of_ucol;              // [n_ucol] one caller column per u-column
   DevSegments vpadding, vgerm, dgerm, jgerm, jpadding;
   const double *vgerm_gene_prob, *vpadding_transition, *vgerm_trans_prod, *jpadding_transition;
   DevJunction vd, dj;
   int32_t max_genes;      // max over regions of the gene count
-  int32_t n_jcols;        // distinct xMSA columns referenced by the junction tables
-  const int32_t* jcols;   // [n_jcols] their xMSA indices, ascending
+  int32_t n_jcols;        // distinct u-columns referenced by the junction tables
+  const int32_t* jcols;   // [n_jcols] their u-column indices, ascending
   int64_t gem_size;       // doubles per sample of germline/padding emission products (2nV + nD + 2nJ)
   int64_t forward_size;   // doubles per sample in the compact forward output
   int64_t scaler_size;    // ints per sample in the scaler-count output
@@ -91,7 +100,7 @@ void launch_model_setup(int n, int R, const double* er, const double* pi, const 
 // inner-branch matrices in schedule order into the scratch area pmat[n][R][T-2][2][16] (op k: [0] =
 // matrix of the child whose CLV is in the accumulator, [1] = matrix of the popped child), tip-branch
 // matrices into its LDS tip table.
-// site_lik[n][R][5][L], site_scal[n][R][L]
+// site_lik[n][R][5][n_pat], site_scal[n][R][n_pat]
 void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
                   const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
                   double* site_lik, int32_t* site_scal, hipStream_t stream);

@@ -140,24 +140,23 @@ __global__ void __launch_bounds__(kFwdThreads)
   extern __shared__ double em[];  // [C + 1] emissions (em[C] = 1.0 sentinel) | reduction scratch
   const size_t s = blockIdx.x;
   const int tid = threadIdx.x;
-  const int C = fam.n_xmsa;
+  const int C = fam.n_ucol;  // u-columns (lh_device.h); the caller's columns only appear in em_in / em_out
   int* redi = reinterpret_cast<int*>(em + ((C + 2) & ~1));  // 2 * kFwdWaves ints
 
   if constexpr (kFromSiteLik) {
     // PhyloHMM::FillXmsaEmission tail: mix the rate categories (equal weights, scalers aligned to the
-    // smallest one) and apply the naive correction.  Columns are visited in (naive base, site) order.
-    const int L = fam.n_sites;
+    // smallest one) and apply the naive correction, once per distinct (naive base, pattern) pair.
+    const int NP = fam.n_pat;
     const double w = 1.0 / R;
-    for (int t = tid; t < C; t += kFwdThreads) {
-      const int c = fam.xmsa_col[t];
-      const int site = fam.xmsa_site[t];
-      const int b = fam.xmsa_naive_base[t];
+    for (int u = tid; u < C; u += kFwdThreads) {
+      const int pat = fam.u_pat[u];
+      const int b = fam.u_base[u];
       int smin = 0x7fffffff;
-      for (int r = 0; r < R; ++r) smin = min(smin, site_scal[(s * R + r) * L + site]);
+      for (int r = 0; r < R; ++r) smin = min(smin, site_scal[(s * R + r) * NP + pat]);
       double acc = 0.0;
       for (int r = 0; r < R; ++r) {
-        double v = site_lik[((s * R + r) * 5 + b) * (size_t)L + site];
-        const int d = site_scal[(s * R + r) * L + site] - smin;
+        double v = site_lik[((s * R + r) * 5 + b) * (size_t)NP + pat];
+        const int d = site_scal[(s * R + r) * NP + pat] - smin;
         for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
         acc += w * v;
       }
@@ -167,14 +166,17 @@ __global__ void __launch_bounds__(kFwdThreads)
       double e = acc;
       if (b != 4) e /= pi[s * 4 + b];
       for (int q = 0; q < smin && e != 0.0; ++q) e *= kScaleThreshold;
-      em[c] = e;
-      if (em_out) em_out[s * C + c] = e;
+      em[u] = e;
     }
   } else {
-    for (int c = tid; c < C; c += kFwdThreads) em[c] = em_in[s * C + c];
+    for (int u = tid; u < C; u += kFwdThreads) em[u] = em_in[s * fam.n_xmsa + fam.col_of_ucol[u]];
   }
   if (tid == 0) em[C] = 1.0;
   __syncthreads();
+  if (em_out) {  // the caller's view: one value per xMSA column
+    const int CX = fam.n_xmsa;
+    for (int c = tid; c < CX; c += kFwdThreads) em_out[s * CX + c] = em[fam.ucol_of_col[c]];
+  }
 
   // emissions of the columns the junction rows touch, compacted for K2b
   {
@@ -603,7 +605,7 @@ static size_t junction_lds_bytes(const DevFamily& fam) {
 }
 
 static size_t emission_lds_bytes(const DevFamily& fam) {
-  return (((size_t)fam.n_xmsa + 2) & ~(size_t)1) * sizeof(double) + 2 * kFwdWaves * sizeof(int);
+  return (((size_t)fam.n_ucol + 2) & ~(size_t)1) * sizeof(double) + 2 * kFwdWaves * sizeof(int);
 }
 
 size_t forward_lds_bytes(const DevFamily& fam) {

@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(512) prune_kernel_deep(LH_PRUNE_PARAMS) {
 void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
                   const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
                   double* site_lik, int32_t* site_scal, hipStream_t stream) {
-  const int L = fam.n_sites;
+  const int L = fam.n_pat;  // distinct alignment columns; identical ones are pruned once
   const bool two = max_depth <= 4;
   // tile: up to 1024 sites as two-site waves plus at most one one-site wave for a remainder below 64
   // (deep variant: up to 8 one-site waves = 512 sites); tiles rebalanced so that they are equally full.
