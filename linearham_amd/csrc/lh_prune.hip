@@ -128,35 +128,34 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
         }
       }
     }
+    // Every op ends in the same element-wise product a = u * v: (tip column, tip column) for a cherry,
+    // (tip column, P_b a) for a tip joining the accumulator, (P_a sibling, P_b a) for a pop.  Keeping that
+    // product common to the three branches lets them leave their factors wherever the loads / FMAs
+    // produced them (with a per-branch product the compiler moved the whole CLV at the join).
+    double u[S][4], v[S][4];
     if (kind == OP_CHERRY) {
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         const double2* ta = reinterpret_cast<const double2*>(tiptab + op.y * 20 + sa[s] * 4);
         const double2* tb = reinterpret_cast<const double2*>(tiptab + op.z * 20 + sb[s] * 4);
         const double2 ta0 = ta[0], ta1 = ta[1], tb0 = tb[0], tb1 = tb[1];
-        a[s][0] = ta0.x * tb0.x;
-        a[s][1] = ta0.y * tb0.y;
-        a[s][2] = ta1.x * tb1.x;
-        a[s][3] = ta1.y * tb1.y;
+        u[s][0] = ta0.x, u[s][1] = ta0.y, u[s][2] = ta1.x, u[s][3] = ta1.y;
+        v[s][0] = tb0.x, v[s][1] = tb0.y, v[s][2] = tb1.x, v[s][3] = tb1.y;
       }
     } else {
       const double* __restrict__ pb = pm + (size_t)k * 32;
-      double x[S][4];
 #pragma unroll
-      for (int s = 0; s < S; ++s) matvec(pb, a[s], x[s]);
+      for (int s = 0; s < S; ++s) matvec(pb, a[s], v[s]);
       if (kind == OP_TIP_ACC) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           const double2* ta = reinterpret_cast<const double2*>(tiptab + op.y * 20 + sa[s] * 4);
           const double2 ta0 = ta[0], ta1 = ta[1];
-          a[s][0] = ta0.x * x[s][0];
-          a[s][1] = ta0.y * x[s][1];
-          a[s][2] = ta1.x * x[s][2];
-          a[s][3] = ta1.y * x[s][3];
+          u[s][0] = ta0.x, u[s][1] = ta0.y, u[s][2] = ta1.x, u[s][3] = ta1.y;
         }
       } else {  // OP_POP_ACC
         const double* __restrict__ pa = pm + (size_t)k * 32 + 16;
-        double z[S][4];
+        double(&z)[S][4] = u;
         if (op.w == 0) {
           LH_POP_SLOT(0)
         } else if (op.w == 1) {
@@ -178,14 +177,14 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
 #pragma unroll
           for (int s = 0; s < S; ++s) matvec(pa, y[s], z[s]);
         }
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-          a[s][0] = z[s][0] * x[s][0];
-          a[s][1] = z[s][1] * x[s][1];
-          a[s][2] = z[s][2] * x[s][2];
-          a[s][3] = z[s][3] * x[s][3];
-        }
       }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      a[s][0] = u[s][0] * v[s][0];
+      a[s][1] = u[s][1] * v[s][1];
+      a[s][2] = u[s][2] * v[s][2];
+      a[s][3] = u[s][3] * v[s][3];
     }
     op = op_next;
     {
