@@ -226,7 +226,7 @@ int ensure_workspace(lh_family* f, int n, int R, int T) {
     *b = nullptr;
   }
   w.n_cap = 0;
-  const size_t L = f->host.n_pat;
+  const size_t L = f->host.n_prune;
   const int cap = std::max(n, 1);
   LH_HIP(hipMalloc((void**)&w.rates, sizeof(double) * cap * R));
   LH_HIP(hipMalloc((void**)&w.eig, sizeof(double) * cap * 36));
@@ -336,11 +336,36 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
         if (it.second) first_site.push_back(j);
         pat_of_site[j] = it.first->second;
       }
+      // Order: patterns without an N, then patterns with some N, then (at most one) the all-N pattern.
+      // The all-N column -- alignment padding -- has likelihood pi_b for naive base b whatever the tree,
+      // i.e. emission 1 (sum of pi for naive base N): K1 never sees it (its site dimension is n_prune),
+      // K2a writes the constant.
+      // If no pattern mixes N with bases, K1 runs the instantiation without N handling.
       const size_t NP = first_site.size();
+      std::vector<int> cls(NP, 0);  // 0 clean, 1 mixed, 2 all-N
+      for (size_t p = 0; p < NP; ++p) {
+        size_t n_n = 0;
+        for (size_t i = 0; i < N; ++i) n_n += desc->msa[i * L + first_site[p]] == 4;
+        cls[p] = n_n == 0 ? 0 : n_n == N ? 2 : 1;
+      }
+      std::vector<int32_t> order(NP), new_id(NP);
+      for (size_t p = 0; p < NP; ++p) order[p] = (int32_t)p;
+      std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cls[a] < cls[b]; });
+      for (size_t q = 0; q < NP; ++q) new_id[order[q]] = (int32_t)q;
+      for (size_t j = 0; j < L; ++j) pat_of_site[j] = new_id[pat_of_site[j]];
+      {
+        std::vector<size_t> fs(NP);
+        for (size_t q = 0; q < NP; ++q) fs[q] = first_site[order[q]];
+        first_site.swap(fs);
+      }
+      const bool has_all_n = NP > 0 && cls[order[NP - 1]] == 2;
       h.n_pat = (int32_t)NP;
-      std::vector<uint8_t> pmsa(N * NP);
+      h.n_prune = (int32_t)(NP - (has_all_n ? 1 : 0));
+      h.msa_mixed_n = 0;
+      for (int c : cls) h.msa_mixed_n |= c == 1;
+      std::vector<uint8_t> pmsa(N * std::max<size_t>(h.n_prune, 1));
       for (size_t i = 0; i < N; ++i)
-        for (size_t p = 0; p < NP; ++p) pmsa[i * NP + p] = desc->msa[i * L + first_site[p]];
+        for (size_t p = 0; p < (size_t)h.n_prune; ++p) pmsa[i * h.n_prune + p] = desc->msa[i * L + first_site[p]];
       // u-columns: distinct (naive base, pattern) pairs, sorted by base then pattern
       std::map<std::pair<int, int32_t>, int32_t> pairs;
       for (size_t c = 0; c < C; ++c) pairs.emplace(std::make_pair((int)desc->xmsa_naive_base[c], pat_of_site[desc->xmsa_site[c]]), 0);
@@ -365,6 +390,8 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
   } else {
     for (size_t c = 0; c < C; ++c) ucol[c] = (int32_t)c;
     h.n_pat = 0;
+    h.n_prune = 0;
+    h.msa_mixed_n = 0;
     h.n_ucol = (int32_t)C;
     rc = rc || upload<uint8_t>(f, nullptr, 0, &h.msa);
     rc = rc || upload<int32_t>(f, nullptr, 0, &h.u_pat);
@@ -466,7 +493,7 @@ int64_t lh_forward_size(const lh_family* f) { return f ? f->host.forward_size : 
 
 int lh_family_info(const lh_family* f, int32_t* n_patterns, int32_t* n_unique_columns) {
   if (!f) return fail("lh_family_info: null family");
-  if (n_patterns) *n_patterns = f->host.n_pat;
+  if (n_patterns) *n_patterns = f->host.n_prune;  // the all-N padding pattern, if any, costs nothing
   if (n_unique_columns) *n_unique_columns = f->host.n_ucol;
   return 0;
 }
@@ -621,7 +648,7 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
   if (T < 3) return fail("lh_eval_batch: need at least 3 tips");
   if (R < 1 || R > 64) return fail("lh_eval_batch: num_rates out of range");
   if (max_depth < 0 || max_depth > 16) return fail("lh_eval_batch: max_depth out of range");
-  if ((size_t)T * 160 > 160 * 1024) return fail("lh_eval_batch: too many tips for the LDS tip table");
+  if ((size_t)T * 128 > 160 * 1024) return fail("lh_eval_batch: too many tips for the LDS tip table");
   if (!ops || !brlen || !er || !pi || !alpha || !loglik) return fail("lh_eval_batch: null array");
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const int chunk = std::min<int>(n, kChunk);

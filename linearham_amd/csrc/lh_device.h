@@ -53,9 +53,12 @@ struct DevJunction {
 //    u-column space.  Families without an alignment (n_seqs == 0) keep their columns one to one.
 struct DevFamily {
   int32_t has_d, n_seqs, n_sites, n_xmsa;  // as described by the caller
-  int32_t n_pat;                           // distinct alignment columns (K1's site dimension)
+  int32_t n_pat;                           // distinct alignment columns
+  int32_t n_prune;                         // K1's site dimension: n_pat minus the all-N pattern, which
+                                           // comes last and whose emission is 1 whatever the tree
+  int32_t msa_mixed_n;                     // 1 if some pattern mixes N with bases (K1 then handles N tips)
   int32_t n_ucol;                          // distinct (naive base, pattern) pairs (K2's column dimension)
-  const uint8_t* msa;                      // [n_seqs][n_pat]
+  const uint8_t* msa;                      // [n_seqs][n_prune]
   const int32_t* u_pat;                    // [n_ucol] pattern of u-column u
   const uint8_t* u_base;                   // [n_ucol] its naive base (4 = N)
   const int32_t* ucol_of_col;              // [n_xmsa] u-column of the caller's column c
@@ -100,7 +103,7 @@ void launch_model_setup(int n, int R, const double* er, const double* pi, const 
 // inner-branch matrices in schedule order into the scratch area pmat[n][R][T-2][2][16] (op k: [0] =
 // matrix of the child whose CLV is in the accumulator, [1] = matrix of the popped child), tip-branch
 // matrices into its LDS tip table.
-// site_lik[n][R][5][n_pat], site_scal[n][R][n_pat]
+// site_lik[n][R][5][n_prune], site_scal[n][R][n_prune]
 void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
                   const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
                   double* site_lik, int32_t* site_scal, hipStream_t stream);

@@ -146,11 +146,17 @@ __global__ void __launch_bounds__(kFwdThreads)
   if constexpr (kFromSiteLik) {
     // PhyloHMM::FillXmsaEmission tail: mix the rate categories (equal weights, scalers aligned to the
     // smallest one) and apply the naive correction, once per distinct (naive base, pattern) pair.
-    const int NP = fam.n_pat;
+    const int NP = fam.n_prune;
     const double w = 1.0 / R;
     for (int u = tid; u < C; u += kFwdThreads) {
       const int pat = fam.u_pat[u];
       const int b = fam.u_base[u];
+      if (pat >= NP) {  // the all-N padding pattern: likelihood pi_b, emission 1 -- and for the naive
+                        // base N the sum of the sample's pi, which is 1 only as far as its digits go
+        const double* q = pi + s * 4;
+        em[u] = b == 4 ? ((q[0] + q[1]) + q[2]) + q[3] : 1.0;
+        continue;
+      }
       int smin = 0x7fffffff;
       for (int r = 0; r < R; ++r) smin = min(smin, site_scal[(s * R + r) * NP + pat]);
       double acc = 0.0;

@@ -22,7 +22,7 @@
 //    independent dependency chains.  A tile's last few sites (fewer than 64) ride in a one-site wave, so
 //    no wave executes for empty lanes.
 //  * Tip children need no mat-vec: P * onehot(state) is a column of P.  Those columns (plus the
-//    row sums for N) are staged once per workgroup in LDS as tiptab[tip][state][4] and gathered
+//    row sums for N, formed on demand) live in LDS as tiptab[tip][state][4] and are gathered
 //    with two ds_read_b128 per lane and site.
 //  * The workgroup first computes its (sample, rate)'s P-matrices itself (no separate kernel, no HBM
 //    round trip): inner-branch matrices in schedule order into a global scratch area that its own
@@ -75,9 +75,27 @@ __device__ __forceinline__ void matvec(const double* __restrict__ p, const doubl
   x[3] = fma(p[15], a[3], fma(p[14], a[2], fma(p[13], a[1], p[12] * a[0])));
 }
 
+// Column `st` of a tip branch's P (= P * onehot(st)) from the LDS table tiptab[tip][4][4]; a tip whose
+// state is N (4) contributes the row sums of P, formed on the spot from the four columns -- only in the
+// kN instantiation, which families whose alignment mixes N with bases run (the table has no fifth row:
+// 128 instead of 160 bytes per tip is what lets a CU hold ten workgroups of configs[2] instead of nine).
+template <bool kN>
+__device__ __forceinline__ void tip_column(const double* tiptab, int tip, int st, double (&c)[4]) {
+  const double* t = tiptab + tip * 16;
+  const double2* q = reinterpret_cast<const double2*>(t + (kN ? (st & 3) : st) * 4);
+  const double2 q0 = q[0], q1 = q[1];
+  c[0] = q0.x, c[1] = q0.y, c[2] = q1.x, c[3] = q1.y;
+  if constexpr (kN) {
+    if (st == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c[i] = ((t[i] + t[4 + i]) + t[8 + i]) + t[12 + i];
+    }
+  }
+}
+
 // The schedule walk of one wave: S sites per lane (site0 + 64*s), all lanes active (sites past the end
 // of the tile are clamped to a valid one and not written back).
-template <int kDepth, int S>
+template <int kDepth, int S, bool kN>
 __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_t* __restrict__ msa, int L,
                                            int n_ops, const int4* __restrict__ op_ptr,
                                            const double* __restrict__ pm, const double* tiptab,
@@ -136,11 +154,8 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
     if (kind == OP_CHERRY) {
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        const double2* ta = reinterpret_cast<const double2*>(tiptab + op.y * 20 + sa[s] * 4);
-        const double2* tb = reinterpret_cast<const double2*>(tiptab + op.z * 20 + sb[s] * 4);
-        const double2 ta0 = ta[0], ta1 = ta[1], tb0 = tb[0], tb1 = tb[1];
-        u[s][0] = ta0.x, u[s][1] = ta0.y, u[s][2] = ta1.x, u[s][3] = ta1.y;
-        v[s][0] = tb0.x, v[s][1] = tb0.y, v[s][2] = tb1.x, v[s][3] = tb1.y;
+        tip_column<kN>(tiptab, op.y, sa[s], u[s]);
+        tip_column<kN>(tiptab, op.z, sb[s], v[s]);
       }
     } else {
       const double* __restrict__ pb = pm + (size_t)k * 32;
@@ -149,9 +164,7 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
       if (kind == OP_TIP_ACC) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          const double2* ta = reinterpret_cast<const double2*>(tiptab + op.y * 20 + sa[s] * 4);
-          const double2 ta0 = ta[0], ta1 = ta[1];
-          u[s][0] = ta0.x, u[s][1] = ta0.y, u[s][2] = ta1.x, u[s][3] = ta1.y;
+          tip_column<kN>(tiptab, op.y, sa[s], u[s]);
         }
       } else {  // OP_POP_ACC
         const double* __restrict__ pa = pm + (size_t)k * 32 + 16;
@@ -223,7 +236,14 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
       const double w0 = p4[0] * a[s][0], w1 = p4[1] * a[s][1], w2 = p4[2] * a[s][2], w3 = p4[3] * a[s][3];
 #pragma unroll
       for (int b = 0; b < 5; ++b) {
-        const double* tv = tiptab + b * 4;  // tip 0 = naive
+        double tv[4];  // tip 0 = naive; its possible states are the five naive bases of the xMSA
+        if (b < 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tv[i] = tiptab[b * 4 + i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tv[i] = ((tiptab[i] + tiptab[4 + i]) + tiptab[8 + i]) + tiptab[12 + i];
+        }
         lik_out[(size_t)b * L + site] = fma(w3, tv[3], fma(w2, tv[2], fma(w1, tv[1], w0 * tv[0])));
       }
       scal_out[site] = scal[s];
@@ -241,7 +261,7 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
 
 // Block = n2 two-site waves followed by n1 one-site waves; the tile's sites are
 // blockIdx.x * tile .. +tile-1 (clipped to L).
-template <int kDepth, bool kTwo>
+template <int kDepth, bool kTwo, bool kN>
 __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __restrict__ msa, int L, int T, int n_ops,
                                            const int32_t* __restrict__ ops, const double* __restrict__ brlen,
                                            const double* __restrict__ rates, const double* __restrict__ eig,
@@ -249,7 +269,7 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
                                            const double* __restrict__ pi, double* __restrict__ site_lik,
                                            int32_t* __restrict__ site_scal) {
   extern __shared__ double2 smem2[];
-  double* tiptab = reinterpret_cast<double*>(smem2);  // [T][5][4]
+  double* tiptab = reinterpret_cast<double*>(smem2);  // [T][4][4]
 
   const int tid = threadIdx.x;
   const int R = gridDim.y;
@@ -265,8 +285,7 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
   // because the walk below wants them as SCALAR operands and scalar loads only read memory; the lines
   // are written and, a barrier later, read back on the same CU, so they are served by its L2.  The
   // second half takes the tip branches: a tip child needs no mat-vec, P * onehot(state) is a column of
-  // P, and those columns (plus the row sums for N) go straight into the LDS table
-  // tiptab[tip][state][4].
+  // P, and those columns go straight into the LDS table tiptab[tip][state][4] (states A,C,G,T).
   {
     const double* __restrict__ e = eig + (size_t)sample * 36;
     const double rt = rates[(size_t)sample * R + rate];
@@ -302,13 +321,11 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
       const int stride = half ? nthr - half : nthr;
       for (int j = half ? tid - half : tid; j < T; j += stride) {
         compute_pmatrix(e, bl[j] * rt, P);
-        double* o = tiptab + j * 20;
+        double* o = tiptab + j * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
-          o[16 + i] = ((P[i][0] + P[i][1]) + P[i][2]) + P[i][3];
-        }
       }
     }
   }
@@ -327,12 +344,12 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
   int32_t* scal_out = site_scal + ((size_t)sample * R + rate) * (size_t)L;
   if constexpr (kTwo) {
     if (wave < n2) {
-      prune_wave<kDepth, 2>(tile0 + wave * 128 + lane, site_end, msa, L, n_ops, op_ptr, pm, tiptab, p4, lik_out,
+      prune_wave<kDepth, 2, kN>(tile0 + wave * 128 + lane, site_end, msa, L, n_ops, op_ptr, pm, tiptab, p4, lik_out,
                             scal_out);
       return;
     }
   }
-  prune_wave<kDepth, 1>(tile0 + n2 * 128 + (wave - n2) * 64 + lane, site_end, msa, L, n_ops, op_ptr, pm, tiptab, p4,
+  prune_wave<kDepth, 1, kN>(tile0 + n2 * 128 + (wave - n2) * 64 + lane, site_end, msa, L, n_ops, op_ptr, pm, tiptab, p4,
                         lik_out, scal_out);
 }
 
@@ -350,21 +367,22 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
 // by the latency of its compulsory scalar-cache misses (every P-matrix line is new to the CU), so
 // resident waves matter more than a few spilled registers: 5 waves per SIMD (96 VGPRs, ~50 bytes of
 // scratch) measured 13 % faster than the 4 the unconstrained allocation (107 VGPRs) gives, 6 slower again.
-template <int kDepth>
+template <int kDepth, bool kN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) prune_kernel(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, true>(LH_PRUNE_ARGS);
+  prune_body<kDepth, true, kN>(LH_PRUNE_ARGS);
 }
 
 // Deep stacks leave no room for two sites per lane.
 template <int kDepth>
 __global__ void __launch_bounds__(512) prune_kernel_deep(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, false>(LH_PRUNE_ARGS);
+  prune_body<kDepth, false, true>(LH_PRUNE_ARGS);
 }
 
 void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
                   const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
                   double* site_lik, int32_t* site_scal, hipStream_t stream) {
-  const int L = fam.n_pat;  // distinct alignment columns; identical ones are pruned once
+  const int L = fam.n_prune;  // distinct alignment columns; identical ones are pruned once
+  if (L == 0) return;         // nothing but all-N padding
   const bool two = max_depth <= 4;
   // tile: up to 1024 sites as two-site waves plus at most one one-site wave for a remainder below 64
   // (deep variant: up to 8 one-site waves = 512 sites); tiles rebalanced so that they are equally full.
@@ -386,7 +404,7 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
   } else {
     n1 = (tile + 63) / 64;
   }
-  const size_t lds = (size_t)T * 20 * sizeof(double);
+  const size_t lds = (size_t)T * 16 * sizeof(double);
   dim3 grid(tiles, R, n), block(64 * (n2 + n1));
   const int n_ops = T - 2;
 #define LH_LAUNCH_K(K)                                                                                        \
@@ -397,10 +415,15 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
     hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, fam.msa, L, T, n_ops, ops, brlen, rates, eig,   \
                        pmat, (const double*)pmat, pi, site_lik, site_scal);                                   \
   }
-  if (max_depth <= 3)
-    LH_LAUNCH_K(prune_kernel<3>)
+  // alignments that never mix N with bases take the instantiation without N handling in the look-ups
+  if (max_depth <= 3 && !fam.msa_mixed_n)
+    LH_LAUNCH_K((prune_kernel<3, false>))
+  else if (max_depth <= 3)
+    LH_LAUNCH_K((prune_kernel<3, true>))
+  else if (max_depth <= 4 && !fam.msa_mixed_n)
+    LH_LAUNCH_K((prune_kernel<4, false>))
   else if (max_depth <= 4)
-    LH_LAUNCH_K(prune_kernel<4>)
+    LH_LAUNCH_K((prune_kernel<4, true>))
   else if (max_depth <= 8)
     LH_LAUNCH_K(prune_kernel_deep<8>)
   else
