@@ -212,17 +212,26 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
     // counter is valid for the whole tree because scalers are additive along the traversal.  CLV
     // entries are non-negative, so the largest has the largest high word; it is below 2^-256 exactly
     // when that word is below 0x2FF00000 (integer compares instead of 7 FP64 max/compare).
+    // (An all-zero CLV -- impossible data -- counts as small too: rescaling it changes nothing but its
+    // counter, and K2a aligns the rates' counters before it mixes them.)
+    unsigned hw[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const unsigned hw = max(max((unsigned)__double2hiint(a[s][0]), (unsigned)__double2hiint(a[s][1])),
-                              max((unsigned)__double2hiint(a[s][2]), (unsigned)__double2hiint(a[s][3])));
-      const bool tiny = hw < 0x2FF00000u && hw != 0u;
-      if (__builtin_expect(__ballot(tiny) != 0, 0) && tiny) {  // rare: skip the whole block wave-wide
-        a[s][0] *= kScaleFactor;
-        a[s][1] *= kScaleFactor;
-        a[s][2] *= kScaleFactor;
-        a[s][3] *= kScaleFactor;
-        ++scal[s];
+    for (int s = 0; s < S; ++s)
+      hw[s] = max(max((unsigned)__double2hiint(a[s][0]), (unsigned)__double2hiint(a[s][1])),
+                  max((unsigned)__double2hiint(a[s][2]), (unsigned)__double2hiint(a[s][3])));
+    unsigned hmin = hw[0];
+#pragma unroll
+    for (int s = 1; s < S; ++s) hmin = min(hmin, hw[s]);
+    if (__builtin_expect(__ballot(hmin < 0x2FF00000u) != 0, 0)) {  // rare: skipped wave-wide
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        if (hw[s] < 0x2FF00000u) {
+          a[s][0] *= kScaleFactor;
+          a[s][1] *= kScaleFactor;
+          a[s][2] *= kScaleFactor;
+          a[s][3] *= kScaleFactor;
+          ++scal[s];
+        }
       }
     }
   }
