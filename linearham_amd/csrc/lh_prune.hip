@@ -397,7 +397,9 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
   // (deep variant: up to 8 one-site waves = 512 sites); tiles rebalanced so that they are equally full.
   // Large tiles matter for large trees: every workgroup of a (sample, rate) repeats the P-matrix
   // prologue and holds its own T x 160-byte tip table in LDS.
-  const int cap = two ? 1024 : 512;
+  // (LH_K1_TILE_CAP: test hook that forces small tiles so that the multi-tile path runs on small families)
+  static const int cap_env = getenv("LH_K1_TILE_CAP") ? atoi(getenv("LH_K1_TILE_CAP")) : 0;
+  const int cap = cap_env >= 64 ? std::min(cap_env, two ? 1024 : 512) : two ? 1024 : 512;
   const int tiles = (L + cap - 1) / cap;
   const int tile = (L + tiles - 1) / tiles;
   int n2 = 0, n1;

@@ -227,6 +227,20 @@ def test_large_tree_family(hip, tmp_path):
     compare(h, desc, ll, res, ref)
 
 
+def test_several_site_tiles_per_sample(tmp_path):
+    """K1 with more site patterns than one workgroup takes (several tiles per (sample, rate), each
+    repeating the P-matrix prologue): forced on the 500-leaf family by the LH_K1_TILE_CAP test hook, which
+    the library reads once per process -- hence the subprocess."""
+    import subprocess
+    import sys
+    code = ("import pathlib, linearham_amd, tests.test_gpu_parity as t; "
+            "t.test_large_tree_family(linearham_amd.load_library(), pathlib.Path(%r))" % str(tmp_path))
+    env = dict(os.environ, LH_K1_TILE_CAP="192")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_gamma_rates_against_scipy(hip, data_dir):
     """K0a discrete-Gamma means over a grid of shapes (pll_compute_gamma_cats restatement)."""
     import linearham_amd
