@@ -16,7 +16,7 @@
 //    CLVs never leave the chip: the running CLV lives in VGPRs and pending siblings live in a
 //    register-resident stack of statically indexed slots.
 //  * A lane carries TWO sites (64 apart) through the schedule.  With one site per lane the scalar data
-//    cache saturates first: measured (tools/scratch/sqc) it delivers ~3.2 bytes/clk per CU, a one-site
+//    cache saturates first: measured (tools/microbench/sqc_bw.hip) it delivers ~3.2 bytes/clk per CU, a one-site
 //    workgroup pulls 7 waves x 14 KB of P-matrices through it, which alone is 1.7 ms per 8192 samples.
 //    Two sites per lane halve the waves, hence the scalar bytes, per site, and give each wave two
 //    independent dependency chains.  A tile's last few sites (fewer than 64) ride in a one-site wave, so
