@@ -227,6 +227,29 @@ def test_large_tree_family(hip, tmp_path):
     compare(h, desc, ll, res, ref)
 
 
+def test_minimal_tree_and_rate_counts(hip, data_dir, tmp_path):
+    """Edge shapes: the smallest tree the path accepts (naive + two sequences: one cherry op, no stack), a
+    single evaluation per call, and R = 1, 2, 8 rate categories."""
+    import yaml
+    with open(os.path.join(data_dir, "phylo_hmm_input_extra.yaml")) as f:
+        doc = yaml.safe_load(f)
+    ev = doc["events"][0]
+    for k in ("input_seqs", "has_shm_indels", "unique_ids"):
+        ev[k] = ev[k][:2]
+    path = str(tmp_path / "two_seqs.yaml")
+    with open(path, "w") as f:
+        yaml.safe_dump(doc, f)
+    h = orc.PhyloHMM(path, 0, os.path.join(data_dir, "hmm_params"), 0)
+    for R in (1, 2, 8):
+        samples = [dict(tree="(0:0.11,naive:0.07,1:0.23);", er=ER, pi=PI, alpha=0.7)]
+        desc, ll, res, ref = run_family(hip, h, samples, R)
+        compare(h, desc, ll, res, ref)
+    samples = [dict(tree="(0:0.11,naive:0.07,1:0.23);", er=ER, pi=PI, alpha=0.7),
+               dict(tree="(1:0.3,(naive:0.02,0:0.4):0.0);", er=[0.5, 2.0, 1.0, 1.0, 3.0, 1.0], pi=PI, alpha=2.5)]
+    desc, ll, res, ref = run_family(hip, h, samples, 4)
+    compare(h, desc, ll, res, ref)
+
+
 def test_several_site_tiles_per_sample(tmp_path):
     """K1 with more site patterns than one workgroup takes (several tiles per (sample, rate), each
     repeating the P-matrix prologue): forced on the 500-leaf family by the LH_K1_TILE_CAP test hook, which
