@@ -372,14 +372,22 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
       double *__restrict__ site_lik, int32_t *__restrict__ site_scal
 #define LH_PRUNE_ARGS n2, tile, msa, L, T, n_ops, ops, brlen, rates, eig, pmat_w, pmat, pi, site_lik, site_scal
 
-// Shallow stacks (depth <= 4, any tree up to a few hundred tips): two sites per lane.  The kernel is bound
-// by the latency of its compulsory scalar-cache misses (every P-matrix line is new to the CU), so
-// resident waves matter more than a few spilled registers: 5 waves per SIMD (96 VGPRs, ~50 bytes of
-// scratch) measured 13 % faster than the 4 the unconstrained allocation (107 VGPRs) gives, 6 slower again.
-template <int kDepth, bool kN>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) prune_kernel(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, true, kN>(LH_PRUNE_ARGS);
-}
+// Shallow stacks (depth <= 4, any tree up to a few hundred tips): two sites per lane.  The walk needs
+// ~100 VGPRs; resident waves matter more to it than a few spilled registers, as long as the LDS tip
+// tables of that many workgroups fit a CU.  Three register budgets are therefore built -- 6 waves per
+// SIMD (80 VGPRs), 5 (96) and 4 (128, no spills) -- and the launcher takes the tightest one whose
+// occupancy the tip tables allow: configs[2] (13 KB of LDS per two-wave workgroup) runs 6 waves per SIMD,
+// 5 % faster than 5 and 19 % faster than 4; a 500-tip tree (64 KB) could not use them and keeps its registers.
+#define LH_PRUNE_KERNEL(NAME, WAVES)                                                                 \
+  template <int kDepth, bool kN>                                                                     \
+  __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) NAME(    \
+      LH_PRUNE_PARAMS) {                                                                             \
+    prune_body<kDepth, true, kN>(LH_PRUNE_ARGS);                                                     \
+  }
+LH_PRUNE_KERNEL(prune_kernel_w6, 6)
+LH_PRUNE_KERNEL(prune_kernel_w5, 5)
+LH_PRUNE_KERNEL(prune_kernel_w4, 4)
+#undef LH_PRUNE_KERNEL
 
 // Deep stacks leave no room for two sites per lane.
 template <int kDepth>
@@ -426,19 +434,31 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
     hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, fam.msa, L, T, n_ops, ops, brlen, rates, eig,   \
                        pmat, (const double*)pmat, pi, site_lik, site_scal);                                   \
   }
+  // waves per SIMD that the LDS tip tables of the resident workgroups allow (160 KB per CU, 4 SIMDs)
+  const int lds_waves = (int)((160 * 1024 / std::max<size_t>(lds, 1)) * (n2 + n1) / 4);
   // alignments that never mix N with bases take the instantiation without N handling in the look-ups
+#define LH_LAUNCH_SHALLOW(D, N)                    \
+  {                                                \
+    if (lds_waves >= 6 && D == 3) /* a fourth slot spills too much at 80 VGPRs */ \
+      LH_LAUNCH_K((prune_kernel_w6<D, N>))         \
+    else if (lds_waves >= 5)                       \
+      LH_LAUNCH_K((prune_kernel_w5<D, N>))         \
+    else                                           \
+      LH_LAUNCH_K((prune_kernel_w4<D, N>))         \
+  }
   if (max_depth <= 3 && !fam.msa_mixed_n)
-    LH_LAUNCH_K((prune_kernel<3, false>))
+    LH_LAUNCH_SHALLOW(3, false)
   else if (max_depth <= 3)
-    LH_LAUNCH_K((prune_kernel<3, true>))
+    LH_LAUNCH_SHALLOW(3, true)
   else if (max_depth <= 4 && !fam.msa_mixed_n)
-    LH_LAUNCH_K((prune_kernel<4, false>))
+    LH_LAUNCH_SHALLOW(4, false)
   else if (max_depth <= 4)
-    LH_LAUNCH_K((prune_kernel<4, true>))
+    LH_LAUNCH_SHALLOW(4, true)
   else if (max_depth <= 8)
     LH_LAUNCH_K(prune_kernel_deep<8>)
   else
     LH_LAUNCH_K(prune_kernel_deep<16>)
+#undef LH_LAUNCH_SHALLOW
 #undef LH_LAUNCH_K
 }
 
