@@ -294,7 +294,7 @@ __device__ static inline RowScale row_scale(unsigned min_key) {  // min_key: wav
 }
 
 // One junction row's table entries for the genes a lane owns (family constants, independent of the
-// sample and of the HMM state -- so the next row's are fetched while this row computes).
+// sample and of the HMM state).
 template <int GL, int GR>
 struct RowTables {
   double ltr[GL], llo[GL];
@@ -440,26 +440,12 @@ __device__ static int junction_wave(const DevJunction& J, const double* jem, con
     if (scal_out && lane == 0) scal_out[i] = count;
   };
 
-  // Two table sets in flight: while one row computes, the next row's entries are on their way.  The
-  // widest instantiations (rare allele counts) have no registers to spare for that and fetch in place.
-  constexpr bool kPrefetch = 5 * GL + 17 * GR <= 60;
-  if constexpr (kPrefetch) {
-    RowTables<GL, GR> ta, tb;
-    load_row<GL, GR>(J, 0, lane, ta);
-    for (int i = 0; i < W; i += 2) {
-      load_row<GL, GR>(J, min(i + 1, W - 1), lane, tb);
-      step(i, ta);
-      if (i + 1 < W) {
-        load_row<GL, GR>(J, min(i + 2, W - 1), lane, ta);
-        step(i + 1, tb);
-      }
-    }
-  } else {
-    for (int i = 0; i < W; ++i) {
-      RowTables<GL, GR> t;
-      load_row<GL, GR>(J, i, lane, t);
-      step(i, t);
-    }
+  // (Fetching the next row's table entries while a row computes was measured: the second table set costs
+  // 90 VGPRs, i.e. the third wave per SIMD, and that wave hides the fetch better than the prefetch did.)
+  for (int i = 0; i < W; ++i) {
+    RowTables<GL, GR> t;
+    load_row<GL, GR>(J, i, lane, t);
+    step(i, t);
   }
 
   // hand-off into the right germline region (A already holds the last row's rank-one sum)
