@@ -667,10 +667,11 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
     lh::launch_model_setup(m, R, er + (size_t)off * 6, pi + (size_t)off * 4, alpha + off, rates, w.eig,
                            stream);
     if (f->profile) LH_HIP(hipEventRecord(es.e[1], stream));
-    lh::launch_prune(f->host, m, R, T, max_depth, ops + (size_t)off * n_ops * 4, brlen + (size_t)off * nodes, rates,
-                     w.eig, w.pmat, pi + (size_t)off * 4, w.site_lik, w.site_scal, stream);
+    const int planes = lh::launch_prune(f->host, m, R, T, max_depth, ops + (size_t)off * n_ops * 4,
+                                        brlen + (size_t)off * nodes, rates, w.eig, w.pmat, pi + (size_t)off * 4,
+                                        w.site_lik, w.site_scal, stream);
     if (f->profile) LH_HIP(hipEventRecord(es.e[2], stream));
-    if (run_forward(f, m, R, w.site_lik, w.site_scal, pi + (size_t)off * 4, nullptr, em_out, loglik + off, outs, off,
+    if (run_forward(f, m, planes, w.site_lik, w.site_scal, pi + (size_t)off * 4, nullptr, em_out, loglik + off, outs, off,
                     stream))
       return 1;
     if (f->profile) {

@@ -104,9 +104,11 @@ void launch_model_setup(int n, int R, const double* er, const double* pi, const 
 // matrix of the child whose CLV is in the accumulator, [1] = matrix of the popped child), tip-branch
 // matrices into its LDS tip table.
 // site_lik[n][R][5][n_prune], site_scal[n][R][n_prune]
-void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
-                  const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
-                  double* site_lik, int32_t* site_scal, hipStream_t stream);
+// Returns the number of rate planes left in site_lik / site_scal: R, or 1 if the rates were mixed in K1
+// (site_lik[n][1][5][n_prune], site_scal[n][1][n_prune]); K2a is to be run with that count.
+int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
+                 const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
+                 double* site_lik, int32_t* site_scal, hipStream_t stream);
 
 // K2a + K2b.  site_lik != null: emissions are assembled from K1's output (rate mix and naive
 // correction; optionally written to em_out[n][C]); site_lik == null: emissions are taken from

@@ -99,8 +99,7 @@ template <int kDepth, int S, bool kN>
 __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_t* __restrict__ msa, int L,
                                            int n_ops, const int4* __restrict__ op_ptr,
                                            const double* __restrict__ pm, const double* tiptab,
-                                           const double* __restrict__ p4, double* __restrict__ lik_out,
-                                           int32_t* __restrict__ scal_out) {
+                                           const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
   unsigned usite[S];  // MSA byte offsets are 32-bit: (tip row) * L + site
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -240,23 +239,20 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
   //   L_b = sum_i pi_i * clv_root[i] * P_naive[i][b]        (N: row sums of P_naive)
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const int site = site0 + 64 * s;
-    if (site < site_end) {
-      const double w0 = p4[0] * a[s][0], w1 = p4[1] * a[s][1], w2 = p4[2] * a[s][2], w3 = p4[3] * a[s][3];
+    const double w0 = p4[0] * a[s][0], w1 = p4[1] * a[s][1], w2 = p4[2] * a[s][2], w3 = p4[3] * a[s][3];
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        double tv[4];  // tip 0 = naive; its possible states are the five naive bases of the xMSA
-        if (b < 4) {
+    for (int b = 0; b < 5; ++b) {
+      double tv[4];  // tip 0 = naive; its possible states are the five naive bases of the xMSA
+      if (b < 4) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) tv[i] = tiptab[b * 4 + i];
-        } else {
+        for (int i = 0; i < 4; ++i) tv[i] = tiptab[b * 4 + i];
+      } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) tv[i] = ((tiptab[i] + tiptab[4 + i]) + tiptab[8 + i]) + tiptab[12 + i];
-        }
-        lik_out[(size_t)b * L + site] = fma(w3, tv[3], fma(w2, tv[2], fma(w1, tv[1], w0 * tv[0])));
+        for (int i = 0; i < 4; ++i) tv[i] = ((tiptab[i] + tiptab[4 + i]) + tiptab[8 + i]) + tiptab[12 + i];
       }
-      scal_out[site] = scal[s];
+      lik[s][b] = fma(w3, tv[3], fma(w2, tv[2], fma(w1, tv[1], w0 * tv[0])));
     }
+    scl[s] = scal[s];
   }
 }
 
@@ -268,28 +264,36 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
 
 }  // namespace
 
-// Block = n2 two-site waves followed by n1 one-site waves; the tile's sites are
+// Block = n2 two-site waves followed by n1 one-site waves per rate; the tile's sites are
 // blockIdx.x * tile .. +tile-1 (clipped to L).
-template <int kDepth, bool kTwo, bool kN>
-__device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __restrict__ msa, int L, int T, int n_ops,
-                                           const int32_t* __restrict__ ops, const double* __restrict__ brlen,
-                                           const double* __restrict__ rates, const double* __restrict__ eig,
-                                           double* pmat_w, const double* __restrict__ pmat,
-                                           const double* __restrict__ pi, double* __restrict__ site_lik,
-                                           int32_t* __restrict__ site_scal) {
+//
+// kFused: the workgroup carries ALL rate categories of its sample (waves [r * wpr, (r + 1) * wpr) walk
+// rate r with their own LDS tip table) and, when the walks are done, mixes them itself:
+// site_lik[n][1][5][L] then holds the rate mixture (equal weights, scalers aligned to the smallest, the
+// arithmetic K2a would do) and K2a runs with a single "rate".  A quarter of the output traffic, and K2a's
+// bandwidth-bound assembly shrinks to a quarter.  Used when R * wpr <= 8 waves and the R tip tables fit.
+template <int kDepth, bool kTwo, bool kN, bool kFused>
+__device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, const uint8_t* __restrict__ msa, int L,
+                                           int T, int n_ops, const int32_t* __restrict__ ops,
+                                           const double* __restrict__ brlen, const double* __restrict__ rates,
+                                           const double* __restrict__ eig, double* pmat_w,
+                                           const double* __restrict__ pmat, const double* __restrict__ pi,
+                                           double* __restrict__ site_lik, int32_t* __restrict__ site_scal) {
   extern __shared__ double2 smem2[];
-  double* tiptab = reinterpret_cast<double*>(smem2);  // [T][4][4]
-
   const int tid = threadIdx.x;
-  const int R = gridDim.y;
-  const int rate = blockIdx.y;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rate = kFused ? wave_all / wpr : (int)blockIdx.y;
+  const int wave = kFused ? wave_all - rate * wpr : wave_all;  // within the rate
+  const int nthr = kFused ? wpr * 64 : (int)blockDim.x;       // threads working on this rate
+  const int rtid = kFused ? tid - rate * nthr : tid;
   const int sample = blockIdx.z;
+  double* tiptab = reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);  // [T][4][4]
   const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
   const size_t pm_off = ((size_t)sample * R + rate) * (size_t)(T - 2) * 32;
 
   // Prologue (formerly a kernel of its own): the P-matrices of this (sample, rate).
   //   P = I + U expm1(lambda t r) U^-1   (pll_update_prob_matrices [3P])
-  // One thread per matrix.  The first half of the block takes the schedule's ops: op k's
+  // One thread per matrix.  The first half of the rate's threads takes the schedule's ops: op k's
   // accumulator-child matrix goes to pmat[k][0], its popped-child matrix to pmat[k][1] -- global memory,
   // because the walk below wants them as SCALAR operands and scalar loads only read memory; the lines
   // are written and, a barrier later, read back on the same CU, so they are served by its L2.  The
@@ -300,14 +304,13 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
     const double rt = rates[(size_t)sample * R + rate];
     const double* __restrict__ bl = brlen + (size_t)sample * (2 * (size_t)T - 2);
     double* pw = pmat_w + pm_off;
-    const int nthr = blockDim.x;
     const int half = nthr >= 128 ? (nthr / 128) * 64 : 0;  // whole waves on either side
-    const bool do_ops = half == 0 || tid < half;
-    const bool do_tips = half == 0 || tid >= half;
+    const bool do_ops = half == 0 || rtid < half;
+    const bool do_tips = half == 0 || rtid >= half;
     double P[4][4];
     if (do_ops) {
       const int stride = half ? half : nthr;
-      for (int k = tid; k < n_ops; k += stride) {
+      for (int k = rtid; k < n_ops; k += stride) {
         const int4 op = op_ptr[k];
         const int kind = op.x & 15;
         if (kind == OP_CHERRY) continue;
@@ -328,7 +331,7 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
     }
     if (do_tips) {
       const int stride = half ? nthr - half : nthr;
-      for (int j = half ? tid - half : tid; j < T; j += stride) {
+      for (int j = half ? rtid - half : rtid; j < T; j += stride) {
         compute_pmatrix(e, bl[j] * rt, P);
         double* o = tiptab + j * 16;
 #pragma unroll
@@ -344,33 +347,92 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
   // P-matrices in schedule order, now through the read-only alias: the scalar loads of the walk stream
   // through memory and their addresses do not depend on the op descriptor.
   const double* __restrict__ pm = pmat + pm_off;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int tile0 = blockIdx.x * tile;
   const int site_end = min(tile0 + tile, L);
   const double* __restrict__ p4 = pi + (size_t)sample * 4;
-  double* lik_out = site_lik + (((size_t)sample * R + rate) * 5) * (size_t)L;
-  int32_t* scal_out = site_scal + ((size_t)sample * R + rate) * (size_t)L;
-  if constexpr (kTwo) {
-    if (wave < n2) {
-      prune_wave<kDepth, 2, kN>(tile0 + wave * 128 + lane, site_end, msa, L, n_ops, op_ptr, pm, tiptab, p4, lik_out,
-                            scal_out);
-      return;
+  // results of this wave's walk: five naive-state likelihoods and a scaler count per site
+  double lik[2][5];
+  int scl[2] = {0, 0};
+  int site0, n_own;
+  bool two_sites = false;
+  if constexpr (kTwo) two_sites = wave < n2;
+  if (two_sites) {
+    site0 = tile0 + wave * 128 + lane;
+    n_own = 2;
+    if constexpr (kTwo) prune_wave<kDepth, 2, kN>(site0, site_end, msa, L, n_ops, op_ptr, pm, tiptab, p4, lik, scl);
+  } else {
+    site0 = tile0 + n2 * 128 + (wave - n2) * 64 + lane;
+    n_own = 1;
+    double lik1[1][5];
+    int scl1[1];
+    prune_wave<kDepth, 1, kN>(site0, site_end, msa, L, n_ops, op_ptr, pm, tiptab, p4, lik1, scl1);
+#pragma unroll
+    for (int b = 0; b < 5; ++b) lik[0][b] = lik1[0][b];
+    scl[0] = scl1[0];
+  }
+
+  if constexpr (!kFused) {
+    double* lik_out = site_lik + (((size_t)sample * R + rate) * 5) * (size_t)L;
+    int32_t* scal_out = site_scal + ((size_t)sample * R + rate) * (size_t)L;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int site = site0 + 64 * s;
+      if (s < n_own && site < site_end) {
+#pragma unroll
+        for (int b = 0; b < 5; ++b) lik_out[(size_t)b * L + site] = lik[s][b];
+        scal_out[site] = scl[s];
+      }
+    }
+  } else {
+    // exchange through LDS (over the tip tables, which no wave needs any more), then mix the rates
+    const int pad = n2 * 128 + (wpr - n2) * 64;  // sites a rate's waves cover
+    __syncthreads();
+    double* X = reinterpret_cast<double*>(smem2);                 // [R][5][pad]
+    int* SC = reinterpret_cast<int*>(X + (size_t)R * 5 * pad);    // [R][pad]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int idx = site0 + 64 * s - tile0;
+      if (s < n_own && idx < pad) {
+#pragma unroll
+        for (int b = 0; b < 5; ++b) X[((size_t)rate * 5 + b) * pad + idx] = lik[s][b];
+        SC[rate * pad + idx] = scl[s];
+      }
+    }
+    __syncthreads();
+    // PhyloHMM::FillXmsaEmission's rate mixture (src/PhyloHMM.cpp:226-237): equal weights, scalers aligned
+    // to the smallest one -- the same operations in the same order as K2a performs on unmixed input
+    const int n_tile = site_end - tile0;
+    const double w = 1.0 / R;
+    double* lik_out = site_lik + ((size_t)sample * 5) * (size_t)L;
+    int32_t* scal_out = site_scal + (size_t)sample * (size_t)L;
+    for (int j = tid; j < 5 * n_tile; j += blockDim.x) {
+      const int b = j / n_tile, p = j - b * n_tile;
+      int smin = 0x7fffffff;
+      for (int r = 0; r < R; ++r) smin = min(smin, SC[r * pad + p]);
+      double acc = 0.0;
+      for (int r = 0; r < R; ++r) {
+        double v = X[((size_t)r * 5 + b) * pad + p];
+        const int d = SC[r * pad + p] - smin;
+        for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
+        acc += w * v;
+      }
+      lik_out[(size_t)b * L + tile0 + p] = acc;
+      if (b == 0) scal_out[tile0 + p] = smin;
     }
   }
-  prune_wave<kDepth, 1, kN>(tile0 + n2 * 128 + (wave - n2) * 64 + lane, site_end, msa, L, n_ops, op_ptr, pm, tiptab, p4,
-                        lik_out, scal_out);
 }
 
 // pmat_w and pmat are the same buffer: written through the first in the prologue, read through the
 // second (declared read-only and unaliased, which is what lets the compiler keep the walk's P-matrix
 // loads on the scalar unit) after the barrier.
 #define LH_PRUNE_PARAMS                                                                                     \
-  int n2, int tile, const uint8_t *__restrict__ msa, int L, int T, int n_ops, const int32_t *__restrict__ ops, \
+  int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, int n_ops,               \
+      const int32_t *__restrict__ ops,                                                                      \
       const double *__restrict__ brlen, const double *__restrict__ rates, const double *__restrict__ eig,  \
       double *pmat_w, const double *__restrict__ pmat, const double *__restrict__ pi,                      \
       double *__restrict__ site_lik, int32_t *__restrict__ site_scal
-#define LH_PRUNE_ARGS n2, tile, msa, L, T, n_ops, ops, brlen, rates, eig, pmat_w, pmat, pi, site_lik, site_scal
+#define LH_PRUNE_ARGS n2, tile, R, wpr, msa, L, T, n_ops, ops, brlen, rates, eig, pmat_w, pmat, pi, site_lik, site_scal
 
 // Shallow stacks (depth <= 4, any tree up to a few hundred tips): two sites per lane.  The walk needs
 // ~100 VGPRs; resident waves matter more to it than a few spilled registers, as long as the LDS tip
@@ -379,10 +441,10 @@ __device__ __forceinline__ void prune_body(int n2, int tile, const uint8_t* __re
 // occupancy the tip tables allow: configs[2] (13 KB of LDS per two-wave workgroup) runs 6 waves per SIMD,
 // 5 % faster than 5 and 19 % faster than 4; a 500-tip tree (64 KB) could not use them and keeps its registers.
 #define LH_PRUNE_KERNEL(NAME, WAVES)                                                                 \
-  template <int kDepth, bool kN>                                                                     \
+  template <int kDepth, bool kN, bool kFused>                                                        \
   __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) NAME(    \
       LH_PRUNE_PARAMS) {                                                                             \
-    prune_body<kDepth, true, kN>(LH_PRUNE_ARGS);                                                     \
+    prune_body<kDepth, true, kN, kFused>(LH_PRUNE_ARGS);                                             \
   }
 LH_PRUNE_KERNEL(prune_kernel_w6, 6)
 LH_PRUNE_KERNEL(prune_kernel_w5, 5)
@@ -392,19 +454,21 @@ LH_PRUNE_KERNEL(prune_kernel_w4, 4)
 // Deep stacks leave no room for two sites per lane.
 template <int kDepth>
 __global__ void __launch_bounds__(512) prune_kernel_deep(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, false, true>(LH_PRUNE_ARGS);
+  prune_body<kDepth, false, true, false>(LH_PRUNE_ARGS);
 }
 
-void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
-                  const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
-                  double* site_lik, int32_t* site_scal, hipStream_t stream) {
+// Returns the number of rate planes it left in site_lik / site_scal: R, or 1 when the workgroups mixed
+// the rate categories themselves (the count K2a must then be run with).
+int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
+                 const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
+                 double* site_lik, int32_t* site_scal, hipStream_t stream) {
   const int L = fam.n_prune;  // distinct alignment columns; identical ones are pruned once
-  if (L == 0) return;         // nothing but all-N padding
+  if (L == 0) return R;       // nothing but all-N padding (K2a reads no plane at all)
   const bool two = max_depth <= 4;
   // tile: up to 1024 sites as two-site waves plus at most one one-site wave for a remainder below 64
   // (deep variant: up to 8 one-site waves = 512 sites); tiles rebalanced so that they are equally full.
   // Large tiles matter for large trees: every workgroup of a (sample, rate) repeats the P-matrix
-  // prologue and holds its own T x 160-byte tip table in LDS.
+  // prologue and holds its own T x 128-byte tip table in LDS.
   // (LH_K1_TILE_CAP: test hook that forces small tiles so that the multi-tile path runs on small families)
   static const int cap_env = getenv("LH_K1_TILE_CAP") ? atoi(getenv("LH_K1_TILE_CAP")) : 0;
   const int cap = cap_env >= 64 ? std::min(cap_env, two ? 1024 : 512) : two ? 1024 : 512;
@@ -423,28 +487,43 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
   } else {
     n1 = (tile + 63) / 64;
   }
-  const size_t lds = (size_t)T * 16 * sizeof(double);
-  dim3 grid(tiles, R, n), block(64 * (n2 + n1));
+  const int wpr = n2 + n1;  // waves per rate
+  const size_t tip_bytes = (size_t)T * 16 * sizeof(double);
+  // all rates of a sample in one workgroup, mixed there: at most 8 waves, and R tip tables (later reused
+  // as the exchange area [R][5][pad] doubles + [R][pad] ints) within a third of a CU's LDS
+  const size_t pad = (size_t)n2 * 128 + (size_t)n1 * 64;
+  const size_t fused_lds = std::max((size_t)R * tip_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
+  const bool fused = two && R * wpr <= 8 && fused_lds <= 53 * 1024;
+  const size_t lds = fused ? fused_lds : tip_bytes;
+  const int wg_waves = fused ? R * wpr : wpr;
+  dim3 grid(tiles, fused ? 1 : R, n), block(64 * wg_waves);
   const int n_ops = T - 2;
 #define LH_LAUNCH_K(K)                                                                                        \
   {                                                                                                           \
     if (lds > 64 * 1024)                                                                                      \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                    \
-    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, fam.msa, L, T, n_ops, ops, brlen, rates, eig,   \
-                       pmat, (const double*)pmat, pi, site_lik, site_scal);                                   \
+    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, R, wpr, fam.msa, L, T, n_ops, ops, brlen, rates, \
+                       eig, pmat, (const double*)pmat, pi, site_lik, site_scal);                              \
   }
-  // waves per SIMD that the LDS tip tables of the resident workgroups allow (160 KB per CU, 4 SIMDs)
-  const int lds_waves = (int)((160 * 1024 / std::max<size_t>(lds, 1)) * (n2 + n1) / 4);
+  // waves per SIMD that the LDS of the resident workgroups allows (160 KB per CU, 4 SIMDs)
+  const int lds_waves = (int)((160 * 1024 / std::max<size_t>(lds, 1)) * wg_waves / 4);
   // alignments that never mix N with bases take the instantiation without N handling in the look-ups
-#define LH_LAUNCH_SHALLOW(D, N)                    \
-  {                                                \
+#define LH_LAUNCH_BUDGET(D, N, F)                                                 \
+  {                                                                               \
     if (lds_waves >= 6 && D == 3) /* a fourth slot spills too much at 80 VGPRs */ \
-      LH_LAUNCH_K((prune_kernel_w6<D, N>))         \
-    else if (lds_waves >= 5)                       \
-      LH_LAUNCH_K((prune_kernel_w5<D, N>))         \
-    else                                           \
-      LH_LAUNCH_K((prune_kernel_w4<D, N>))         \
+      LH_LAUNCH_K((prune_kernel_w6<D, N, F>))                                     \
+    else if (lds_waves >= 5)                                                      \
+      LH_LAUNCH_K((prune_kernel_w5<D, N, F>))                                     \
+    else                                                                          \
+      LH_LAUNCH_K((prune_kernel_w4<D, N, F>))                                     \
+  }
+#define LH_LAUNCH_SHALLOW(D, N)      \
+  {                                  \
+    if (fused)                       \
+      LH_LAUNCH_BUDGET(D, N, true)   \
+    else                             \
+      LH_LAUNCH_BUDGET(D, N, false)  \
   }
   if (max_depth <= 3 && !fam.msa_mixed_n)
     LH_LAUNCH_SHALLOW(3, false)
@@ -459,7 +538,9 @@ void launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, cons
   else
     LH_LAUNCH_K(prune_kernel_deep<16>)
 #undef LH_LAUNCH_SHALLOW
+#undef LH_LAUNCH_BUDGET
 #undef LH_LAUNCH_K
+  return fused ? 1 : R;
 }
 
 }  // namespace lh
