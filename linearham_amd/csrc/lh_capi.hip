@@ -102,6 +102,7 @@ int upload(lh_family* f, const T* src, size_t count, const T** dst) {
 // whose emission is 1.0 sits at position n_ucol.
 int upload_segments(lh_family* f, const lh_segments& s, int n_xmsa, const std::vector<int32_t>& ucol, int n_ucol,
                     lh::DevSegments* d) {
+  const int scale = f->host.idx_byte_offsets ? 8 : 1;  // byte offsets into the LDS emission vector
   if (s.n_genes < 0) return fail("segments: negative gene count");
   d->n_genes = s.n_genes;
   if (s.n_genes > 0) {
@@ -117,11 +118,11 @@ int upload_segments(lh_family* f, const lh_segments& s, int n_xmsa, const std::v
     d->n_chunks = (longest + 7) / 8;
     if (n_ucol > 0xfffe) return fail("segments: more than 65534 distinct xMSA columns");
     // [chunk][gene][8] 16-bit indices, sentinel = column n_ucol (em = 1)
-    std::vector<uint16_t> t((size_t)d->n_chunks * s.n_genes * 8, (uint16_t)n_ucol);
+    std::vector<uint16_t> t((size_t)d->n_chunks * s.n_genes * 8, (uint16_t)(n_ucol * scale));
     for (int g = 0; g < s.n_genes; ++g)
       for (int j = s.offsets[g]; j < s.offsets[g + 1]; ++j) {
         const int k = j - s.offsets[g];
-        t[((size_t)(k / 8) * s.n_genes + g) * 8 + (k % 8)] = (uint16_t)ucol[s.xmsa_inds[j]];
+        t[((size_t)(k / 8) * s.n_genes + g) * 8 + (k % 8)] = (uint16_t)(ucol[s.xmsa_inds[j]] * scale);
       }
     const uint16_t* dev = nullptr;
     if (upload(f, t.data(), t.size(), &dev)) return 1;
@@ -399,6 +400,7 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
     rc = rc || upload(f, ucol.data(), C, &h.ucol_of_col);
     rc = rc || upload(f, ucol.data(), C, &h.col_of_ucol);
   }
+  h.idx_byte_offsets = ((int64_t)h.n_ucol + 1) * 8 <= 0xffff ? 1 : 0;
   rc = rc || upload_segments(f, desc->vpadding, desc->n_xmsa, ucol, h.n_ucol, &h.vpadding);
   rc = rc || upload_segments(f, desc->vgerm, desc->n_xmsa, ucol, h.n_ucol, &h.vgerm);
   rc = rc || upload_segments(f, desc->jgerm, desc->n_xmsa, ucol, h.n_ucol, &h.jgerm);

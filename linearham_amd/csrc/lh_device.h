@@ -18,7 +18,8 @@ enum : int { OP_CHERRY = 0, OP_TIP_ACC = 1, OP_POP_ACC = 2, OP_PUSH_FLAG = 16 };
 struct DevSegments {
   int32_t n_genes;
   int32_t n_chunks;      // ceil(longest segment / 8)
-  const uint4* inds_c;   // [n_chunks][n_genes] eight 16-bit xMSA column indices per entry (lane g's next
+  const uint4* inds_c;   // [n_chunks][n_genes] eight 16-bit u-column indices (or byte offsets, see
+                         // DevFamily::idx_byte_offsets) per entry (lane g's next
                          // eight factors in one coalesced 16-byte load), padded with the sentinel
                          // column C whose emission is 1.0
 };
@@ -58,6 +59,8 @@ struct DevFamily {
                                            // comes last and whose emission is 1 whatever the tree
   int32_t msa_mixed_n;                     // 1 if some pattern mixes N with bases (K1 then handles N tips)
   int32_t n_ucol;                          // distinct (naive base, pattern) pairs (K2's column dimension)
+  int32_t idx_byte_offsets;                // 1: the segment index chunks hold byte offsets (index * 8),
+                                           // possible when (n_ucol + 1) * 8 fits 16 bits
   const uint8_t* msa;                      // [n_seqs][n_prune]
   const int32_t* u_pat;                    // [n_ucol] pattern of u-column u
   const uint8_t* u_base;                   // [n_ucol] its naive base (4 = N)

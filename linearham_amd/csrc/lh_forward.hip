@@ -62,7 +62,7 @@ __device__ static inline double pow_scale(int d) {  // std::pow(SCALE_FACTOR, d)
 // columns' emissions with ScaleMatrix after every factor, then the 2^(256*d) equalisation to the
 // region's largest scaler count (returned).  Thread `tid` owns genes tid + 256*q; the products go to
 // out[gene].  One 16-byte load brings a gene's next eight column indices.
-template <int kG>
+template <int kG, bool kByteOff>
 __device__ static int fill_segments(const DevSegments& seg, const double* em, int tid, double* __restrict__ out,
                                     int* redi, int phase) {
   double v[kG];
@@ -86,7 +86,11 @@ __device__ static int fill_segments(const DevSegments& seg, const double* em, in
         const unsigned packed[4] = {w.x, w.y, w.z, w.w};
         double e[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) e[u] = em[(packed[u >> 1] >> (16 * (u & 1))) & 0xffffu];
+        for (int u = 0; u < 8; ++u) {
+          const unsigned x = (packed[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+          // families with at most 8190 distinct columns store byte offsets (index * 8): no shift here
+          e[u] = kByteOff ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(em) + x) : em[x];
+        }
         // The eight factors are applied without looking at the threshold, tracking the smallest prefix
         // product m.  ScaleMatrix multiplies by 2^256 (exact) until the value is back above 2^-256, so
         // after the chunk the reference holds p * 2^(256 k) with k = the number of rescalings the
@@ -99,7 +103,9 @@ __device__ static int fill_segments(const DevSegments& seg, const double* em, in
           p *= e[u];
           m = fmin(m, p);
         }
-        if (m >= 0x1p-768) {
+        if (__ballot(!(m >= kScaleThreshold)) == 0) {
+          v[q] = p;  // no gene of this wave crossed the threshold in this chunk (the usual case)
+        } else if (m >= 0x1p-768) {
           const int k = (m < kScaleThreshold) + (m < 0x1p-512);
           v[q] = p * (k == 0 ? 1.0 : k == 1 ? 0x1p256 : 0x1p512);
           c[q] += k;
@@ -131,7 +137,7 @@ __device__ static int fill_segments(const DevSegments& seg, const double* em, in
   return mx;
 }
 
-template <int kG, bool kFromSiteLik>
+template <int kG, bool kFromSiteLik, bool kByteOff>
 __global__ void __launch_bounds__(kFwdThreads)
     emission_kernel(const DevFamily fam, int R, const double* __restrict__ site_lik,
                     const int32_t* __restrict__ site_scal, const double* __restrict__ pi,
@@ -193,16 +199,16 @@ __global__ void __launch_bounds__(kFwdThreads)
   // [vpadding nV | vgerm nV | dgerm nD | jgerm nJ | jpadding nJ]
   const int nV = fam.vgerm.n_genes, nD = fam.dgerm.n_genes, nJ = fam.jgerm.n_genes;
   double* gem = gem_all + s * fam.gem_size;
-  int cv = fill_segments<kG>(fam.vpadding, em, tid, gem, redi, 0);
-  cv += fill_segments<kG>(fam.vgerm, em, tid, gem + nV, redi, 1);
+  int cv = fill_segments<kG, kByteOff>(fam.vpadding, em, tid, gem, redi, 0);
+  cv += fill_segments<kG, kByteOff>(fam.vgerm, em, tid, gem + nV, redi, 1);
   int cd = 0, cj;
   if (fam.has_d) {
-    cd = fill_segments<kG>(fam.dgerm, em, tid, gem + 2 * (size_t)nV, redi, 0);
-    cj = fill_segments<kG>(fam.jgerm, em, tid, gem + 2 * (size_t)nV + nD, redi, 1);
-    cj += fill_segments<kG>(fam.jpadding, em, tid, gem + 2 * (size_t)nV + nD + nJ, redi, 0);
+    cd = fill_segments<kG, kByteOff>(fam.dgerm, em, tid, gem + 2 * (size_t)nV, redi, 0);
+    cj = fill_segments<kG, kByteOff>(fam.jgerm, em, tid, gem + 2 * (size_t)nV + nD, redi, 1);
+    cj += fill_segments<kG, kByteOff>(fam.jpadding, em, tid, gem + 2 * (size_t)nV + nD + nJ, redi, 0);
   } else {
-    cj = fill_segments<kG>(fam.jgerm, em, tid, gem + 2 * (size_t)nV, redi, 0);
-    cj += fill_segments<kG>(fam.jpadding, em, tid, gem + 2 * (size_t)nV + nJ, redi, 1);
+    cj = fill_segments<kG, kByteOff>(fam.jgerm, em, tid, gem + 2 * (size_t)nV, redi, 0);
+    cj += fill_segments<kG, kByteOff>(fam.jpadding, em, tid, gem + 2 * (size_t)nV + nJ, redi, 1);
   }
   if (tid == 0) {
     gcnt_all[s * 3 + 0] = cv;
@@ -605,24 +611,35 @@ size_t forward_lds_bytes(const DevFamily& fam) {
   return a > b ? a : b;
 }
 
+template <int kG, bool kSite, bool kByteOff>
+static void launch_emission_k(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
+                              const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt,
+                              double* jem, hipStream_t stream) {
+  const size_t lds = emission_lds_bytes(fam);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emission_kernel<kG, kSite, kByteOff>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((emission_kernel<kG, kSite, kByteOff>), dim3(n), dim3(kFwdThreads), lds, stream, fam, R,
+                     site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem);
+}
+
 template <int kG>
 static void launch_emission_g(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
                               const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt,
                               double* jem, hipStream_t stream) {
-  const size_t lds = emission_lds_bytes(fam);
+#define LH_ARGS fam, n, R, site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, stream
   if (site_lik) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emission_kernel<kG, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((emission_kernel<kG, true>), dim3(n), dim3(kFwdThreads), lds, stream, fam, R, site_lik,
-                       site_scal, pi, em_in, em_out, gem, gcnt, jem);
+    if (fam.idx_byte_offsets)
+      launch_emission_k<kG, true, true>(LH_ARGS);
+    else
+      launch_emission_k<kG, true, false>(LH_ARGS);
   } else {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emission_kernel<kG, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((emission_kernel<kG, false>), dim3(n), dim3(kFwdThreads), lds, stream, fam, R, site_lik,
-                       site_scal, pi, em_in, em_out, gem, gcnt, jem);
+    if (fam.idx_byte_offsets)
+      launch_emission_k<kG, false, true>(LH_ARGS);
+    else
+      launch_emission_k<kG, false, false>(LH_ARGS);
   }
+#undef LH_ARGS
 }
 
 template <int GA, int GB>
