@@ -253,7 +253,9 @@ int stage(lh_family* f, int slot, size_t bytes, void** out) {
   return 0;
 }
 
-constexpr int kChunk = 8192;  // samples per launch group (bounds the workspace)
+constexpr int kChunk = 24576;  // samples per launch group (bounds the workspace: ~110 KB per sample for a
+                               // 100-tip tree; a multiple of 6144 = whole rounds of all three kernels on
+                               // 256 CUs for configs[2]-like shapes)
 
 int run_forward(lh_family* f, int n, int R, const double* site_lik, const int32_t* site_scal, const double* pi,
                 const double* em_in, double* em_out, double* loglik_dev, const lh_eval_outputs* outs,

@@ -155,8 +155,8 @@ def test_batch_of_varied_models_on_toy_family(hip, data_dir):
 
 
 def test_more_samples_than_one_launch_group(hip, data_dir):
-    """n > 8192 samples run as several launch groups over the same workspace: the P-matrix scratch area is
-    rewritten with different matrices at the same addresses and read back through the scalar cache, the
+    """More samples than one launch group (24576) run as several groups over the same workspace: the
+    P-matrix scratch area is rewritten with different matrices at the same addresses and read back through the scalar cache, the
     K2a -> K2b hand-off buffers are reused."""
     import linearham_amd
     h = orc.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input_extra.yaml"), 0,
@@ -181,8 +181,8 @@ def test_more_samples_than_one_launch_group(hip, data_dir):
         children, root, brlen = db.tree_arrays(orc.parse_newick(s["tree"]), h.xmsa_labels)
         o, d = hip.schedule_tree(T, children, root)
         sched.append((o, brlen, d))
-    n = 2 * 8192 + 7
-    pick = [(i * 7 + i // 8192) % len(sets) for i in range(n)]   # position p differs between the groups
+    n = 2 * 24576 + 7
+    pick = [(i * 7 + i // 24576) % len(sets) for i in range(n)]   # position p differs between the groups
     ll, _ = fam.eval_batch(T, max(x[2] for x in sched), np.stack([sched[j][0] for j in pick]),
                            np.stack([sched[j][1] for j in pick]), [sets[j]["er"] for j in pick],
                            [sets[j]["pi"] for j in pick], [sets[j]["alpha"] for j in pick], 4, want=())
