@@ -27,7 +27,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 peak (MI355X_MICROARCH.md)
 DEFAULT_BATCH = 24576          # tree samples per GPU per step (= one launch group of the C ABI)
-PMC_PROFILE = "r01_v9_bench_pmc_per_launch.json"   # committed PMC passes of the default command
+PMC_PROFILE = "r01_v10_bench_pmc_per_launch.json"   # committed PMC passes of the default command
 
 
 def log(*a):

@@ -156,8 +156,8 @@ def test_batch_of_varied_models_on_toy_family(hip, data_dir):
 
 def test_more_samples_than_one_launch_group(hip, data_dir):
     """More samples than one launch group (24576) run as several groups over the same workspace: the
-    P-matrix scratch area is rewritten with different matrices at the same addresses and read back through the scalar cache, the
-    K2a -> K2b hand-off buffers are reused."""
+    P-matrix scratch area is rewritten with different matrices at the same addresses and read back through
+    the scalar cache, the K2a -> K2b hand-off buffers are reused."""
     import linearham_amd
     h = orc.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input_extra.yaml"), 0,
                      os.path.join(data_dir, "hmm_params"), 0)
