@@ -224,9 +224,10 @@ def main():
             ll_pcie = np.zeros(n)
             p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
             h_ops, h_brl = np.ascontiguousarray(flat["ops"]), np.ascontiguousarray(flat["brlen"])
-            t1 = time.perf_counter()
             reps = 3
-            for _ in range(reps):
+            for rep in range(reps + 1):   # the first call sizes the pinned staging slots and is not timed
+                if rep == 1:
+                    t1 = time.perf_counter()
                 lib.check(lib.lib.lh_eval_batch(C.c_void_p(fam_handle), n, T, depth, p(h_ops, C.c_int32),
                                                 p(h_brl, C.c_double), p(flat["er"], C.c_double),
                                                 p(flat["pi"], C.c_double), p(flat["alpha"], C.c_double), R,

@@ -4,7 +4,9 @@
 #include <map>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "lh_device.h"
@@ -42,6 +44,14 @@ struct Staging {  // device copies of host inputs/outputs for the host-pointer e
   void* ptr[10] = {nullptr};
 };
 
+// lh_eval_batch's host -> device pipeline: two pinned staging slots, a copy stream and a compute stream
+struct HostPipe {
+  void* pinned[2] = {nullptr, nullptr};
+  size_t cap = 0;
+  hipStream_t copy = nullptr, comp = nullptr;
+  hipEvent_t staged[2] = {nullptr, nullptr};
+};
+
 struct EventSet {
   hipEvent_t e[4];
 };
@@ -58,6 +68,7 @@ struct lh_family {
   Workspace ws;
   ForwardWs fws;
   Staging st;
+  HostPipe pipe;
   bool profile = false;
   std::vector<EventSet> events;
   double ms[3] = {0, 0, 0};
@@ -490,6 +501,12 @@ void lh_family_destroy(lh_family* f) {
     if (p) (void)hipFree(p);
   for (EventSet& es : f->events)
     for (hipEvent_t e : es.e) (void)hipEventDestroy(e);
+  for (void* p : f->pipe.pinned)
+    if (p) (void)hipHostFree(p);
+  for (hipEvent_t e : f->pipe.staged)
+    if (e) (void)hipEventDestroy(e);
+  if (f->pipe.copy) (void)hipStreamDestroy(f->pipe.copy);
+  if (f->pipe.comp) (void)hipStreamDestroy(f->pipe.comp);
   delete f;
 }
 
@@ -687,6 +704,21 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
   return 0;
 }
 
+// One schedule op as lh_schedule_tree writes it (a malformed op would index out of bounds on the device).
+static bool valid_op(const int32_t* op, int T, int nodes, int max_depth) {
+  const int kind = op[0] & 15;
+  const bool push = op[0] & lh::OP_PUSH_FLAG;
+  bool ok = (op[0] & ~31) == 0 && kind <= 2;
+  if (kind == lh::OP_CHERRY) ok = ok && op[1] >= 1 && op[1] < T && op[2] >= 1 && op[2] < T;
+  if (kind == lh::OP_TIP_ACC) ok = ok && !push && op[1] >= 1 && op[1] < T && op[2] >= T && op[2] < nodes;
+  if (kind == lh::OP_POP_ACC) ok = ok && !push && op[1] >= T && op[1] < nodes && op[2] >= T && op[2] < nodes;
+  if (push || kind == lh::OP_POP_ACC) ok = ok && op[3] >= 0 && op[3] < max_depth;
+  return ok;
+}
+
+// Host pointers in, host pointers out.  The batch moves in sub-chunks through two pinned staging slots:
+// while the kernels of one sub-chunk run on the compute stream, a few host threads validate the next
+// sub-chunk's schedules and gather its inputs into the other slot, and the copy stream ships it.
 int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const int32_t* ops,
                   const double* brlen, const double* er, const double* pi, const double* alpha, int32_t R,
                   double* loglik, const lh_eval_outputs* outs) {
@@ -695,19 +727,6 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
   if (T < 3) return fail("lh_eval_batch: need at least 3 tips");
   if (!ops || !brlen || !er || !pi || !alpha || !loglik) return fail("lh_eval_batch: null array");
   const size_t nodes = 2 * (size_t)T - 2, n_ops = (size_t)T - 2;
-  // host-side validation of the schedules (a malformed op would index out of bounds on the device)
-  for (size_t k = 0; k < (size_t)n * n_ops; ++k) {
-    const int32_t* op = ops + 4 * k;
-    const int kind = op[0] & 15;
-    const bool push = op[0] & lh::OP_PUSH_FLAG;
-    bool ok = (op[0] & ~31) == 0 && kind <= 2;
-    if (kind == lh::OP_CHERRY) ok = ok && op[1] >= 1 && op[1] < T && op[2] >= 1 && op[2] < T;
-    if (kind == lh::OP_TIP_ACC) ok = ok && !push && op[1] >= 1 && op[1] < T && op[2] >= T && op[2] < (int)nodes;
-    if (kind == lh::OP_POP_ACC)
-      ok = ok && !push && op[1] >= T && op[1] < (int)nodes && op[2] >= T && op[2] < (int)nodes;
-    if (push || kind == lh::OP_POP_ACC) ok = ok && op[3] >= 0 && op[3] < max_depth;
-    if (!ok) return fail("lh_eval_batch: malformed schedule op (use lh_schedule_tree)");
-  }
   void *d_ops, *d_brlen, *d_er, *d_pi, *d_alpha, *d_ll;
   if (stage(f, 0, sizeof(int32_t) * 4 * n_ops * n, &d_ops)) return 1;
   if (stage(f, 1, sizeof(double) * nodes * n, &d_brlen)) return 1;
@@ -715,11 +734,6 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
   if (stage(f, 3, sizeof(double) * 4 * n, &d_pi)) return 1;
   if (stage(f, 4, sizeof(double) * n, &d_alpha)) return 1;
   if (stage(f, 5, sizeof(double) * n, &d_ll)) return 1;
-  LH_HIP(hipMemcpy(d_ops, ops, sizeof(int32_t) * 4 * n_ops * n, hipMemcpyHostToDevice));
-  LH_HIP(hipMemcpy(d_brlen, brlen, sizeof(double) * nodes * n, hipMemcpyHostToDevice));
-  LH_HIP(hipMemcpy(d_er, er, sizeof(double) * 6 * n, hipMemcpyHostToDevice));
-  LH_HIP(hipMemcpy(d_pi, pi, sizeof(double) * 4 * n, hipMemcpyHostToDevice));
-  LH_HIP(hipMemcpy(d_alpha, alpha, sizeof(double) * n, hipMemcpyHostToDevice));
   lh_eval_outputs d_outs{nullptr, nullptr, nullptr, nullptr};
   const size_t C = f->host.n_xmsa, FS = f->host.forward_size, SS = f->host.scaler_size;
   if (outs) {
@@ -728,11 +742,91 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
     if (outs->forward && stage(f, 8, sizeof(double) * FS * n, (void**)&d_outs.forward)) return 1;
     if (outs->scaler_counts && stage(f, 9, sizeof(int32_t) * SS * n, (void**)&d_outs.scaler_counts)) return 1;
   }
-  if (lh_eval_batch_device(f, n, T, max_depth, (const int32_t*)d_ops, (const double*)d_brlen,
-                           (const double*)d_er, (const double*)d_pi, (const double*)d_alpha, R, (double*)d_ll,
-                           &d_outs, nullptr))
-    return 1;
-  LH_HIP(hipDeviceSynchronize());
+
+  // per-sample bytes of the five input arrays, in the order they sit in a staging slot
+  const size_t bytes[5] = {sizeof(int32_t) * 4 * n_ops, sizeof(double) * nodes, sizeof(double) * 6,
+                           sizeof(double) * 4, sizeof(double)};
+  const char* src[5] = {(const char*)ops, (const char*)brlen, (const char*)er, (const char*)pi, (const char*)alpha};
+  char* dst[5] = {(char*)d_ops, (char*)d_brlen, (char*)d_er, (char*)d_pi, (char*)d_alpha};
+  size_t per_sample = 0;
+  for (size_t b : bytes) per_sample += b;
+  constexpr int kSub = 6144;  // whole rounds of all kernels for configs[2]-like shapes
+  const int sub = std::min<int>(n, kSub);
+  HostPipe& hp = f->pipe;
+  if (!hp.copy) {
+    LH_HIP(hipStreamCreateWithFlags(&hp.copy, hipStreamNonBlocking));
+    LH_HIP(hipStreamCreateWithFlags(&hp.comp, hipStreamNonBlocking));
+    for (hipEvent_t& e : hp.staged) LH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  if (hp.cap < per_sample * sub) {
+    for (void*& p : hp.pinned) {
+      if (p) LH_HIP(hipHostFree(p));
+      p = nullptr;
+    }
+    hp.cap = 0;
+    for (void*& p : hp.pinned) LH_HIP(hipHostMalloc(&p, per_sample * sub, hipHostMallocDefault));
+    hp.cap = per_sample * sub;
+  }
+  LH_HIP(hipDeviceSynchronize());  // the staging buffers may still be in use by an earlier device-pointer call
+
+  const int n_workers = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 8u));
+  int rc = 0;
+  int slot = 0;
+  bool slot_used[2] = {false, false};
+  for (int off = 0; off < n && !rc; off += sub, slot ^= 1) {
+    const int m = std::min(sub, n - off);
+    if (slot_used[slot]) LH_HIP(hipEventSynchronize(hp.staged[slot]));  // its last copy has left the slot
+    char* base = static_cast<char*>(hp.pinned[slot]);
+    char* part[5];
+    {
+      size_t o = 0;
+      for (int a = 0; a < 5; ++a) {
+        part[a] = base + o;
+        o += bytes[a] * m;
+      }
+    }
+    std::atomic<bool> bad{false};
+    auto work = [&](int lo, int hi) {
+      for (size_t k = (size_t)lo * n_ops; k < (size_t)hi * n_ops; ++k)
+        if (!valid_op(ops + ((size_t)off * n_ops + k) * 4, T, (int)nodes, max_depth)) {
+          bad = true;
+          return;
+        }
+      for (int a = 0; a < 5; ++a)
+        memcpy(part[a] + bytes[a] * lo, src[a] + bytes[a] * ((size_t)off + lo), bytes[a] * (size_t)(hi - lo));
+    };
+    const int nw = std::max(1, std::min(n_workers, m / 256));
+    if (nw == 1) {
+      work(0, m);
+    } else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nw; ++t)
+        pool.emplace_back(work, (int)((long long)m * t / nw), (int)((long long)m * (t + 1) / nw));
+      for (std::thread& th : pool) th.join();
+    }
+    if (bad) {
+      rc = fail("lh_eval_batch: malformed schedule op (use lh_schedule_tree)");
+      break;
+    }
+    for (int a = 0; a < 5; ++a)
+      if (hipMemcpyAsync(dst[a] + bytes[a] * off, part[a], bytes[a] * m, hipMemcpyHostToDevice, hp.copy) !=
+          hipSuccess)
+        rc = fail("lh_eval_batch: hipMemcpyAsync failed");
+    if (rc) break;
+    LH_HIP(hipEventRecord(hp.staged[slot], hp.copy));
+    slot_used[slot] = true;
+    LH_HIP(hipStreamWaitEvent(hp.comp, hp.staged[slot], 0));
+    lh_eval_outputs o{d_outs.rates ? d_outs.rates + (size_t)off * R : nullptr,
+                      d_outs.xmsa_emission ? d_outs.xmsa_emission + (size_t)off * C : nullptr,
+                      d_outs.forward ? d_outs.forward + (size_t)off * FS : nullptr,
+                      d_outs.scaler_counts ? d_outs.scaler_counts + (size_t)off * SS : nullptr};
+    rc = lh_eval_batch_device(f, m, T, max_depth, (const int32_t*)(dst[0] + bytes[0] * off),
+                              (const double*)(dst[1] + bytes[1] * off), (const double*)(dst[2] + bytes[2] * off),
+                              (const double*)(dst[3] + bytes[3] * off), (const double*)(dst[4] + bytes[4] * off), R,
+                              (double*)d_ll + off, &o, hp.comp);
+  }
+  if (hipDeviceSynchronize() != hipSuccess && !rc) rc = fail("lh_eval_batch: device synchronisation failed");
+  if (rc) return 1;
   LH_HIP(hipMemcpy(loglik, d_ll, sizeof(double) * n, hipMemcpyDeviceToHost));
   if (outs) {
     if (outs->rates) LH_HIP(hipMemcpy(outs->rates, d_outs.rates, sizeof(double) * R * n, hipMemcpyDeviceToHost));
