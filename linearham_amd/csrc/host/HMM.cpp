@@ -1,6 +1,7 @@
 #include "HMM.hpp"
 
 #include <algorithm>
+#include <limits>
 #include <cmath>
 #include <tuple>
 
@@ -157,34 +158,41 @@ double HMM::LogLikelihood() {
 namespace {
 
 // Scatter one compact junction row block (include/linearham_amd.h, lh_forward_size) into the dense
-// W x S matrix of the reference (HMM::*_junction_forward_).
+// W x S matrix of the reference (HMM::*_junction_forward_).  Which dense entry a compact slot lands on
+// depends on the family only: the positions are worked out once (`scatter`), the matrix is zeroed once,
+// and every later call overwrites the same entries.
 const double* UnpackJunction(const double* p, const RegionStates& J, const RegionStates& G_left,
-                             const RegionStates& G_right, int js, int W, MatrixXd& F) {
+                             const RegionStates& G_right, int js, int W, MatrixXd& F, std::vector<int>& scatter) {
   const int S = (int)J.state_strs.size();
   const int nL = (int)G_left.ggene_ranges.size(), nR = (int)G_right.ggene_ranges.size();
-  F.setZero(W, S);
-  for (int i = 0; i < W; ++i) {
-    const double* fL = p;
-    const double* fN = p + nL;
-    const double* fR = p + nL + 4 * nR;
-    int l = 0;
-    for (auto it = G_left.ggene_ranges.begin(); it != G_left.ggene_ranges.end(); ++it, ++l) {
-      const auto& rg = J.ggene_ranges.at(it->first);
-      if (i < rg.second - rg.first) F(i, rg.first + i) = fL[l];
-    }
-    int r = 0;
-    for (auto it = G_right.ggene_ranges.begin(); it != G_right.ggene_ranges.end(); ++it, ++r) {
-      const auto& rg = J.ggene_ranges.at(it->first);
-      for (int b = 0; b < 4; ++b) F(i, rg.first + b) = fN[4 * r + b];
-      if (rg.second > rg.first + 4) {
-        const int first_site = J.site_inds[rg.first + 4];
-        const int k = rg.first + 4 + (js + i - first_site);
-        if (js + i >= first_site && k < rg.second) F(i, k) = fR[r];
+  const int stride = nL + 5 * nR;
+  if (scatter.empty() || F.rows() != W || F.cols() != S) {
+    F.setZero(W, S);
+    scatter.assign((std::size_t)W * stride, -1);
+    for (int i = 0; i < W; ++i) {
+      int* sc = scatter.data() + (std::size_t)i * stride;
+      int l = 0;
+      for (auto it = G_left.ggene_ranges.begin(); it != G_left.ggene_ranges.end(); ++it, ++l) {
+        const auto& rg = J.ggene_ranges.at(it->first);
+        if (i < rg.second - rg.first) sc[l] = i * S + rg.first + i;
+      }
+      int r = 0;
+      for (auto it = G_right.ggene_ranges.begin(); it != G_right.ggene_ranges.end(); ++it, ++r) {
+        const auto& rg = J.ggene_ranges.at(it->first);
+        for (int b = 0; b < 4; ++b) sc[nL + 4 * r + b] = i * S + rg.first + b;
+        if (rg.second > rg.first + 4) {
+          const int first_site = J.site_inds[rg.first + 4];
+          const int k = rg.first + 4 + (js + i - first_site);
+          if (js + i >= first_site && k < rg.second) sc[nL + 4 * nR + r] = i * S + k;
+        }
       }
     }
-    p += nL + 5 * nR;
   }
-  return p;
+  double* f = F.data();
+  const std::size_t total = (std::size_t)W * stride;
+  for (std::size_t t = 0; t < total; ++t)
+    if (scatter[t] >= 0) f[scatter[t]] = p[t];
+  return p + total;
 }
 
 }  // namespace
@@ -197,7 +205,7 @@ void HMM::UnpackForward(const double* fwd, const int32_t* sco) {
   const bool igh = locus_ == "igh";
   const int W1 = flexbounds_.at(igh ? "d_l" : "j_l").second - flexbounds_.at("v_r").first;
   fwd = UnpackJunction(fwd, vd_junction_, vgerm_, igh ? dgerm_ : jgerm_, flexbounds_.at("v_r").first, W1,
-                       vd_junction_forward_);
+                       vd_junction_forward_, vd_scatter_);
   vd_junction_scaler_counts_.assign(sco, sco + W1);
   sco += W1;
   if (igh) {
@@ -206,7 +214,8 @@ void HMM::UnpackForward(const double* fwd, const int32_t* sco) {
     fwd += nD;
     dgerm_scaler_count_ = *sco++;
     const int W2 = flexbounds_.at("j_l").second - flexbounds_.at("d_r").first;
-    fwd = UnpackJunction(fwd, dj_junction_, dgerm_, jgerm_, flexbounds_.at("d_r").first, W2, dj_junction_forward_);
+    fwd = UnpackJunction(fwd, dj_junction_, dgerm_, jgerm_, flexbounds_.at("d_r").first, W2, dj_junction_forward_,
+                         dj_scatter_);
     dj_junction_scaler_counts_.assign(sco, sco + W2);
     sco += W2;
   }
@@ -228,6 +237,10 @@ void HMM::SampleInitialState() {
     naive_seq_samp_[jgerm_.site_inds[i]] = alphabet_[jgerm_.naive_bases[i]];
 }
 
+struct HMM::SamplingLists {
+  ColumnLists vd_germ, vd_junction, dj_germ, dj_junction;
+};
+
 // src/HMM.cpp:358-431.  Sampling stays on the host: it consumes ONE std::mt19937 stream in file
 // order (src/HMM.cpp:56), with libstdc++'s discrete_distribution, exactly like the reference.
 std::string HMM::SampleNaiveSequence() {
@@ -236,24 +249,37 @@ std::string HMM::SampleNaiveSequence() {
     cache_forward_ = false;
   }
   naive_seq_samp_.assign(msa_.cols(), 'N');
+  if (!sampling_lists_) {
+    sampling_lists_.reset(new SamplingLists());
+    sampling_lists_->vd_germ = ColumnLists::Build(vd_junction_dgerm_transition_);
+    sampling_lists_->vd_junction = ColumnLists::Build(vd_junction_transition_);
+    if (locus_ == "igh") {
+      sampling_lists_->dj_germ = ColumnLists::Build(dj_junction_jgerm_transition_);
+      sampling_lists_->dj_junction = ColumnLists::Build(dj_junction_transition_);
+    }
+  }
+  const SamplingLists& sl = *sampling_lists_;
   SampleInitialState();
   if (locus_ == "igh") {
     SampleJunctionStates(jgerm_state_ind_samp_, dj_junction_jgerm_transition_, dj_junction_, dj_junction_transition_,
                          dj_junction_forward_, GermlineType::D, GermlineType::J, flexbounds_.at("d_r"), alphabet_,
                          rng_, distr_, naive_seq_samp_, jgerm_left_del_samp_, dj_junction_state_str_samps_,
-                         dj_junction_state_ind_samps_, dj_junction_insertion_samp_, dgerm_right_del_samp_);
+                         dj_junction_state_ind_samps_, dj_junction_insertion_samp_, dgerm_right_del_samp_, &sl.dj_germ,
+                         &sl.dj_junction);
     SampleGermlineState(dj_junction_state_ind_samps_, dgerm_dj_junction_transition_, dgerm_, dgerm_forward_,
                         alphabet_, rng_, distr_, naive_seq_samp_, dgerm_state_str_samp_, dgerm_state_ind_samp_,
                         dgerm_left_del_samp_, dgerm_right_del_samp_);
     SampleJunctionStates(dgerm_state_ind_samp_, vd_junction_dgerm_transition_, vd_junction_, vd_junction_transition_,
                          vd_junction_forward_, GermlineType::V, GermlineType::D, flexbounds_.at("v_r"), alphabet_,
                          rng_, distr_, naive_seq_samp_, dgerm_left_del_samp_, vd_junction_state_str_samps_,
-                         vd_junction_state_ind_samps_, vd_junction_insertion_samp_, vgerm_right_del_samp_);
+                         vd_junction_state_ind_samps_, vd_junction_insertion_samp_, vgerm_right_del_samp_, &sl.vd_germ,
+                         &sl.vd_junction);
   } else {
     SampleJunctionStates(jgerm_state_ind_samp_, vd_junction_dgerm_transition_, vd_junction_, vd_junction_transition_,
                          vd_junction_forward_, GermlineType::V, GermlineType::J, flexbounds_.at("v_r"), alphabet_,
                          rng_, distr_, naive_seq_samp_, jgerm_left_del_samp_, vd_junction_state_str_samps_,
-                         vd_junction_state_ind_samps_, vd_junction_insertion_samp_, vgerm_right_del_samp_);
+                         vd_junction_state_ind_samps_, vd_junction_insertion_samp_, vgerm_right_del_samp_, &sl.vd_germ,
+                         &sl.vd_junction);
   }
   SampleGermlineState(vd_junction_state_ind_samps_, vgerm_vd_junction_transition_, vgerm_, vgerm_forward_, alphabet_,
                       rng_, distr_, naive_seq_samp_, vgerm_state_str_samp_, vgerm_state_ind_samp_,
@@ -586,6 +612,47 @@ JunctionTables HMM::BuildJunctionTables(const RegionStates& J, const RegionState
   return t;
 }
 
+ColumnLists ColumnLists::Build(const MatrixXd& M) {
+  ColumnLists c;
+  const int R = M.rows(), C = M.cols();
+  c.start.assign(C + 1, 0);
+  for (int r = 0; r < R; ++r) {
+    const double* row = M.row(r);
+    for (int k = 0; k < C; ++k)
+      if (row[k] != 0.0) ++c.start[k + 1];
+  }
+  for (int k = 0; k < C; ++k) c.start[k + 1] += c.start[k];
+  c.rows.resize(c.start[C]);
+  std::vector<int> fill(c.start.begin(), c.start.end() - 1);
+  for (int r = 0; r < R; ++r) {  // rows visited in order: ascending within every column
+    const double* row = M.row(r);
+    for (int k = 0; k < C; ++k)
+      if (row[k] != 0.0) c.rows[fill[k]++] = r;
+  }
+  return c;
+}
+
+// libstdc++'s discrete_distribution (bits/random.tcc): probabilities = weights / sum, cumulative by
+// partial_sum, last cumulative forced to 1.0, one generate_canonical<double, 53> draw p, result =
+// lower_bound(cumulative, p).  Zeros add 0.0 to the sum and to every partial sum, so only the non-zero
+// entries have to be visited; a zero entry can be returned in two corner cases only, kept here: p == 0
+// returns index 0, and p above the last computed partial sum returns the last index (whose cumulative is
+// the forced 1.0).
+int DrawDiscreteSparse(std::mt19937& rng, const int* idx, const double* weights, int k, int size) {
+  if (size < 2) return 0;  // libstdc++ keeps no table for fewer than two weights and draws nothing
+  double sum = 0.0;
+  for (int j = 0; j < k; ++j) sum += weights[j];
+  const double p = std::generate_canonical<double, std::numeric_limits<double>::digits>(rng);
+  if (!(p > 0.0) || k == 0) return 0;  // (all weights zero: libstdc++'s table is all NaN, index 0 comes back)
+  double cum = 0.0;
+  for (int j = 0; j < k; ++j) {
+    cum += weights[j] / sum;
+    const double cp = (j == k - 1 && idx[j] == size - 1) ? 1.0 : cum;
+    if (cp >= p) return idx[j];
+  }
+  return size - 1;
+}
+
 // src/HMM.cpp:1222-1278
 void SampleJunctionStates(int germ_state_ind_samp, const MatrixXd& junction_germ_transition, const RegionStates& J,
                           const MatrixXd& junction_transition, const MatrixXd& junction_forward,
@@ -594,7 +661,7 @@ void SampleJunctionStates(int germ_state_ind_samp, const MatrixXd& junction_germ
                           std::string& naive_seq_samp, int& germ_left_del_samp,
                           std::vector<std::string>& junction_state_str_samps,
                           std::vector<int>& junction_state_ind_samps, std::string& junction_insertion_samp,
-                          int& germ_right_del_samp) {
+                          int& germ_right_del_samp, const ColumnLists* germ_cols, const ColumnLists* junction_cols) {
   const int site_start = left_flexbounds.first;
   const int W = junction_forward.rows(), S = junction_forward.cols();
   junction_state_str_samps.assign(W, "");
@@ -602,14 +669,35 @@ void SampleJunctionStates(int germ_state_ind_samp, const MatrixXd& junction_germ
   junction_insertion_samp = "";
   germ_right_del_samp = -1;
   VectorXd probs(S);
+  std::vector<int> nz_idx;
+  std::vector<double> nz_w;
   for (int i = W - 1; i >= 0; i--) {
-    for (int s = 0; s < S; ++s) {
-      const double tr = (i == W - 1) ? junction_germ_transition(s, germ_state_ind_samp)
-                                     : junction_transition(s, junction_state_ind_samps[i + 1]);
-      probs[s] = tr * junction_forward(i, s);
+    int k;
+    const ColumnLists* cols = (i == W - 1) ? germ_cols : junction_cols;
+    if (cols) {
+      // only the states with a non-zero transition into the sampled successor can have weight
+      const MatrixXd& T = (i == W - 1) ? junction_germ_transition : junction_transition;
+      const int col = (i == W - 1) ? germ_state_ind_samp : junction_state_ind_samps[i + 1];
+      nz_idx.clear();
+      nz_w.clear();
+      for (int t = cols->start[col]; t < cols->start[col + 1]; ++t) {
+        const int s = cols->rows[t];
+        const double w = T(s, col) * junction_forward(i, s);
+        if (w != 0.0) {
+          nz_idx.push_back(s);
+          nz_w.push_back(w);
+        }
+      }
+      k = DrawDiscreteSparse(rng, nz_idx.data(), nz_w.data(), (int)nz_idx.size(), S);
+    } else {
+      for (int s = 0; s < S; ++s) {
+        const double tr = (i == W - 1) ? junction_germ_transition(s, germ_state_ind_samp)
+                                       : junction_transition(s, junction_state_ind_samps[i + 1]);
+        probs[s] = tr * junction_forward(i, s);
+      }
+      distr.param(std::discrete_distribution<int>::param_type(probs.data(), probs.data() + probs.size()));
+      k = distr(rng);
     }
-    distr.param(std::discrete_distribution<int>::param_type(probs.data(), probs.data() + probs.size()));
-    const int k = distr(rng);
     junction_state_ind_samps[i] = k;
     junction_state_str_samps[i] = J.state_strs[k];
     naive_seq_samp[site_start + i] = alphabet[J.naive_bases[k]];

@@ -6,6 +6,7 @@
 #define LINEARHAM_HMM_
 
 #include <map>
+#include <memory>
 #include <random>
 #include <string>
 #include <unordered_map>
@@ -88,6 +89,11 @@ class HMM {
   std::string jgerm_state_str_samp_;
   int jgerm_state_ind_samp_ = 0, jgerm_left_del_samp_ = 0, jgerm_right_del_samp_ = 0;
   std::string jgerm_right_insertion_samp_;
+
+  // host-side accelerators of the sampling pass, built on first use
+  std::vector<int> vd_scatter_, dj_scatter_;  // compact forward slot -> position in the dense matrix
+  struct SamplingLists;
+  std::unique_ptr<SamplingLists> sampling_lists_;
 
   // GPU side
   lh_family* family_ = nullptr;
@@ -216,6 +222,22 @@ void FillTransition(const GermlineGene& from_ggene, const GermlineGene& to_ggene
                     int site_ind_row_start, int site_ind_col_start, int nti_row_start, int nti_col_start,
                     int nti_row_length, int nti_col_length, int germ_row_start, int germ_col_start,
                     int germ_row_length, int germ_col_length, MatrixXd& T, int row_off, int col_off);
+/// The non-zero rows of every column of a dense transition matrix (the junction matrices are >99 %
+/// zeros; sampling reads one column per step).
+struct ColumnLists {
+  std::vector<int> start;  // [cols + 1]
+  std::vector<int> rows;   // ascending within a column
+  static ColumnLists Build(const MatrixXd& M);
+};
+
+/// One draw of std::discrete_distribution<int> over a weight vector of length `size` of which only the
+/// entries idx[0..k) (ascending) are non-zero -- the same std::mt19937 consumption and, operation for
+/// operation, the same arithmetic as libstdc++ performs on the full vector (adding the zeros changes
+/// neither the sum nor a partial sum), so the sampled index is the one the dense call returns.
+int DrawDiscreteSparse(std::mt19937& rng, const int* idx, const double* weights, int k, int size);
+
+/// germ_cols / junction_cols (optional): column lists of the two transition matrices; with them a step
+/// costs the handful of states that can precede the sampled one instead of all S.
 void SampleJunctionStates(int germ_state_ind_samp, const MatrixXd& junction_germ_transition, const RegionStates& J,
                           const MatrixXd& junction_transition, const MatrixXd& junction_forward,
                           GermlineType left_gtype, GermlineType right_gtype, std::pair<int, int> left_flexbounds,
@@ -223,7 +245,8 @@ void SampleJunctionStates(int germ_state_ind_samp, const MatrixXd& junction_germ
                           std::string& naive_seq_samp, int& germ_left_del_samp,
                           std::vector<std::string>& junction_state_str_samps,
                           std::vector<int>& junction_state_ind_samps, std::string& junction_insertion_samp,
-                          int& germ_right_del_samp);
+                          int& germ_right_del_samp, const ColumnLists* germ_cols = nullptr,
+                          const ColumnLists* junction_cols = nullptr);
 void SampleGermlineState(const std::vector<int>& junction_state_ind_samps, const MatrixXd& germ_junction_transition,
                          const RegionStates& G, const VectorXd& germ_forward, const std::string& alphabet,
                          std::mt19937& rng, std::discrete_distribution<int>& distr, std::string& naive_seq_samp,

@@ -147,7 +147,8 @@ void PhyloHMM::InitializePhyloParametersFromString(const std::string& newick, co
   sr_.assign(num_rates, 0.0);
 }
 
-PhyloHMM::DeviceBatch PhyloHMM::FlattenBatch(const std::vector<TreeSample>& samples) const {
+PhyloHMM::DeviceBatch PhyloHMM::FlattenBatch(const std::vector<TreeSample>& samples, std::vector<TreeArrays>* trees,
+                                             std::vector<std::string>* exported) const {
   DeviceBatch b;
   const int T = (int)xmsa_labels_.size();
   b.n = (int)samples.size();
@@ -157,13 +158,15 @@ PhyloHMM::DeviceBatch PhyloHMM::FlattenBatch(const std::vector<TreeSample>& samp
   b.er.resize((std::size_t)b.n * 6);
   b.pi.resize((std::size_t)b.n * 4);
   b.alpha.resize(b.n);
+  if (trees) trees->resize(b.n);
+  if (exported) exported->resize(b.n);
   // Rows are independent (parse, unroot at naive's neighbour, schedule): the GPU evaluates a few million
   // trees per second, one host core flattens a few ten thousand, so the rows are spread over the cores.
   auto flatten_rows = [&](int lo, int hi, int* max_depth) {
     for (int s = lo; s < hi; ++s) {
       const TreeSample& ts = samples[s];
       Require(ts.er.size() == 6 && ts.pi.size() == 4, "er must have 6 and pi 4 entries");
-      const TreeArrays tr = ParseNewick(ts.newick, xmsa_labels_, EPS);
+      TreeArrays tr = ParseNewick(ts.newick, xmsa_labels_, EPS);
       int32_t depth = 0;
       CheckHip(lh_schedule_tree(T, tr.children.data(), tr.root, b.ops.data() + (std::size_t)s * (T - 2) * 4, &depth),
                "lh_schedule_tree");
@@ -172,6 +175,8 @@ PhyloHMM::DeviceBatch PhyloHMM::FlattenBatch(const std::vector<TreeSample>& samp
       std::copy(ts.er.begin(), ts.er.end(), b.er.begin() + (std::size_t)s * 6);
       std::copy(ts.pi.begin(), ts.pi.end(), b.pi.begin() + (std::size_t)s * 4);
       b.alpha[s] = ts.alpha;
+      if (exported) (*exported)[s] = ExportNewick(tr, xmsa_labels_);
+      if (trees) (*trees)[s] = std::move(tr);
     }
   };
   const int hw = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
@@ -256,7 +261,10 @@ void PhyloHMM::WriteOutputLine(std::ofstream& outfile) const {
   outfile << iteration_ << "\t" << rb_loglikelihood_ << "\t" << prior_ << "\t" << alpha_ << "\t";
   for (auto er : er_) outfile << er << "\t";
   for (auto pi : pi_) outfile << pi << "\t";
-  outfile << ExportNewick(tree_, xmsa_labels_) << "\t";
+  if (pending_newick_)
+    outfile << *pending_newick_ << "\t";  // exported by FlattenBatch's workers
+  else
+    outfile << ExportNewick(tree_, xmsa_labels_) << "\t";
   for (auto sr : sr_) outfile << sr << "\t";
   outfile << lh_loglikelihood_ << "\t" << logweight_ << "\t" << naive_sequence_ << "\t";
   outfile << vgerm_state_str_samp_ << "\t" << vgerm_left_del_samp_ << "\t" << vgerm_right_del_samp_ << "\t"
@@ -356,7 +364,9 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
     const std::size_t m = std::min(kBatch, rows.size() - off);
     std::vector<TreeSample> samples;
     for (std::size_t i = 0; i < m; ++i) samples.push_back(rows[off + i].ts);
-    const DeviceBatch b = FlattenBatch(samples);
+    std::vector<TreeArrays> trees;
+    std::vector<std::string> exported;
+    const DeviceBatch b = FlattenBatch(samples, &trees, &exported);
     std::vector<double> ll(m), rates(m * num_rates), fwd(m * FS);
     std::vector<int32_t> sco(m * SS);
     lh_eval_outputs outs{rates.data(), nullptr, fwd.data(), sco.data()};
@@ -371,8 +381,9 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       alpha_ = r.ts.alpha;
       er_ = r.ts.er;
       pi_ = r.ts.pi;
-      tree_ = ParseNewick(r.ts.newick, xmsa_labels_, EPS);
+      tree_ = std::move(trees[i]);
       have_tree_ = true;
+      pending_newick_ = &exported[i];
       sr_.assign(rates.begin() + i * num_rates, rates.begin() + (i + 1) * num_rates);
       pending_forward_.assign(fwd.begin() + i * FS, fwd.begin() + (i + 1) * FS);
       pending_scalers_.assign(sco.begin() + i * SS, sco.begin() + (i + 1) * SS);
@@ -383,6 +394,7 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       naive_sequence_ = SampleNaiveSequence();
       if (line_ind == 0) WriteOutputHeaders(outfile);
       WriteOutputLine(outfile);
+      pending_newick_ = nullptr;
       line_ind += 1;
     }
   }

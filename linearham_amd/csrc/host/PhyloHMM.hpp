@@ -34,6 +34,7 @@ class PhyloHMM : public HMM {
   int num_rates_ = 1;
   double lh_loglikelihood_ = 0, logweight_ = 0;
   std::string naive_sequence_;
+  const std::string* pending_newick_ = nullptr;  // RunPipeline: this row's tree, already exported
 
   // raw device outputs of the pending evaluation (unpacked by RunForwardAlgorithm)
   std::vector<double> pending_forward_;
@@ -97,7 +98,10 @@ class PhyloHMM : public HMM {
     std::vector<int32_t> ops;
     std::vector<double> brlen, er, pi, alpha;
   };
-  DeviceBatch FlattenBatch(const std::vector<TreeSample>& samples) const;
+  /// `trees` / `exported` (optional): the parsed trees and their re-exported Newick strings, produced by the
+  /// same worker threads (RunPipeline needs both per row and would otherwise redo them one by one).
+  DeviceBatch FlattenBatch(const std::vector<TreeSample>& samples, std::vector<TreeArrays>* trees = nullptr,
+                           std::vector<std::string>* exported = nullptr) const;
   lh_family* family() {
     CreateFamily();
     return family_;
