@@ -4,6 +4,7 @@
 #include <cstring>
 #include <iomanip>
 #include <sstream>
+#include <random>
 #include <string>
 
 #include "PhyloHMM.hpp"
@@ -323,6 +324,38 @@ int lhh_phylo_sizes(void* h, int* n_tips, int* n_sites, int* n_xmsa, int* s_vd, 
     *g_total = (int)(p.vpadding_xmsa_inds().size() + p.vgerm_xmsa_inds().size() + p.dgerm_xmsa_inds().size() +
                      p.jgerm_xmsa_inds().size() + p.jpadding_xmsa_inds().size());
   });
+}
+
+// Self-test of DrawDiscreteSparse (HMM.hpp) against std::discrete_distribution on the full weight vector:
+// random sizes and sparsity patterns plus the corner cases (first / last weight zero or not, a single
+// non-zero weight, all weights zero, fewer than two weights).  Both generators start from the same seed
+// and must agree on every sampled index and stay in the same state.  Returns the number of disagreements.
+int lhh_selftest_sparse_draw(int seed, int trials) {
+  std::mt19937 gen(seed), a(seed + 1), b(seed + 1);
+  int bad = 0;
+  for (int t = 0; t < trials; ++t) {
+    const int size = (t % 17 == 0) ? 1 : 2 + (int)(gen() % 60);
+    std::vector<double> w(size, 0.0);
+    const int mode = (int)(gen() % 6);
+    for (int i = 0; i < size; ++i) {
+      const bool on = mode == 0 ? (gen() % 4 == 0) : mode == 1 ? (i == size - 1) : mode == 2 ? (i == 0)
+                    : mode == 3 ? false : mode == 4 ? (i != 0 && i != size - 1 && gen() % 3 == 0) : true;
+      if (on) w[i] = std::ldexp((double)(gen() % 100000 + 1), -(int)(gen() % 600));
+    }
+    std::vector<int> idx;
+    std::vector<double> nz;
+    for (int i = 0; i < size; ++i)
+      if (w[i] != 0.0) {
+        idx.push_back(i);
+        nz.push_back(w[i]);
+      }
+    std::discrete_distribution<int> dist;
+    dist.param(std::discrete_distribution<int>::param_type(w.data(), w.data() + size));
+    const int dense = dist(a);
+    const int sparse = DrawDiscreteSparse(b, idx.data(), nz.data(), (int)idx.size(), size);
+    if (dense != sparse || a != b) ++bad;
+  }
+  return bad;
 }
 
 }  // extern "C"

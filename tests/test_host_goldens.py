@@ -114,3 +114,15 @@ def test_yaml_reader_dialects(tmp_path, data_dir):
     a = host.germline_json(str(p), "D")
     b = host.germline_json(os.path.join(data_dir, "hmm_params", "IGHD_ex_star_01.yaml"), "D")
     assert a == b
+
+
+def test_sparse_draw_equals_discrete_distribution():
+    """HMM sampling draws with a sparse restatement of libstdc++'s std::discrete_distribution (only the
+    non-zero weights are visited): same index, same generator state, on 200 000 random and corner-case
+    weight vectors (C++ self-test in liblinearham_host.so)."""
+    import ctypes as C
+    from linearham_amd import host
+    lib = host.load_host()
+    lib.lhh_selftest_sparse_draw.argtypes = [C.c_int, C.c_int]
+    lib.lhh_selftest_sparse_draw.restype = C.c_int
+    assert lib.lhh_selftest_sparse_draw(7, 200000) == 0
