@@ -27,6 +27,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 peak (MI355X_MICROARCH.md)
 DEFAULT_BATCH = 24576          # tree samples per GPU per step (= one launch group of the C ABI)
+WORKLOADS = {
+    "config2": "BASELINE.json configs[2]: synthetic 100-leaf random tree, 400-site MSA, full V/D/J germline set "
+               "(200 V / 30 D / 12 J alleles), R=4 rate categories",
+    "config4": "BASELINE.json configs[4] shape on one GPU: synthetic 500-leaf random tree, 600-site MSA, full V/D/J "
+               "germline set, R=4 rate categories (not the headline workload)",
+    "small": "small synthetic family (development only, not the headline workload)",
+}
 PMC_PROFILE = "r01_v10_bench_pmc_per_launch.json"   # committed PMC passes of the default command
 
 
@@ -198,8 +205,7 @@ def main():
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: synthetic 100-leaf random tree, 400-site MSA, full "
-                                   "V/D/J germline set (200 V / 30 D / 12 J alleles), R=4 rate categories",
+            "config": {"workload": WORKLOADS[args.preset],
                        "preset": args.preset, "tree_samples_per_gpu_per_step": n, "n_tips": T,
                        "n_sites": sizes["n_sites"], "xmsa_columns": Cx, "site_patterns": n_pat.value,
                        "distinct_xmsa_columns": n_ucol.value, "S_vd": sizes["s_vd"],

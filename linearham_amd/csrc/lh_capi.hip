@@ -229,6 +229,8 @@ int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_
   return 0;
 }
 
+size_t scratch_doubles(int T) { return (size_t)std::max(T - 2, 1) * 32 + (T > 106 ? (size_t)T * 16 : 0); }
+
 int ensure_workspace(lh_family* f, int n, int R, int T) {
   Workspace& w = f->ws;
   if (n <= w.n_cap && R == w.R && T == w.T) return 0;
@@ -242,7 +244,9 @@ int ensure_workspace(lh_family* f, int n, int R, int T) {
   const int cap = std::max(n, 1);
   LH_HIP(hipMalloc((void**)&w.rates, sizeof(double) * cap * R));
   LH_HIP(hipMalloc((void**)&w.eig, sizeof(double) * cap * 36));
-  LH_HIP(hipMalloc((void**)&w.pmat, sizeof(double) * cap * R * (size_t)std::max(T - 2, 1) * 32));
+  // K1's scratch area per (sample, rate): the schedule's P-matrices and, for trees large enough that K1
+  // may keep the tip table there instead of in LDS, the tip table
+  LH_HIP(hipMalloc((void**)&w.pmat, sizeof(double) * cap * R * scratch_doubles(T)));
   LH_HIP(hipMalloc((void**)&w.site_lik, sizeof(double) * cap * R * 5 * std::max(L, (size_t)1)));
   LH_HIP(hipMalloc((void**)&w.site_scal, sizeof(int32_t) * cap * R * std::max(L, (size_t)1)));
   w.n_cap = cap;
@@ -672,7 +676,10 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
   if ((size_t)T * 128 > 160 * 1024) return fail("lh_eval_batch: too many tips for the LDS tip table");
   if (!ops || !brlen || !er || !pi || !alpha || !loglik) return fail("lh_eval_batch: null array");
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-  const int chunk = std::min<int>(n, kChunk);
+  // launch groups of at most kChunk samples and at most ~6 GB of per-sample workspace
+  const size_t per_sample = sizeof(double) * R * (scratch_doubles(T) + 6 * (size_t)std::max(f->host.n_prune, 1));
+  const int by_memory = (int)std::max<size_t>(1024, ((size_t)6 << 30) / per_sample);
+  const int chunk = std::min<int>(n, std::min(kChunk, by_memory));
   if (ensure_workspace(f, chunk, R, T)) return 1;
   Workspace& w = f->ws;
   const size_t nodes = 2 * (size_t)T - 2, n_ops = (size_t)T - 2, C = f->host.n_xmsa;

@@ -272,7 +272,7 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
 // site_lik[n][1][5][L] then holds the rate mixture (equal weights, scalers aligned to the smallest, the
 // arithmetic K2a would do) and K2a runs with a single "rate".  A quarter of the output traffic, and K2a's
 // bandwidth-bound assembly shrinks to a quarter.  Used when R * wpr <= 8 waves and the R tip tables fit.
-template <int kDepth, bool kTwo, bool kN, bool kFused>
+template <int kDepth, bool kTwo, bool kN, bool kFused, bool kTipGlobal = false>
 __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, const uint8_t* __restrict__ msa, int L,
                                            int T, int n_ops, const int32_t* __restrict__ ops,
                                            const double* __restrict__ brlen, const double* __restrict__ rates,
@@ -287,9 +287,14 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
   const int nthr = kFused ? wpr * 64 : (int)blockDim.x;       // threads working on this rate
   const int rtid = kFused ? tid - rate * nthr : tid;
   const int sample = blockIdx.z;
-  double* tiptab = reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);  // [T][4][4]
+  // scratch area of one (sample, rate): the schedule's P-matrices, followed -- for large trees only, whose
+  // tip table (128 B per tip) would leave room for just one or two workgroups in a CU's LDS -- by the tip
+  // table, which the walk then reads through the vector cache instead
+  const size_t pm_stride = (size_t)(T - 2) * 32 + (kTipGlobal ? (size_t)T * 16 : 0);
+  const size_t pm_off = ((size_t)sample * R + rate) * pm_stride;
+  double* tiptab = kTipGlobal ? pmat_w + pm_off + (size_t)(T - 2) * 32
+                              : reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);  // [T][4][4]
   const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
-  const size_t pm_off = ((size_t)sample * R + rate) * (size_t)(T - 2) * 32;
 
   // Prologue (formerly a kernel of its own): the P-matrices of this (sample, rate).
   //   P = I + U expm1(lambda t r) U^-1   (pll_update_prob_matrices [3P])
@@ -451,6 +456,12 @@ LH_PRUNE_KERNEL(prune_kernel_w5, 5)
 LH_PRUNE_KERNEL(prune_kernel_w4, 4)
 #undef LH_PRUNE_KERNEL
 
+// Large trees: tip table in the scratch area instead of LDS (see prune_body), five waves per SIMD.
+template <int kDepth, bool kN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) prune_kernel_tg(LH_PRUNE_PARAMS) {
+  prune_body<kDepth, true, kN, false, true>(LH_PRUNE_ARGS);
+}
+
 // Deep stacks leave no room for two sites per lane.
 template <int kDepth>
 __global__ void __launch_bounds__(512) prune_kernel_deep(LH_PRUNE_PARAMS) {
@@ -494,7 +505,9 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   const size_t pad = (size_t)n2 * 128 + (size_t)n1 * 64;
   const size_t fused_lds = std::max((size_t)R * tip_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
   const bool fused = two && R * wpr <= 8 && fused_lds <= 53 * 1024;
-  const size_t lds = fused ? fused_lds : tip_bytes;
+  // large trees: with the tip table in LDS fewer than three waves per SIMD would be resident
+  const bool tip_global = two && !fused && (160 * 1024 / tip_bytes) * wpr / 4 < 3;
+  const size_t lds = fused ? fused_lds : tip_global ? 0 : tip_bytes;
   const int wg_waves = fused ? R * wpr : wpr;
   dim3 grid(tiles, fused ? 1 : R, n), block(64 * wg_waves);
   const int n_ops = T - 2;
@@ -507,7 +520,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
                        eig, pmat, (const double*)pmat, pi, site_lik, site_scal);                              \
   }
   // waves per SIMD that the LDS of the resident workgroups allows (160 KB per CU, 4 SIMDs)
-  const int lds_waves = (int)((160 * 1024 / std::max<size_t>(lds, 1)) * wg_waves / 4);
+  const int lds_waves = lds == 0 ? 8 : (int)((160 * 1024 / lds) * wg_waves / 4);
   // alignments that never mix N with bases take the instantiation without N handling in the look-ups
 #define LH_LAUNCH_BUDGET(D, N, F)                                                 \
   {                                                                               \
@@ -518,12 +531,14 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
     else                                                                          \
       LH_LAUNCH_K((prune_kernel_w4<D, N, F>))                                     \
   }
-#define LH_LAUNCH_SHALLOW(D, N)      \
-  {                                  \
-    if (fused)                       \
-      LH_LAUNCH_BUDGET(D, N, true)   \
-    else                             \
-      LH_LAUNCH_BUDGET(D, N, false)  \
+#define LH_LAUNCH_SHALLOW(D, N)             \
+  {                                         \
+    if (fused)                              \
+      LH_LAUNCH_BUDGET(D, N, true)          \
+    else if (tip_global)                    \
+      LH_LAUNCH_K((prune_kernel_tg<D, N>))  \
+    else                                    \
+      LH_LAUNCH_BUDGET(D, N, false)         \
   }
   if (max_depth <= 3 && !fam.msa_mixed_n)
     LH_LAUNCH_SHALLOW(3, false)
