@@ -138,7 +138,7 @@ void PhyloHMM::InitializePhyloParametersFromString(const std::string& newick, co
                                                    const std::vector<double>& pi, double alpha, int num_rates) {
   Require(er.size() == 6 && pi.size() == 4, "er must have 6 and pi 4 entries");
   Require(num_rates >= 1, "num_rates must be positive");
-  tree_ = ParseNewick(newick, xmsa_labels_, EPS);
+  tree_ = ParseNewick(newick, xmsa_labels_, EPS, true);
   have_tree_ = true;
   er_ = er;
   pi_ = pi;
@@ -166,7 +166,7 @@ PhyloHMM::DeviceBatch PhyloHMM::FlattenBatch(const std::vector<TreeSample>& samp
     for (int s = lo; s < hi; ++s) {
       const TreeSample& ts = samples[s];
       Require(ts.er.size() == 6 && ts.pi.size() == 4, "er must have 6 and pi 4 entries");
-      TreeArrays tr = ParseNewick(ts.newick, xmsa_labels_, EPS);
+      TreeArrays tr = ParseNewick(ts.newick, xmsa_labels_, EPS, exported != nullptr);
       int32_t depth = 0;
       CheckHip(lh_schedule_tree(T, tr.children.data(), tr.root, b.ops.data() + (std::size_t)s * (T - 2) * 4, &depth),
                "lh_schedule_tree");
@@ -175,7 +175,10 @@ PhyloHMM::DeviceBatch PhyloHMM::FlattenBatch(const std::vector<TreeSample>& samp
       std::copy(ts.er.begin(), ts.er.end(), b.er.begin() + (std::size_t)s * 6);
       std::copy(ts.pi.begin(), ts.pi.end(), b.pi.begin() + (std::size_t)s * 4);
       b.alpha[s] = ts.alpha;
-      if (exported) (*exported)[s] = ExportNewick(tr, xmsa_labels_);
+      if (exported) {
+        (*exported)[s] = ExportNewick(tr, xmsa_labels_);
+        tr.as_parsed = std::string();
+      }
       if (trees) (*trees)[s] = std::move(tr);
     }
   };

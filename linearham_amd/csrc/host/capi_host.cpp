@@ -358,4 +358,29 @@ int lhh_selftest_sparse_draw(int seed, int trials) {
   return bad;
 }
 
+// Newick ingest + re-export without a device: `labels` is a '\n'-separated list (first = naive).  *out is the
+// output table's tree column (ExportNewick); children/brlen/root may be NULL.
+int lhh_newick_roundtrip(const char* newick, const char* labels, const char** out, int32_t* children,
+                         double* brlen, int32_t* root) {
+  return Guard([&] {
+    std::vector<std::string> labs;
+    std::string cur;
+    for (const char* c = labels; *c; ++c) {
+      if (*c == '\n') {
+        labs.push_back(cur);
+        cur.clear();
+      } else {
+        cur.push_back(*c);
+      }
+    }
+    if (!cur.empty()) labs.push_back(cur);
+    const TreeArrays tr = ParseNewick(newick, labs, EPS, true);
+    g_out = ExportNewick(tr, labs);
+    *out = g_out.c_str();
+    if (children) std::copy(tr.children.begin(), tr.children.end(), children);
+    if (brlen) std::copy(tr.brlen.begin(), tr.brlen.end(), brlen);
+    if (root) *root = tr.root;
+  });
+}
+
 }  // extern "C"

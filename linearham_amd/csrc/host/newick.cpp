@@ -75,7 +75,7 @@ struct NewickParser {
         ++pos;
         break;
       }
-      parse_label();  // inner label ignored
+      nodes[id].label = parse_label();  // inner label: kept for the export only
     } else {
       nodes[id].label = parse_label();
       if (nodes[id].label.empty()) fail("empty tip label");
@@ -100,9 +100,46 @@ std::string StripComments(const std::string& s) {
   return o;
 }
 
+// pll_utree_export_newick(GetVirtualRoot(tree), NULL) [libpll-2, third party; src/PhyloHMM.cpp:299-300] on a
+// tree that pll_utree_parse_newick_string built: libpll's parser hangs the top level's three subtrees on
+// the virtual root's ring in input order and every inner node's two subtrees likewise, and the exporter
+// walks the rings in that order, so the output is the input's own nesting and order with tips printed as
+// "label:%f", inner nodes as "(a,b)label:%f" and the top level as "(a,b,c)label;" (its length dropped),
+// missing and zero lengths already replaced (pt::pll::set_missing_branch_length).
+std::string ExportAsParsed(const std::vector<PNode>& N, int top, double eps) {
+  std::string out;
+  out.reserve(N.size() * 24);
+  char b[64];
+  struct Fr {
+    int node;
+    std::size_t next_kid;
+  };
+  std::vector<Fr> stack{{top, 0}};
+  while (!stack.empty()) {
+    Fr& f = stack.back();
+    const PNode& n = N[f.node];
+    if (f.next_kid < n.kids.size()) {
+      out.push_back(f.next_kid == 0 ? '(' : ',');
+      const int k = n.kids[f.next_kid++];
+      stack.push_back({k, 0});
+      continue;
+    }
+    if (!n.kids.empty()) out.push_back(')');
+    out += n.label;
+    if (f.node != top) {
+      std::snprintf(b, sizeof b, ":%f", (n.len < 0.0 || n.len == 0.0) ? eps : n.len);
+      out += b;
+    }
+    stack.pop_back();
+  }
+  out.push_back(';');
+  return out;
+}
+
 }  // namespace
 
-TreeArrays ParseNewick(const std::string& text, const std::vector<std::string>& labels, double eps) {
+TreeArrays ParseNewick(const std::string& text, const std::vector<std::string>& labels, double eps,
+                       bool with_export) {
   const std::string clean = StripComments(text);
   NewickParser p(clean);
   const int top = p.parse_node(0);
@@ -191,13 +228,16 @@ TreeArrays ParseNewick(const std::string& text, const std::vector<std::string>& 
     if (slot != 2) throw std::runtime_error("newick: inner node of degree < 3");
   }
   if (next != 2 * T - 2) throw std::runtime_error("newick: not an unrooted binary tree");
+  // a rooted (bifurcating) top level is something libpll's unrooted parser rejects: no libpll order exists
+  if (with_export && N[top].kids.size() == 3) out.as_parsed = ExportAsParsed(N, top, eps);
   return out;
 }
 
 std::string ExportNewick(const TreeArrays& tr, const std::vector<std::string>& labels) {
+  if (!tr.as_parsed.empty()) return tr.as_parsed;
+  // rooted input (accepted here, rejected by the reference): the unrooted tree, trifurcating at naive's neighbour
   const int T = tr.n_tips;
   char buf[64];
-  // recursive lambda via explicit stack would obscure; trees are at most a few thousand deep
   struct Rec {
     const TreeArrays& tr;
     const std::vector<std::string>& labels;

@@ -16,15 +16,19 @@ struct TreeArrays {
   int root = -1;
   std::vector<int> children;   // [(T-2)*2]
   std::vector<double> brlen;   // [2T-2], branch above each node (root entry unused = 0)
+  std::string as_parsed;       // the tree as libpll would re-export it (input order; see ExportNewick)
 };
 
 /// Strips "[&index=N]" (and any other bracket comment), parses the unrooted tree (trifurcating top
 /// level, or a bifurcating one whose two root branches are merged), replaces missing/zero branch
 /// lengths by `eps`, and maps tip labels onto `labels`.  Throws std::runtime_error on malformed
 /// input or label mismatch (the reference does not check the libpll return value, :421).
-TreeArrays ParseNewick(const std::string& text, const std::vector<std::string>& labels, double eps);
+/// `with_export` also fills TreeArrays::as_parsed (the output table's tree column).
+TreeArrays ParseNewick(const std::string& text, const std::vector<std::string>& labels, double eps,
+                       bool with_export = false);
 
-/// Newick string with "%f" branch lengths (libpll's export format), trifurcating at `root`.
+/// The tree column of the output table (pll_utree_export_newick at src/PhyloHMM.cpp:299-300): the input's
+/// own nesting and order, "%f" branch lengths, missing/zero lengths replaced, comments gone.
 std::string ExportNewick(const TreeArrays& tree, const std::vector<std::string>& labels);
 
 }  // namespace linearham

@@ -37,6 +37,15 @@ def germline_json(path, gtype):
     return json.loads(out.value.decode())
 
 
+def newick_roundtrip(newick, labels):
+    """Parse a Newick string as the host does and return the output table's tree column
+    (PhyloHMM::WriteOutputLine, src/PhyloHMM.cpp:299-300).  No device needed."""
+    out = C.c_char_p()
+    _check(load_host().lhh_newick_roundtrip(newick.encode(), "\n".join(labels).encode(), C.byref(out), None, None,
+                                            None))
+    return out.value.decode()
+
+
 class _HMM:
     def __init__(self, handle):
         self.h = handle

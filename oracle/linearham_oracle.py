@@ -946,6 +946,60 @@ def parse_newick(text, eps=EPS):
     return Tree(labels, adj)
 
 
+def export_newick(text, eps=EPS):
+    """The tree column of the output table: pll_utree_export_newick(GetVirtualRoot(tree_), NULL)
+    (src/PhyloHMM.cpp:299-300) [libpll-2, 3P] applied to what pll_utree_parse_newick_string built from
+    `text` (src/PhyloHMM.cpp:417-422).  libpll's parser hangs the three top-level subtrees on the virtual
+    root's ring in input order (and each inner node's two subtrees likewise); its exporter walks the rings
+    in that order and prints tips as "label:%f", inner nodes as "(a,b)label:%f" and the top level as
+    "(a,b,c)label;".  Published algorithm restated -- libpll itself is absent here."""
+    text = re.sub(r"\[[^\]]*\]", "", text).strip()
+    pos = [0]
+
+    def ws():
+        while pos[0] < len(text) and text[pos[0]].isspace():
+            pos[0] += 1
+
+    def length():
+        ws()
+        if pos[0] < len(text) and text[pos[0]] == ":":
+            m = re.match(r":\s*([-+0-9.eE]+)", text[pos[0]:])
+            pos[0] += m.end()
+            return float(m.group(1))
+        return None
+
+    def fmt(l):
+        return ":%f" % (eps if (l is None or l == 0.0) else l)
+
+    def node(top):
+        ws()
+        if text[pos[0]] == "(":
+            pos[0] += 1
+            parts = []
+            while True:
+                parts.append(node(False))
+                ws()
+                if text[pos[0]] == ",":
+                    pos[0] += 1
+                    continue
+                assert text[pos[0]] == ")"
+                pos[0] += 1
+                break
+            ws()
+            m = re.match(r"[^,():;\s]*", text[pos[0]:])
+            pos[0] += m.end()
+            l = length()
+            if top:
+                assert len(parts) == 3, "libpll's unrooted parser needs a trifurcating top level"
+                return "(" + ",".join(parts) + ")" + m.group(0) + ";"
+            return "(" + ",".join(parts) + ")" + m.group(0) + fmt(l)
+        m = re.match(r"[^,():;\s]+", text[pos[0]:])
+        pos[0] += m.end()
+        return m.group(0) + fmt(length())
+
+    return node(True)
+
+
 def gamma_rates_mean(alpha, R):
     """pll_compute_gamma_cats(alpha, R, rates, PLL_GAMMA_RATES_MEAN) [3P] (src/PhyloHMM.cpp:360):
     means of R equiprobable categories of Gamma(shape alpha, rate alpha)."""

@@ -126,3 +126,33 @@ def test_sparse_draw_equals_discrete_distribution():
     lib.lhh_selftest_sparse_draw.argtypes = [C.c_int, C.c_int]
     lib.lhh_selftest_sparse_draw.restype = C.c_int
     assert lib.lhh_selftest_sparse_draw(7, 200000) == 0
+
+
+def test_newick_export_is_libpll_order(data_dir, tmp_path):
+    """The output table's tree column (pll_utree_export_newick, src/PhyloHMM.cpp:299-300): the input's own
+    nesting and order, "%f" lengths, `[&index=N]` comments gone, missing / zero lengths replaced by 1e-6.
+    Known answers written out by hand from libpll's export format, then host == oracle on synthetic
+    RevBayes rows."""
+    from linearham_amd import host
+    from oracle import linearham_oracle as orc
+    from tools import synth_family as sf
+    newton = open(os.path.join(data_dir, "newton.tree")).read()
+    want = "((0:0.200000,1:0.400000):0.600000,naive:0.300000,2:0.500000);"
+    assert orc.export_newick(newton) == want
+    assert host.newick_roundtrip(newton, ["naive", "0", "1", "2"]) == want
+    odd = "(naive[&index=2]:0.008054984868,s0[&index=3]:0,(s3[&index=5],s4:1e-7)lab[&index=4]:1.5e-3)[&index=1]:0.0;"
+    want = "(naive:0.008055,s0:0.000001,(s3:0.000001,s4:0.000000)lab:0.001500);"
+    assert orc.export_newick(odd) == want
+    assert host.newick_roundtrip(odd, ["naive", "s0", "s3", "s4"]) == want
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_samples=6), out)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    labels = orc.parse_newick(rows[0]["tree"]).labels
+    labels = ["naive"] + sorted(l for l in labels if l != "naive")
+    for r in rows:
+        assert host.newick_roundtrip(r["tree"], labels) == orc.export_newick(r["tree"])
+    # a rooted (bifurcating) top level has no libpll order (its unrooted parser rejects it): same tree, unrooted
+    rooted = "((naive:0.1,a:0.2):0.05,(b:0.3,c:0.4):0.05);"
+    t1 = orc.parse_newick(host.newick_roundtrip(rooted, ["naive", "a", "b", "c"]))
+    t2 = orc.parse_newick(rooted)
+    assert abs(sum(l for a in t1.adj for _, l in a) - sum(l for a in t2.adj for _, l in a)) < 1e-5
