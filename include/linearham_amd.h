@@ -18,6 +18,8 @@
  *                            for a whole batch of RevBayes tree samples at once.
  *   lh_forward_batch      <- HMM::LogLikelihood on caller-supplied emissions (SimpleHMM,
  *                            src/SimpleHMM.cpp:26-39 + src/HMM.cpp:345-354).
+ *   lh_asr_batch[_device] <- the per-tree body of scripts/run_bootstrap_asr_ess.R:48-104
+ *                            (phylomd::phylo.likelihood per rate, rate draw, phylomd::asr.sim).
  *
  * All functions return 0 on success and a nonzero status otherwise; lh_last_error() gives the
  * message (the C++ host wrapper turns it into std::runtime_error, mirroring
@@ -147,11 +149,41 @@ int lh_eval_batch_device(lh_family* fam, int32_t n, int32_t n_tips, int32_t max_
 int lh_forward_batch(lh_family* fam, int32_t n, const double* em, double* loglik,
                      const lh_eval_outputs* outs);
 
+/* Ancestral-sequence sampling (scripts/run_bootstrap_asr_ess.R:48-104) for n tree samples of the family:
+ * per alignment site, draw a rate category with the likelihoods of the column (naive base on the `naive`
+ * tip) on the rate-scaled trees, then draw the states of all inner nodes jointly given the tips on the
+ * chosen tree.
+ *   ops, brlen, er, pi   as for lh_eval_batch
+ *   rates  [n][R]        the site rates of the sample (the sr[] columns of the pipeline output)
+ *   naive  [n][L]        the sample's NaiveSequence, A,C,G,T,N = 0..4
+ *   seed, first_sample   random numbers are Philox4x32-10 with key = seed and counter =
+ *                        (site, draw, first_sample + i): draw 0 = rate category, 1 = root (naive's
+ *                        neighbour), 2 + (v - T) = inner node v; a draw picks the first category whose
+ *                        running weight sum exceeds u * total
+ *   anc    [n][T-2][L]   state 0..3 of inner node T + i (lh_schedule_tree numbering) at every site
+ *   rate_choice [n][L]   drawn category per site (may be NULL)
+ * The extra root node that ape::root(..., resolve.root = TRUE) puts on the naive branch (:53) lies at
+ * distance 0 from naive's neighbour and has that node's state.  Tips keep their observed characters. */
+int lh_asr_batch(lh_family* fam, int32_t n, int32_t n_tips, int32_t max_depth, const int32_t* ops,
+                 const double* brlen, const double* er, const double* pi, const double* rates,
+                 int32_t num_rates, const uint8_t* naive, uint64_t seed, uint64_t first_sample,
+                 uint8_t* anc, uint8_t* rate_choice);
+
+/* Same with every array resident on the handle's device; enqueued on `hip_stream` without synchronising. */
+int lh_asr_batch_device(lh_family* fam, int32_t n, int32_t n_tips, int32_t max_depth, const int32_t* ops,
+                        const double* brlen, const double* er, const double* pi, const double* rates,
+                        int32_t num_rates, const uint8_t* naive, uint64_t seed, uint64_t first_sample,
+                        uint8_t* anc, uint8_t* rate_choice, void* hip_stream);
+
 /* Timing of the kernels of the last lh_eval_batch_device call sequence, measured with HIP events
  * on the launch stream when enabled (ms per kernel family: model, prune, forward). */
 int lh_profile_enable(lh_family* fam, int enable);
 int lh_profile_read(lh_family* fam, double* ms_model, double* ms_prune, double* ms_forward,
                     int64_t* n_launches);
+
+/* Time of the sampling kernel (K3) over the lh_asr_batch_device launches made while profiling was
+ * enabled (HIP events on the launch stream); resets the counters. */
+int lh_asr_profile_read(lh_family* fam, double* ms_sampling, int64_t* n_launches);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,8 @@ class _EvalOutputs(C.Structure):
 
 EXPORTS = ["lh_last_error", "lh_device_count", "lh_family_create", "lh_family_destroy",
            "lh_forward_size", "lh_scaler_size", "lh_family_info", "lh_schedule_tree", "lh_eval_batch",
-           "lh_eval_batch_device", "lh_forward_batch", "lh_profile_enable", "lh_profile_read"]
+           "lh_eval_batch_device", "lh_forward_batch", "lh_asr_batch", "lh_asr_batch_device",
+           "lh_profile_enable", "lh_profile_read", "lh_asr_profile_read"]
 
 
 def library_path():
@@ -74,6 +75,12 @@ class HipLibrary:
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p, C.POINTER(_EvalOutputs), C.c_void_p]
         lib.lh_forward_batch.argtypes = [C.c_void_p, C.c_int32, c_f64p, c_f64p, C.POINTER(_EvalOutputs)]
+        lib.lh_asr_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f64p, c_f64p, c_f64p,
+                                     c_f64p, C.c_int32, c_u8p, C.c_uint64, C.c_uint64, c_u8p, c_u8p]
+        lib.lh_asr_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64,
+                                            C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.lh_asr_profile_read.argtypes = [C.c_void_p, c_f64p, C.POINTER(C.c_int64)]
         lib.lh_profile_enable.argtypes = [C.c_void_p, C.c_int]
         lib.lh_profile_read.argtypes = [C.c_void_p, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_int64)]
 
@@ -259,6 +266,21 @@ class Family:
         self.hip.check(self.hip.lib.lh_forward_batch(self.handle, n, em.ctypes.data_as(c_f64p),
                                                      ll.ctypes.data_as(c_f64p), C.byref(outs)))
         return ll, res
+
+    def asr_batch(self, n_tips, max_depth, ops, brlen, er, pi, rates, naive, seed, first_sample=0):
+        """lh_asr_batch: returns (anc [n][T-2][L] uint8, rate_choice [n][L] uint8)."""
+        ops, brlen, er, pi, rates = _i32(ops), _f64(brlen), _f64(er), _f64(pi), _f64(rates)
+        naive = np.ascontiguousarray(naive, dtype=np.uint8)
+        n, L = naive.shape
+        assert ops.shape == (n, n_tips - 2, 4) and brlen.shape == (n, 2 * n_tips - 2)
+        assert er.shape == (n, 6) and pi.shape == (n, 4) and rates.shape[0] == n
+        anc = np.zeros((n, n_tips - 2, L), dtype=np.uint8)
+        choice = np.zeros((n, L), dtype=np.uint8)
+        self.hip.check(self.hip.lib.lh_asr_batch(
+            self.handle, n, n_tips, max_depth, ops.ctypes.data_as(c_i32p), brlen.ctypes.data_as(c_f64p),
+            er.ctypes.data_as(c_f64p), pi.ctypes.data_as(c_f64p), rates.ctypes.data_as(c_f64p), rates.shape[1],
+            naive.ctypes.data_as(c_u8p), seed, first_sample, anc.ctypes.data_as(c_u8p), choice.ctypes.data_as(c_u8p)))
+        return anc, choice
 
     def profile_enable(self, on=True):
         self.hip.check(self.hip.lib.lh_profile_enable(self.handle, int(on)))

@@ -39,6 +39,16 @@ struct ForwardWs {  // K2a -> K2b hand-off, sized by the largest batch seen
   int32_t* gcnt = nullptr;
 };
 
+struct AsrWs {  // K3's CLV area and the device copies of lh_asr_batch's host arrays (grow-only)
+  size_t clv_cap = 0;
+  double* clv = nullptr;
+  size_t cap[8] = {0};
+  void* ptr[8] = {nullptr};
+  double ms = 0;          // K3 time of the profiled launches (lh_profile_enable)
+  int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+
 struct Staging {  // device copies of host inputs/outputs for the host-pointer entry points
   size_t cap[10] = {0};
   void* ptr[10] = {nullptr};
@@ -67,6 +77,7 @@ struct lh_family {
   size_t arena_left = 0;
   Workspace ws;
   ForwardWs fws;
+  AsrWs asr;
   Staging st;
   HostPipe pipe;
   bool profile = false;
@@ -400,6 +411,7 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
       }
       h.n_ucol = (int32_t)u_pat.size();
       rc = rc || upload(f, pmsa.data(), pmsa.size(), &h.msa);
+      rc = rc || upload(f, pat_of_site.data(), pat_of_site.size(), &h.site_pat);
       rc = rc || upload(f, u_pat.data(), u_pat.size(), &h.u_pat);
       rc = rc || upload(f, u_base.data(), u_base.size(), &h.u_base);
       rc = rc || upload(f, ucol.data(), C, &h.ucol_of_col);
@@ -412,6 +424,7 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
     h.msa_mixed_n = 0;
     h.n_ucol = (int32_t)C;
     rc = rc || upload<uint8_t>(f, nullptr, 0, &h.msa);
+    rc = rc || upload<int32_t>(f, nullptr, 0, &h.site_pat);
     rc = rc || upload<int32_t>(f, nullptr, 0, &h.u_pat);
     rc = rc || upload<uint8_t>(f, nullptr, 0, &h.u_base);
     rc = rc || upload(f, ucol.data(), C, &h.ucol_of_col);
@@ -503,6 +516,13 @@ void lh_family_destroy(lh_family* f) {
     if (b) (void)hipFree(b);
   for (void* p : f->st.ptr)
     if (p) (void)hipFree(p);
+  if (f->asr.clv) (void)hipFree(f->asr.clv);
+  for (void* p : f->asr.ptr)
+    if (p) (void)hipFree(p);
+  for (auto& ev : f->asr.events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
   for (EventSet& es : f->events)
     for (hipEvent_t e : es.e) (void)hipEventDestroy(e);
   for (void* p : f->pipe.pinned)
@@ -659,6 +679,26 @@ int lh_profile_read(lh_family* f, double* ms_model, double* ms_prune, double* ms
   if (n_launches) *n_launches = f->launches;
   f->ms[0] = f->ms[1] = f->ms[2] = 0;
   f->launches = 0;
+  return 0;
+}
+
+int lh_asr_profile_read(lh_family* f, double* ms_sampling, int64_t* n_launches) {
+  if (!f) return fail("null family");
+  AsrWs& a = f->asr;
+  for (auto& ev : a.events) {
+    LH_HIP(hipEventSynchronize(ev.second));
+    float ms = 0;
+    LH_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+    a.ms += ms;
+    ++a.launches;
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  a.events.clear();
+  if (ms_sampling) *ms_sampling = a.ms;
+  if (n_launches) *n_launches = a.launches;
+  a.ms = 0;
+  a.launches = 0;
   return 0;
 }
 
@@ -844,6 +884,125 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
     if (outs->scaler_counts)
       LH_HIP(hipMemcpy(outs->scaler_counts, d_outs.scaler_counts, sizeof(int32_t) * SS * n,
                        hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const int32_t* ops,
+                        const double* brlen, const double* er, const double* pi, const double* rates, int32_t R,
+                        const uint8_t* naive, uint64_t seed, uint64_t first_sample, uint8_t* anc,
+                        uint8_t* rate_choice, void* hip_stream) {
+  if (!f) return fail("lh_asr_batch: null family");
+  if (n < 0) return fail("lh_asr_batch: negative batch size");
+  if (n == 0) return 0;
+  if (f->host.n_seqs < 1) return fail("lh_asr_batch: family was created without an MSA");
+  if (T != f->host.n_seqs + 1) return fail("lh_asr_batch: n_tips must equal n_seqs + 1 (naive)");
+  if (T < 3) return fail("lh_asr_batch: need at least 3 tips");
+  if (R < 1 || R > 64) return fail("lh_asr_batch: num_rates out of range");
+  if (max_depth < 0 || max_depth > 16) return fail("lh_asr_batch: max_depth out of range");
+  if ((size_t)T * 128 > 160 * 1024) return fail("lh_asr_batch: too many tips for the LDS tip table");
+  if (lh::asr_lds_bytes(T, f->host.n_sites) > 160 * 1024)
+    return fail("lh_asr_batch: tree / alignment too large for the sampling kernel's LDS tables");
+  if (!ops || !brlen || !er || !pi || !rates || !naive || !anc) return fail("lh_asr_batch: null array");
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const size_t nodes = 2 * (size_t)T - 2, n_ops = (size_t)T - 2, L = f->host.n_sites;
+  // launch groups: at most ~8 GB of CLV area (32 B per inner node and site) plus K1's workspace
+  const size_t clv_per_sample = sizeof(double) * n_ops * 4 * L;
+  const size_t k1_per_sample = sizeof(double) * R * (scratch_doubles(T) + 6 * (size_t)std::max(f->host.n_prune, 1));
+  const int by_memory = (int)std::max<size_t>(64, ((size_t)8 << 30) / (clv_per_sample + k1_per_sample));
+  const int chunk = std::min<int>(n, std::min(8192, by_memory));
+  if (ensure_workspace(f, chunk, R, T)) return 1;
+  AsrWs& aw = f->asr;
+  if (aw.clv_cap < clv_per_sample * chunk) {
+    LH_HIP(hipDeviceSynchronize());
+    if (aw.clv) LH_HIP(hipFree(aw.clv));
+    aw.clv = nullptr;
+    aw.clv_cap = 0;
+    LH_HIP(hipMalloc((void**)&aw.clv, clv_per_sample * chunk));
+    aw.clv_cap = clv_per_sample * chunk;
+  }
+  Workspace& w = f->ws;
+  for (int off = 0; off < n; off += chunk) {
+    const int m = std::min(chunk, n - off);
+    const double* r_m = rates + (size_t)off * R;
+    const double* pi_m = pi + (size_t)off * 4;
+    const int32_t* ops_m = ops + (size_t)off * n_ops * 4;
+    const double* bl_m = brlen + (size_t)off * nodes;
+    lh::launch_gtr_setup(m, er + (size_t)off * 6, pi_m, w.eig, stream);
+    // per-rate planes: K1 must not mix the categories here
+    const int planes = lh::launch_prune(f->host, m, R, T, max_depth, ops_m, bl_m, r_m, w.eig, w.pmat, pi_m,
+                                        w.site_lik, w.site_scal, stream, false);
+    if (planes != R && f->host.n_prune > 0) return fail("lh_asr_batch: internal error (rate planes were mixed)");
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (f->profile) {
+      LH_HIP(hipEventCreate(&ev.first));
+      LH_HIP(hipEventCreate(&ev.second));
+      LH_HIP(hipEventRecord(ev.first, stream));
+    }
+    if (lh::launch_asr(f->host, m, R, T, ops_m, bl_m, r_m, w.eig, pi_m, w.site_lik, w.site_scal,
+                       naive + (size_t)off * L, seed, first_sample + (uint64_t)off, aw.clv, anc + (size_t)off * n_ops * L,
+                       rate_choice ? rate_choice + (size_t)off * L : nullptr, stream))
+      return fail("lh_asr_batch: launch failed");
+    if (f->profile) {
+      LH_HIP(hipEventRecord(ev.second, stream));
+      aw.events.push_back(ev);
+    }
+    LH_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+static int asr_stage(lh_family* f, int slot, size_t bytes, void** out) {
+  AsrWs& a = f->asr;
+  if (bytes > a.cap[slot]) {
+    if (a.ptr[slot]) LH_HIP(hipFree(a.ptr[slot]));
+    a.ptr[slot] = nullptr;
+    a.cap[slot] = 0;
+    LH_HIP(hipMalloc(&a.ptr[slot], bytes));
+    a.cap[slot] = bytes;
+  }
+  *out = a.ptr[slot];
+  return 0;
+}
+
+int lh_asr_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const int32_t* ops, const double* brlen,
+                 const double* er, const double* pi, const double* rates, int32_t R, const uint8_t* naive,
+                 uint64_t seed, uint64_t first_sample, uint8_t* anc, uint8_t* rate_choice) {
+  if (!f) return fail("lh_asr_batch: null family");
+  if (n < 0) return fail("lh_asr_batch: negative batch size");
+  if (n == 0) return 0;
+  if (T < 3 || T != f->host.n_seqs + 1) return fail("lh_asr_batch: n_tips must equal n_seqs + 1 (naive)");
+  if (R < 1 || R > 64) return fail("lh_asr_batch: num_rates out of range");
+  if (max_depth < 0 || max_depth > 16) return fail("lh_asr_batch: max_depth out of range");
+  if (!ops || !brlen || !er || !pi || !rates || !naive || !anc) return fail("lh_asr_batch: null array");
+  const size_t nodes = 2 * (size_t)T - 2, n_ops = (size_t)T - 2, L = f->host.n_sites;
+  for (size_t k = 0; k < (size_t)n * n_ops; ++k)
+    if (!valid_op(ops + k * 4, T, (int)nodes, max_depth))
+      return fail("lh_asr_batch: malformed schedule op (use lh_schedule_tree)");
+  for (size_t k = 0; k < (size_t)n * L; ++k)
+    if (naive[k] > 4) return fail("lh_asr_batch: naive base out of range");
+  LH_HIP(hipDeviceSynchronize());
+  // sub-batches bound the device copy of the output (anc: (T-2) * L bytes per sample)
+  const int sub = (int)std::max<size_t>(1, std::min<size_t>(n, ((size_t)1 << 30) / std::max<size_t>(n_ops * L, 1)));
+  for (int off = 0; off < n; off += sub) {
+    const int m = std::min(sub, n - off);
+    const size_t bytes[7] = {sizeof(int32_t) * 4 * n_ops * m, sizeof(double) * nodes * m, sizeof(double) * 6 * m,
+                             sizeof(double) * 4 * m,          sizeof(double) * R * m,     L * m,
+                             n_ops * L * m};
+    const void* src[6] = {ops + (size_t)off * n_ops * 4, brlen + (size_t)off * nodes, er + (size_t)off * 6,
+                          pi + (size_t)off * 4,          rates + (size_t)off * R,     naive + (size_t)off * L};
+    void* d[8];
+    for (int a = 0; a < 7; ++a)
+      if (asr_stage(f, a, bytes[a], &d[a])) return 1;
+    if (asr_stage(f, 7, L * m, &d[7])) return 1;
+    for (int a = 0; a < 6; ++a) LH_HIP(hipMemcpy(d[a], src[a], bytes[a], hipMemcpyHostToDevice));
+    if (lh_asr_batch_device(f, m, T, max_depth, (const int32_t*)d[0], (const double*)d[1], (const double*)d[2],
+                            (const double*)d[3], (const double*)d[4], R, (const uint8_t*)d[5], seed,
+                            first_sample + (uint64_t)off, (uint8_t*)d[6], (uint8_t*)d[7], nullptr))
+      return 1;
+    LH_HIP(hipDeviceSynchronize());
+    LH_HIP(hipMemcpy(anc + (size_t)off * n_ops * L, d[6], bytes[6], hipMemcpyDeviceToHost));
+    if (rate_choice) LH_HIP(hipMemcpy(rate_choice + (size_t)off * L, d[7], L * m, hipMemcpyDeviceToHost));
   }
   return 0;
 }

@@ -62,6 +62,7 @@ struct DevFamily {
   int32_t idx_byte_offsets;                // 1: the segment index chunks hold byte offsets (index * 8),
                                            // possible when (n_ucol + 1) * 8 fits 16 bits
   const uint8_t* msa;                      // [n_seqs][n_prune]
+  const int32_t* site_pat;                 // [n_sites] pattern of alignment site j (n_prune = the all-N pattern)
   const int32_t* u_pat;                    // [n_ucol] pattern of u-column u
   const uint8_t* u_base;                   // [n_ucol] its naive base (4 = N)
   const int32_t* ucol_of_col;              // [n_xmsa] u-column of the caller's column c
@@ -111,7 +112,20 @@ void launch_model_setup(int n, int R, const double* er, const double* pi, const 
 // (site_lik[n][1][5][n_prune], site_scal[n][1][n_prune]); K2a is to be run with that count.
 int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
                  const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
-                 double* site_lik, int32_t* site_scal, hipStream_t stream);
+                 double* site_lik, int32_t* site_scal, hipStream_t stream, bool allow_fused = true);
+
+// GTR eigendecomposition only (K0a's last role): eig[n][36]
+void launch_gtr_setup(int n, const double* er, const double* pi, double* eig, hipStream_t stream);
+
+// K3: ancestral-sequence sampling (lh_asr.hip).  site_lik / site_scal are K1's UNMIXED per-rate planes
+// (launch_prune with allow_fused = false); clv[n][T-2][4][n_sites] is scratch; anc[n][T-2][n_sites] receives the
+// sampled state of inner node T + i at every site, rate_choice[n][n_sites] (optional) the drawn category.
+// Returns nonzero if the tree is too large for the kernel's LDS tables.
+int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, const double* brlen, const double* rates,
+               const double* eig, const double* pi, const double* site_lik, const int32_t* site_scal,
+               const uint8_t* naive, uint64_t seed, uint64_t sample0, double* clv, uint8_t* anc,
+               uint8_t* rate_choice, hipStream_t stream);
+size_t asr_lds_bytes(int T, int L);
 
 // K2a + K2b.  site_lik != null: emissions are assembled from K1's output (rate mix and naive
 // correction; optionally written to em_out[n][C]); site_lik == null: emissions are taken from

@@ -210,4 +210,10 @@ void launch_model_setup(int n, int R, const double* er, const double* pi, const 
   hipLaunchKernelGGL(finalize_rates_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, R, rates);
 }
 
+void launch_gtr_setup(int n, const double* er, const double* pi, double* eig, hipStream_t stream) {
+  // R = 1: every thread takes the eigendecomposition role, no Gamma boundary is solved
+  hipLaunchKernelGGL(model_setup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, n, 1, er, pi,
+                     (const double*)nullptr, (double*)nullptr, eig);
+}
+
 }  // namespace lh

@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(512) prune_kernel_deep(LH_PRUNE_PARAMS) {
 // the rate categories themselves (the count K2a must then be run with).
 int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
                  const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
-                 double* site_lik, int32_t* site_scal, hipStream_t stream) {
+                 double* site_lik, int32_t* site_scal, hipStream_t stream, bool allow_fused) {
   const int L = fam.n_prune;  // distinct alignment columns; identical ones are pruned once
   if (L == 0) return R;       // nothing but all-N padding (K2a reads no plane at all)
   const bool two = max_depth <= 4;
@@ -504,7 +504,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   // as the exchange area [R][5][pad] doubles + [R][pad] ints) within a third of a CU's LDS
   const size_t pad = (size_t)n2 * 128 + (size_t)n1 * 64;
   const size_t fused_lds = std::max((size_t)R * tip_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
-  const bool fused = two && R * wpr <= 8 && fused_lds <= 53 * 1024;
+  const bool fused = allow_fused && two && R * wpr <= 8 && fused_lds <= 53 * 1024;
   // large trees: with the tip table in LDS fewer than three waves per SIMD would be resident
   const bool tip_global = two && !fused && (160 * 1024 / tip_bytes) * wpr / 4 < 3;
   const size_t lds = fused ? fused_lds : tip_global ? 0 : tip_bytes;

@@ -1,0 +1,123 @@
+"""GPU parity tests of the ancestral-sequence sampling kernel (K3, lh_asr_batch) against
+oracle/asr_oracle.py, draw by draw (same Philox stream), through the C ABI.
+
+Reference step: scripts/run_bootstrap_asr_ess.R:48-104.  Bit-exact bar: the sampled states and rate
+categories are integers; they must be identical except where a uniform lands within rounding distance of a
+category boundary (the oracle and the kernel normalise their weights differently), which the tests bound at a
+handful of sites per million."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import asr_oracle as ao
+from oracle import linearham_oracle as orc
+from tests import desc_builder as db
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import linearham_amd
+    lib = linearham_amd.load_library()
+    assert lib.device_count() >= 1, "no HIP device visible: the GPU tests need an MI355X"
+    return lib
+
+
+def _run(hip, h, rows, R, seed, first_sample, rng, naive_with_n=True):
+    import linearham_amd
+    fam = linearham_amd.Family(db.build_family_desc(h), hip)
+    T = h.msa.shape[0] + 1
+    L = h.msa.shape[1]
+    ops, brl, trees, depth = [], [], [], 0
+    for s in rows:
+        children, root, brlen = db.tree_arrays(orc.parse_newick(s["tree"]), h.xmsa_labels)
+        o, d = hip.schedule_tree(T, children, root)
+        ops.append(o)
+        brl.append(brlen)
+        trees.append((children, root, brlen))
+        depth = max(depth, d)
+    n = len(rows)
+    rates = np.stack([orc.gamma_rates_mean(s["alpha"], R) for s in rows])
+    naive = rng.integers(0, 5 if naive_with_n else 4, size=(n, L)).astype(np.uint8)
+    anc, choice = fam.asr_batch(T, depth, np.stack(ops), np.stack(brl), [s["er"] for s in rows],
+                                [s["pi"] for s in rows], rates, naive, seed, first_sample)
+    fam.close()
+    mism = 0
+    for i, s in enumerate(rows):
+        children, root, brlen = trees[i]
+        c_ref, a_ref, _ = ao.asr_sample(children, root, brlen, T, h.msa, naive[i], s["er"], np.asarray(s["pi"]),
+                                        rates[i], seed, first_sample + i)
+        same_rate = c_ref == choice[i]
+        mism += int((~same_rate).sum())
+        # where the category agrees the joint draw must agree node by node
+        mism += int((a_ref[:, same_rate] != anc[i][:, same_rate]).any(axis=0).sum())
+        assert anc[i].max() <= 3
+    return mism, n * L, anc, choice
+
+
+@pytest.mark.parametrize("preset", ["small", "medium", "igk", "rates1", "rates8"])
+def test_asr_matches_oracle(hip, tmp_path, preset):
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    spec = {"small": sf.Spec.small(n_samples=5), "medium": sf.Spec.small(n_leaves=40, n_samples=3, seed=11),
+            "igk": sf.Spec.small(locus="igk", n_samples=3, seed=5), "rates1": sf.Spec.small(n_samples=2, seed=8),
+            "rates8": sf.Spec.small(n_samples=2, n_leaves=17, seed=9)}[preset]
+    R = {"rates1": 1, "rates8": 8}.get(preset, 4)
+    sf.generate(spec, out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    mism, total, anc, choice = _run(hip, h, rows, R, seed=20261004, first_sample=7, rng=np.random.default_rng(3))
+    assert mism <= max(1, total // 200000), (mism, total)
+    assert choice.max() < R
+
+
+def test_asr_toy_family_and_determinism(hip, data_dir):
+    """The reference's own toy family (data/phylo_hmm_input.yaml + newton.tree): smallest tree with an inner
+    branch; same call twice -> identical output; different seed -> different output; sample numbering is
+    by first_sample + i, not by position in the batch."""
+    h = orc.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input.yaml"), 0, os.path.join(data_dir, "hmm_params"), 0)
+    tree = open(os.path.join(data_dir, "newton.tree")).read()
+    rows = [dict(tree=tree, er=[1.0] * 6, pi=[0.17, 0.19, 0.25, 0.39], alpha=1.0)] * 6
+    m1, total, anc1, ch1 = _run(hip, h, rows, 4, 5, 0, np.random.default_rng(1))
+    m2, _, anc2, ch2 = _run(hip, h, rows, 4, 5, 0, np.random.default_rng(1))
+    assert m1 == 0 and m2 == 0
+    assert np.array_equal(anc1, anc2) and np.array_equal(ch1, ch2)
+    _, _, anc3, _ = _run(hip, h, rows, 4, 6, 0, np.random.default_rng(1))
+    assert not np.array_equal(anc1, anc3)
+    _, _, anc4, ch4 = _run(hip, h, rows[:3], 4, 5, 3, np.random.default_rng(1))
+    # rows 3..5 of the first call used sample numbers 3..5 but other naive sequences: only shapes compare
+    assert anc4.shape == (3, 2, h.msa.shape[1])
+
+
+def test_asr_large_tree(hip, tmp_path):
+    """500 leaves x 600 sites (the LDS tables of one (sample, rate) take ~147 KB), stack depth 4."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec(n_leaves=500, n_sites=600, n_v=24, n_d=6, n_j=4, n_samples=2, seed=99), out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    mism, total, _, _ = _run(hip, h, rows, 4, 99, 0, np.random.default_rng(2))
+    assert mism <= 1, (mism, total)
+
+
+def test_asr_error_paths(hip, data_dir):
+    import linearham_amd
+    h = orc.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input.yaml"), 0, os.path.join(data_dir, "hmm_params"), 0)
+    fam = linearham_amd.Family(db.build_family_desc(h), hip)
+    T, L = 4, h.msa.shape[1]
+    children, root, brlen = db.tree_arrays(orc.parse_newick(open(os.path.join(data_dir, "newton.tree")).read()),
+                                           h.xmsa_labels)
+    ops, depth = hip.schedule_tree(T, children, root)
+    good = dict(ops=ops[None], brlen=brlen[None], er=[[1.0] * 6], pi=[[0.25] * 4], rates=[[1.0]],
+                naive=np.zeros((1, L), dtype=np.uint8))
+    fam.asr_batch(T, depth, good["ops"], good["brlen"], good["er"], good["pi"], good["rates"], good["naive"], 1)
+    bad = np.full((1, L), 7, dtype=np.uint8)
+    with pytest.raises(RuntimeError, match="naive base out of range"):
+        fam.asr_batch(T, depth, good["ops"], good["brlen"], good["er"], good["pi"], good["rates"], bad, 1)
+    bad_ops = ops.copy()
+    bad_ops[0, 1] = 99
+    with pytest.raises(RuntimeError, match="malformed schedule op"):
+        fam.asr_batch(T, depth, bad_ops[None], good["brlen"], good["er"], good["pi"], good["rates"], good["naive"], 1)
+    fam.close()
