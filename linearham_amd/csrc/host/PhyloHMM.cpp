@@ -404,6 +404,136 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
   outfile.close();
 }
 
+// scripts/run_bootstrap_asr_ess.R:86-101: the tree rooted on the naive branch (the added root node sits at
+// distance 0 from naive's neighbour, :53), every node followed by [&ancestral="..."] as
+// phylotate::print_annotated writes node comments.  Branch lengths "%.10g" (R's own formatting of doubles is
+// not restated).
+std::string PhyloHMM::AnnotatedNewick(const TreeArrays& tr, const std::string& naive_sequence,
+                                      const uint8_t* anc) const {
+  const int T = tr.n_tips;
+  const int L = (int)msa_.cols();
+  auto comment = [&](int v) {
+    std::string s = "[&ancestral=\"";
+    if (v == 0) {
+      s += naive_sequence;
+    } else if (v < T) {
+      for (int j = 0; j < L; ++j) s.push_back(alphabet_[msa_(v - 1, j)]);
+    } else {
+      const uint8_t* a = anc + (std::size_t)(v - T) * L;
+      for (int j = 0; j < L; ++j) s.push_back(alphabet_[a[j]]);
+    }
+    return s + "\"]";
+  };
+  auto len = [](double l) {
+    char b[48];
+    std::snprintf(b, sizeof b, ":%.10g", l);
+    return std::string(b);
+  };
+  std::string out;
+  struct Fr {
+    int node, next_kid;
+  };
+  std::vector<Fr> stack{{tr.root, 0}};
+  out = "(" + xmsa_labels_[0] + comment(0) + len(tr.brlen[0]) + ",";
+  while (!stack.empty()) {
+    Fr& f = stack.back();
+    if (f.node < T) {
+      out += xmsa_labels_[f.node] + comment(f.node) + len(tr.brlen[f.node]);
+      stack.pop_back();
+      continue;
+    }
+    if (f.next_kid < 2) {
+      out.push_back(f.next_kid == 0 ? '(' : ',');
+      const int k = tr.children[2 * (std::size_t)(f.node - T) + f.next_kid++];
+      stack.push_back({k, 0});
+      continue;
+    }
+    out += ")" + comment(f.node) + len(f.node == tr.root ? 0.0 : tr.brlen[f.node]);
+    stack.pop_back();
+  }
+  return out + ")" + comment(tr.root) + ";";
+}
+
+void PhyloHMM::RunAsr(const std::string& input_path, const std::string& output_path, uint64_t seed) {
+  std::ifstream in(input_path);
+  if (!in) throw std::runtime_error("Can't open linearham output file " + input_path);
+  std::string line;
+  if (!std::getline(in, line)) throw std::runtime_error("Empty linearham output file " + input_path);
+  const std::vector<std::string> header = SplitTsv(line);
+  auto find = [&](const std::string& name) {
+    const auto it = std::find(header.begin(), header.end(), name);
+    return it == header.end() ? -1 : (int)(it - header.begin());
+  };
+  std::vector<int> col;
+  for (int k = 1; k <= 6; ++k) col.push_back(find("er[" + std::to_string(k) + "]"));
+  for (int k = 1; k <= 4; ++k) col.push_back(find("pi[" + std::to_string(k) + "]"));
+  col.push_back(find("tree"));
+  col.push_back(find("NaiveSequence"));
+  const char* names[12] = {"er[1]", "er[2]", "er[3]", "er[4]", "er[5]", "er[6]", "pi[1]", "pi[2]", "pi[3]", "pi[4]",
+                           "tree",  "NaiveSequence"};
+  for (int k = 0; k < 12; ++k)
+    if (col[k] < 0) throw std::runtime_error(std::string("Missing column \"") + names[k] + "\" in " + input_path);
+  std::vector<int> sr_col;
+  for (int k = 1;; ++k) {
+    const int c = find("sr[" + std::to_string(k) + "]");
+    if (c < 0) break;
+    sr_col.push_back(c);
+  }
+  if (sr_col.empty()) throw std::runtime_error("Missing column \"sr[1]\" in " + input_path);
+  const int R = (int)sr_col.size();
+  const int L = (int)msa_.cols();
+  struct Row {
+    TreeSample ts;
+    std::vector<double> sr;
+    std::string naive;
+  };
+  std::vector<Row> rows;
+  while (std::getline(in, line)) {
+    if (line.empty()) continue;
+    const std::vector<std::string> f = SplitTsv(line);
+    auto get = [&](int c) -> const std::string& {
+      if (c >= (int)f.size()) throw std::runtime_error("Too few columns in " + input_path);
+      return f[c];
+    };
+    Row r;
+    for (int k = 0; k < 6; ++k) r.ts.er.push_back(std::stod(get(col[k])));
+    for (int k = 0; k < 4; ++k) r.ts.pi.push_back(std::stod(get(col[6 + k])));
+    r.ts.alpha = 1.0;  // unused: the rates come from the sr[] columns
+    r.ts.newick = get(col[10]);
+    r.naive = get(col[11]);
+    if ((int)r.naive.size() != L) throw std::runtime_error("NaiveSequence length differs from the alignment's in " + input_path);
+    for (int c : sr_col) r.sr.push_back(std::stod(get(c)));
+    rows.push_back(std::move(r));
+  }
+  CreateFamily();
+  std::ofstream outfile(output_path);
+  if (!outfile) throw std::runtime_error("Can't open output file " + output_path);
+  const int T = (int)xmsa_labels_.size();
+  const std::size_t kBatch = 1024;
+  for (std::size_t off = 0; off < rows.size(); off += kBatch) {
+    const std::size_t m = std::min(kBatch, rows.size() - off);
+    std::vector<TreeSample> samples;
+    for (std::size_t i = 0; i < m; ++i) samples.push_back(rows[off + i].ts);
+    std::vector<TreeArrays> trees;
+    const DeviceBatch b = FlattenBatch(samples, &trees);
+    std::vector<double> rates(m * R);
+    std::vector<uint8_t> naive(m * (std::size_t)L), anc(m * (std::size_t)(T - 2) * L);
+    for (std::size_t i = 0; i < m; ++i) {
+      std::copy(rows[off + i].sr.begin(), rows[off + i].sr.end(), rates.begin() + i * R);
+      for (int j = 0; j < L; ++j) {
+        const std::size_t a = alphabet_.find(rows[off + i].naive[j]);
+        if (a == std::string::npos) throw std::runtime_error("NaiveSequence holds a character outside the alphabet");
+        naive[i * L + j] = (uint8_t)a;
+      }
+    }
+    CheckHip(lh_asr_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(), b.pi.data(),
+                          rates.data(), R, naive.data(), seed, (uint64_t)off, anc.data(), nullptr),
+             "lh_asr_batch");
+    for (std::size_t i = 0; i < m; ++i)
+      outfile << AnnotatedNewick(trees[i], rows[off + i].naive, anc.data() + i * (std::size_t)(T - 2) * L) << "\n";
+  }
+}
+
 // src/PhyloHMM.cpp:461-471
 void StoreGermlinePaddingXmsaIndices(const std::vector<int>& naive_bases, const std::vector<int>& site_inds,
                                      std::map<std::pair<int, int>, int>& xmsa_ids, VectorXi& xmsa_inds) {

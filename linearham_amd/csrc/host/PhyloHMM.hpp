@@ -83,6 +83,16 @@ class PhyloHMM : public HMM {
   void InitializePhyloEmission();
   void RunPipeline(const std::string& input_path, const std::string& output_path, int num_rates);
 
+  /// The per-tree body of scripts/run_bootstrap_asr_ess.R:48-104 for every row of a RunPipeline output table
+  /// (columns er[1..6], pi[1..4], tree, sr[1..R], NaiveSequence): per alignment site a rate category is drawn
+  /// with the column likelihoods on the rate-scaled trees, then the inner-node states are drawn jointly given
+  /// the tips (K3, lh_asr_batch).  Writes one Newick string per row, rooted on the naive branch as
+  /// ape::root(tree, "naive", resolve.root = TRUE) does, every node annotated [&ancestral="<L bases>"] (tips:
+  /// their observed sequence).  Random numbers: Philox stream `seed`, sample number = row number.
+  void RunAsr(const std::string& input_path, const std::string& output_path, uint64_t seed);
+  /// One annotated tree (RunAsr's output line) from the sampled states anc[(T-2)][L] of a row.
+  std::string AnnotatedNewick(const TreeArrays& tree, const std::string& naive_sequence, const uint8_t* anc) const;
+
   /// Batched log-likelihoods of many tree samples (the GPU-native entry point RunPipeline uses).
   /// Rows are (newick, er[6], pi[4], alpha).  Returns HMM::LogLikelihood() per row.
   struct TreeSample {

@@ -227,7 +227,11 @@ int lhh_sample(void* h, const char** out) {
 int lhh_run_pipeline(void* h, const char* input_path, const char* output_path, int num_rates) {
   return Guard([&] { dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h)).RunPipeline(input_path, output_path, num_rates); });
 }
+int lhh_run_asr(void* h, const char* input_path, const char* output_path, uint64_t seed) {
+  return Guard([&] { dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h)).RunAsr(input_path, output_path, seed); });
+}
 // what: bit 0 = state space + transitions, bit 1 = forward arrays, bit 2 = sample, bit 3 = xMSA structures
+
 int lhh_dump_json(void* h, int what, const char** out) {
   return Guard([&] {
     HMM* hmm = static_cast<HMM*>(h);

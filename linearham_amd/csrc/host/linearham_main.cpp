@@ -1,5 +1,6 @@
 // `linearham` command line (same sub-commands and flag names as src/linearham.cpp:268-455 of the
-// reference, without TCLAP): --compute-logl | --sample | --pipeline.
+// reference, without TCLAP): --compute-logl | --sample | --pipeline; plus --asr, the per-tree body of
+// scripts/run_bootstrap_asr_ess.R:48-104 on a --pipeline output table.
 #include <cstdlib>
 #include <iostream>
 #include <map>
@@ -50,13 +51,13 @@ int main(int argc, char** argv) {
   try {
     if (argc < 2 || std::string(argv[1]) == "-h" || std::string(argv[1]) == "--help") {
       std::cout << "A Phylo-HMM implementation for B cell receptor sequence analysis.\n"
-                   "USAGE: linearham {--compute-logl|--sample|--pipeline} --yaml-path <string> --cluster-ind <int> "
+                   "USAGE: linearham {--compute-logl|--sample|--pipeline|--asr} --yaml-path <string> --cluster-ind <int> "
                    "--hmm-param-dir <string> [--seed <int>] [--num-rates <int>] ...\n";
       return argc < 2 ? EXIT_FAILURE : EXIT_SUCCESS;
     }
     const std::string subcmd = argv[1];
     const Args a = Parse(argc, argv, 2);
-    if (subcmd != "--compute-logl" && subcmd != "--sample" && subcmd != "--pipeline")
+    if (subcmd != "--compute-logl" && subcmd != "--sample" && subcmd != "--pipeline" && subcmd != "--asr")
       throw std::invalid_argument("'" + subcmd + "' is not a valid subcommand.");
     const std::string yaml_path = a.one("yaml-path");
     const int cluster_ind = std::stoi(a.one("cluster-ind"));
@@ -67,6 +68,10 @@ int main(int argc, char** argv) {
         std::make_shared<linearham::PhyloHMM>(yaml_path, cluster_ind, hmm_param_dir, seed);
     if (subcmd == "--pipeline") {
       phylo_hmm_ptr->RunPipeline(a.one("input-path"), a.one("output-path"), num_rates);
+      return EXIT_SUCCESS;
+    }
+    if (subcmd == "--asr") {
+      phylo_hmm_ptr->RunAsr(a.one("input-path"), a.one("output-path"), (uint64_t)std::stoll(a.opt("seed", "0")));
       return EXIT_SUCCESS;
     }
     phylo_hmm_ptr->InitializePhyloParameters(a.one("newick-path"), a.multi("er"), a.multi("pi"),

@@ -46,6 +46,20 @@ def newick_roundtrip(newick, labels):
     return out.value.decode()
 
 
+def newick_arrays(newick, labels):
+    """The host's rooted-at-naive arrays of a Newick string: (children [(T-2)*2], root, brlen [2T-2])."""
+    import numpy as np
+    T = len(labels)
+    children = np.zeros(2 * (T - 2), dtype=np.int32)
+    brlen = np.zeros(2 * T - 2)
+    root = C.c_int32()
+    out = C.c_char_p()
+    _check(load_host().lhh_newick_roundtrip(newick.encode(), "\n".join(labels).encode(), C.byref(out),
+                                            children.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            brlen.ctypes.data_as(C.POINTER(C.c_double)), C.byref(root)))
+    return children, root.value, brlen
+
+
 class _HMM:
     def __init__(self, handle):
         self.h = handle
@@ -105,6 +119,11 @@ class PhyloHMM(_HMM):
 
     def run_pipeline(self, input_path, output_path, num_rates):
         _check(self.lib.lhh_run_pipeline(self.h, input_path.encode(), output_path.encode(), num_rates))
+
+    def run_asr(self, input_path, output_path, seed):
+        lib = load_host()
+        lib.lhh_run_asr.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint64]
+        _check(lib.lhh_run_asr(self.h, input_path.encode(), output_path.encode(), seed))
 
     def sizes(self):
         v = [C.c_int() for _ in range(8)]

@@ -124,6 +124,60 @@ def test_run_pipeline_matches_oracle(tmp_path, locus):
         assert abs(sum(l for a in t1.adj for _, l in a) - sum(l for a in t2.adj for _, l in a)) < 1e-4
 
 
+def _annotated(children, root, brlen, labels, naive_seq, msa, anc, alphabet="ACGTN"):
+    """The line PhyloHMM::RunAsr writes (scripts/run_bootstrap_asr_ess.R:86-101), rebuilt from oracle states."""
+    T = len(labels)
+
+    def comment(v):
+        if v == 0:
+            s = naive_seq
+        elif v < T:
+            s = "".join(alphabet[b] for b in msa[v - 1])
+        else:
+            s = "".join(alphabet[b] for b in anc[v - T])
+        return '[&ancestral="%s"]' % s
+
+    def go(v):
+        if v < T:
+            return labels[v] + comment(v) + ":%.10g" % brlen[v]
+        a, b = children[2 * (v - T)], children[2 * (v - T) + 1]
+        return "(" + go(a) + "," + go(b) + ")" + comment(v) + ":%.10g" % (0.0 if v == root else brlen[v])
+
+    return "(" + labels[0] + comment(0) + ":%.10g" % brlen[0] + "," + go(root) + ")" + comment(root) + ";"
+
+
+@pytest.mark.parametrize("locus", ["igh", "igk"])
+def test_run_asr_matches_oracle(tmp_path, locus):
+    """--pipeline then --asr (scripts/run_bootstrap_asr_ess.R:48-104 on every row of the pipeline's table): the
+    annotated trees must be the oracle's draws (same Philox stream; rates = the 6-digit sr[] columns, naive =
+    the NaiveSequence column, as the R script reads them), written in the host's own node numbering."""
+    from oracle import asr_oracle as ao
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_samples=5, locus=locus, seed=31), out)
+    yaml_path, pdir, tsv = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params"), os.path.join(out, "trees.tsv")
+    h = host.PhyloHMM(yaml_path, 0, pdir, 3)
+    res, asr = os.path.join(out, "lh.tsv"), os.path.join(out, "asr.trees")
+    h.run_pipeline(tsv, res, 4)
+    h.run_asr(res, asr, 77)
+    got = [l.rstrip("\n") for l in open(asr)]
+    lines = [l.rstrip("\n").split("\t") for l in open(res)]
+    col = {name: i for i, name in enumerate(lines[0])}
+    o = orc.PhyloHMM(yaml_path, 0, pdir, 3)
+    labels = list(o.xmsa_labels)
+    assert len(got) == len(lines) - 1
+    for i, f in enumerate(lines[1:]):
+        children, root, brlen = host.newick_arrays(f[col["tree"]], labels)
+        er = [float(f[col["er[%d]" % k]]) for k in range(1, 7)]
+        pi = np.array([float(f[col["pi[%d]" % k]]) for k in range(1, 5)])
+        sr = [float(f[col["sr[%d]" % k]]) for k in range(1, 5)]
+        naive_seq = f[col["NaiveSequence"]]
+        naive = np.array(["ACGTN".index(c) for c in naive_seq])
+        _, anc, _ = ao.asr_sample(children, root, brlen, len(labels), o.msa, naive, er, pi, sr, 77, i)
+        want = _annotated(children, root, brlen, labels, naive_seq, o.msa, anc)
+        assert got[i] == want, i
+
+
 def test_cli_compute_logl(data_dir):
     """`linearham --compute-logl` prints the log-likelihood with 6 significant digits
     (src/linearham.cpp:341-348)."""
