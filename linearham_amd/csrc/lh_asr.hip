@@ -87,6 +87,9 @@ __device__ __forceinline__ void matvec_lds(const double* p, const double (&a)[4]
 
 }  // namespace
 
+// slots per sample in the CLV area: every category's region starts on a multiple of 8 slots
+size_t asr_slots(int L, int R) { return (((size_t)L + 7) & ~(size_t)7) + 8 * (size_t)R + 8; }
+
 size_t asr_lds_bytes(int T, int L) {
   const size_t n_ops = (size_t)T - 2;
   size_t b = 0;
@@ -96,20 +99,66 @@ size_t asr_lds_bytes(int T, int L) {
   b += n_ops * 2 * sizeof(int32_t);      // popped_op, node_of_op
   b += (size_t)L * sizeof(int32_t);      // list
   b += 16 * 256;                         // state stack [16][256]
-  b += (((size_t)L + 15) & ~(size_t)15); // choice
-  b += 128;                              // counters + slot_op
+  b += 16;                               // counters
   return b;
+}
+
+// K3a: the rate category of every (sample, site): one thread each.  Weights = K1's per-rate column
+// likelihoods for the site's naive base, scalers aligned to the smallest (the arithmetic of K2a's mixture).
+__global__ void __launch_bounds__(256) asr_rate_kernel(int n, int R, int L, int n_prune,
+                                                       const int32_t* __restrict__ site_pat,
+                                                       const double* __restrict__ site_lik,
+                                                       const int32_t* __restrict__ site_scal,
+                                                       const uint8_t* __restrict__ naive, uint64_t seed,
+                                                       uint64_t sample0, uint8_t* __restrict__ choice) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)n * L) return;
+  const int sample = (int)(gid / L), j = (int)(gid - (long long)sample * L);
+  const int pat = site_pat[j];
+  const int b = naive[gid];
+  const double u = asr_uniform(seed, sample0 + (uint64_t)sample, (uint32_t)j, 0u);
+  int pick = R - 1;
+  if (pat >= n_prune) {  // all-N column: every category has the same likelihood
+    const double t = u * (double)R;
+    for (int k = R - 1; k >= 0; --k)
+      if (t < (double)(k + 1)) pick = k;
+  } else {
+    const int32_t* sc = site_scal + (size_t)sample * R * n_prune + pat;
+    const double* lk = site_lik + ((size_t)sample * R * 5 + b) * n_prune + pat;
+    int smin = 0x7fffffff;
+    for (int k = 0; k < R; ++k) smin = min(smin, sc[(size_t)k * n_prune]);
+    double total = 0.0;
+    for (int k = 0; k < R; ++k) {
+      double v = lk[(size_t)k * 5 * n_prune];
+      const int d = sc[(size_t)k * n_prune] - smin;
+      for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
+      total += v;
+    }
+    const double t = u * total;
+    double cum = 0.0;
+    bool found = false;
+    for (int k = 0; k < R; ++k) {
+      double v = lk[(size_t)k * 5 * n_prune];
+      const int d = sc[(size_t)k * n_prune] - smin;
+      for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
+      cum += v;
+      if (!found && t < cum) {
+        pick = k;
+        found = true;
+      }
+    }
+  }
+  choice[gid] = (uint8_t)pick;
 }
 
 __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_prune, const uint8_t* __restrict__ msa,
                                                   const int32_t* __restrict__ site_pat,
                                                   const int32_t* __restrict__ ops, const double* __restrict__ brlen,
                                                   const double* __restrict__ rates, const double* __restrict__ eig,
-                                                  const double* __restrict__ pi, const double* __restrict__ site_lik,
-                                                  const int32_t* __restrict__ site_scal,
+                                                  const double* __restrict__ pi,
+                                                  const uint8_t* __restrict__ choice_g,
                                                   const uint8_t* __restrict__ naive, uint64_t seed, uint64_t sample0,
-                                                  double* clv, uint8_t* __restrict__ anc,
-                                                  uint8_t* __restrict__ rate_choice) {
+                                                  double2* clv, int Lp, uint8_t* __restrict__ anc) {
   extern __shared__ double2 asr_smem[];
   const int n_ops = T - 2;
   double* tiptab = reinterpret_cast<double*>(asr_smem);           // [T][4][4]
@@ -119,8 +168,7 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
   int32_t* node_of_op = popped_op + n_ops;                         // [n_ops]
   int32_t* list = node_of_op + n_ops;                              // [L]
   uint8_t* st_stack = reinterpret_cast<uint8_t*>(list + L);        // [16][256]
-  uint8_t* choice = st_stack + 16 * 256;                           // [L]
-  int32_t* misc = reinterpret_cast<int32_t*>(choice + ((L + 15) & ~15));  // cnt, base, slot_op[...]
+  int32_t* misc = reinterpret_cast<int32_t*>(st_stack + 16 * 256);  // cnt, base
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -132,22 +180,55 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
   const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
 
   for (int k = tid; k < n_ops; k += blockDim.x) ops_s[k] = op_ptr[k];
-  __syncthreads();
 
-  // ---- schedule bookkeeping (one thread; ~10 cycles per op out of LDS): which op produced the sibling a
-  // pop op takes from the stack, and which tree node every op produces
+  // ---- the site list of this rate (last wave): deterministic slots, site order within a category
+  if (wave == n_waves - 1) {
+    const uint8_t* __restrict__ ch = choice_g + (size_t)sample * L;
+    int run = 0, lower = 0;
+    for (int j0 = 0; j0 < L; j0 += 64) {
+      const int j = j0 + lane;
+      const int c = j < L ? (int)ch[j] : 255;
+      const unsigned long long mine = __ballot(c == rate);
+      const unsigned long long low = __ballot(c < rate);
+      if (c == rate) list[run + __popcll(mine & ((1ull << lane) - 1ull))] = j;
+      run += __popcll(mine);
+      lower += __popcll(low);
+    }
+    if (lane == 0) {
+      misc[0] = run;
+      // region of this category in the sample's slot space: starts on a multiple of 8 slots (one 128-byte
+      // line of a 16-byte-per-slot plane), disjoint from the other categories' regions (Lp >= L + 8 R + 7)
+      misc[1] = ((lower + 7) & ~7) + 8 * rate;
+    }
+  }
+  __syncthreads();
+  const int cnt = misc[0], base = misc[1];
+  if (cnt == 0) return;  // no site of this sample drew this category (uniform over the workgroup)
+
+  // ---- schedule bookkeeping (one thread): which op produced the sibling a pop op takes from the stack, and
+  // which tree node every op produces.  The 16 stack slots' op numbers sit in four 64-bit registers.
   if (tid == 0) {
-    int32_t* slot_op = misc + 2;  // [16]
+    unsigned long long so[4] = {0, 0, 0, 0};
     long long named = 0;
     for (int k = 0; k < n_ops; ++k) {
       const int4 op = ops_s[k];
       const int kind = op.x & 15;
-      if (op.x & OP_PUSH_FLAG) slot_op[op.w] = k - 1;
+      const int sh = (op.w & 3) * 16, wi = (op.w >> 2) & 3;
+      if (op.x & OP_PUSH_FLAG) {
+        const unsigned long long v = (unsigned long long)(unsigned)(k - 1) << sh, m = ~(0xffffull << sh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i == wi) so[i] = (so[i] & m) | v;
+      }
       if (kind == OP_TIP_ACC) {
         node_of_op[k - 1] = op.z;
         named += op.z;
       } else if (kind == OP_POP_ACC) {
-        const int q = slot_op[op.w];
+        unsigned long long word = so[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+          if (i == wi) word = so[i];
+        const int q = (int)((word >> sh) & 0xffffull);
         popped_op[k] = q;
         node_of_op[k - 1] = op.z;
         node_of_op[q] = op.y;
@@ -174,50 +255,9 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
         for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
     }
   }
-
-  // ---- rate category of every site of the sample (every workgroup of the sample computes the same)
-  {
-    const uint8_t* __restrict__ nv = naive + (size_t)sample * L;
-    for (int j = tid; j < L; j += blockDim.x) {
-      const int pat = site_pat[j];
-      const int b = nv[j];
-      const double u = asr_uniform(seed, sample_id, (uint32_t)j, 0u);
-      int pick = R - 1;
-      if (pat >= n_prune) {  // all-N column: every category has the same likelihood
-        const double t = u * (double)R;
-        for (int k = R - 1; k >= 0; --k)
-          if (t < (double)(k + 1)) pick = k;
-      } else {
-        int smin = 0x7fffffff;
-        for (int k = 0; k < R; ++k) smin = min(smin, site_scal[((size_t)sample * R + k) * n_prune + pat]);
-        double total = 0.0;
-        for (int k = 0; k < R; ++k) {
-          double v = site_lik[(((size_t)sample * R + k) * 5 + b) * n_prune + pat];
-          const int d = site_scal[((size_t)sample * R + k) * n_prune + pat] - smin;
-          for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
-          total += v;
-        }
-        const double t = u * total;
-        double cum = 0.0;
-        bool found = false;
-        for (int k = 0; k < R; ++k) {
-          double v = site_lik[(((size_t)sample * R + k) * 5 + b) * n_prune + pat];
-          const int d = site_scal[((size_t)sample * R + k) * n_prune + pat] - smin;
-          for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
-          cum += v;
-          if (!found && t < cum) {
-            pick = k;
-            found = true;
-          }
-        }
-      }
-      choice[j] = (uint8_t)pick;
-      if (rate == 0 && rate_choice) rate_choice[(size_t)sample * L + j] = (uint8_t)pick;
-    }
-  }
   __syncthreads();
 
-  // ---- inner-branch P-matrices (indexed by the op that produced the child), and the site list of this rate
+  // ---- inner-branch P-matrices, indexed by the op that produced the child
   {
     double P[4][4];
     for (int k = tid; k < n_ops; k += blockDim.x) {
@@ -240,64 +280,72 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
       }
     }
   }
-  if (wave == n_waves - 1) {  // one wave compacts: deterministic slots (site order within a category)
-    int run = 0, lower = 0;
-    for (int j0 = 0; j0 < L; j0 += 64) {
-      const int j = j0 + lane;
-      const int c = j < L ? (int)choice[j] : 255;
-      const unsigned long long mine = __ballot(c == rate);
-      const unsigned long long low = __ballot(c < rate);
-      if (c == rate) list[run + __popcll(mine & ((1ull << lane) - 1ull))] = j;
-      run += __popcll(mine);
-      lower += __popcll(low);
-    }
-    if (lane == 0) {
-      misc[0] = run;
-      misc[1] = lower;
-    }
-  }
   __syncthreads();
 
-  const int cnt = misc[0], base = misc[1];
   const double* __restrict__ p4 = pi + (size_t)sample * 4;
   const uint8_t* __restrict__ nv = naive + (size_t)sample * L;
-  const size_t plane = (size_t)L;  // doubles between the component planes of one (sample, op)
-  double* clv_s = clv + (size_t)sample * n_ops * 4 * plane;
+  // CLV area of the sample: [op][2][Lp] double2 -- components (0,1) and (2,3) of a slot are 16-byte entries of
+  // two planes, so a wave's store is one contiguous run of whole 128-byte lines per plane
+  const size_t plane = (size_t)Lp;
+  double2* clv_s = clv + (size_t)sample * n_ops * 2 * plane;
   uint8_t* anc_s = anc + (size_t)sample * n_ops * (size_t)L;
   uint8_t* my_stack = st_stack + tid;
 
-  for (int s0 = wave * 64; s0 < cnt; s0 += n_waves * 64) {
+  // The walk is latency-bound (dependent loads per op), not lane-bound: the sites of this category are spread
+  // evenly over ALL waves of the workgroup (a category typically holds a quarter of the sites, fewer than two
+  // full waves), so that every resident wave carries a dependency chain.
+  const int per = min(64, (((cnt + n_waves - 1) / n_waves) + 15) & ~15);  // sites per wave and round
+  for (int s0 = wave * per; s0 < cnt; s0 += n_waves * per) {
     const int slot = s0 + lane;
-    const bool active = slot < cnt;
+    const bool active = lane < per && slot < cnt;
     const int site = list[active ? slot : cnt - 1];
     const int gslot = base + (active ? slot : cnt - 1);
     const int pat = site_pat[site];
     const bool all_n = pat >= n_prune;
     const unsigned upat = all_n ? 0u : (unsigned)pat;
+    const int b_naive = nv[site];
 
-    // ---- upward pass: CLV of every op's node, stored for the way down
+    // ---- upward pass: CLV of every op's node, stored for the way down.  What op k + 1 needs from memory
+    // (its tips' states, or the CLV of the sibling it pops, stored at least two ops earlier) is requested
+    // while op k computes.
     double a[4] = {1.0, 1.0, 1.0, 1.0};
+    int sa, sb = 4;
+    double y[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+      const int4 op0 = ops_s[0];  // the first op is a cherry
+      sa = all_n ? 4 : (int)msa[(unsigned)((op0.y - 1) * n_prune) + upat];
+      sb = all_n ? 4 : (int)msa[(unsigned)((op0.z - 1) * n_prune) + upat];
+    }
     for (int k = 0; k < n_ops; ++k) {
       const int4 op = ops_s[k];
       const int kind = __builtin_amdgcn_readfirstlane(op.x & 15);
       const int oy = __builtin_amdgcn_readfirstlane(op.y), oz = __builtin_amdgcn_readfirstlane(op.z);
+      int sa_n = 4, sb_n = 4;
+      double y_n[4] = {0.0, 0.0, 0.0, 0.0};
+      if (k + 1 < n_ops) {
+        const int4 on = ops_s[k + 1];
+        const int kn = __builtin_amdgcn_readfirstlane(on.x & 15);
+        const int ny = __builtin_amdgcn_readfirstlane(on.y), nz = __builtin_amdgcn_readfirstlane(on.z);
+        if (kn == OP_POP_ACC) {
+          const int q = __builtin_amdgcn_readfirstlane(popped_op[k + 1]);
+          const double2* cq = clv_s + (size_t)q * 2 * plane + gslot;
+          const double2 lo = cq[0], hi = cq[plane];
+          y_n[0] = lo.x, y_n[1] = lo.y, y_n[2] = hi.x, y_n[3] = hi.y;
+        } else {
+          if (!all_n) sa_n = (int)msa[(unsigned)((ny - 1) * n_prune) + upat];
+          if (kn == OP_CHERRY && !all_n) sb_n = (int)msa[(unsigned)((nz - 1) * n_prune) + upat];
+        }
+      }
       double u[4], v[4];
       if (kind == OP_CHERRY) {
-        const int sa = all_n ? 4 : (int)msa[(unsigned)((oy - 1) * n_prune) + upat];
-        const int sb = all_n ? 4 : (int)msa[(unsigned)((oz - 1) * n_prune) + upat];
         tip_col(tiptab, oy, sa, u);
         tip_col(tiptab, oz, sb, v);
       } else {
         matvec_lds(pin + (size_t)(k - 1) * 16, a, v);
         if (kind == OP_TIP_ACC) {
-          const int sa = all_n ? 4 : (int)msa[(unsigned)((oy - 1) * n_prune) + upat];
           tip_col(tiptab, oy, sa, u);
         } else {
           const int q = __builtin_amdgcn_readfirstlane(popped_op[k]);
-          double y[4];
-          const double* cq = clv_s + (size_t)q * 4 * plane + gslot;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) y[i] = cq[(size_t)i * plane];
           matvec_lds(pin + (size_t)q * 16, y, u);
         }
       }
@@ -308,23 +356,56 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
         for (int i = 0; i < 4; ++i) a[i] *= kScaleFactor;
       }
       if (active) {
-        double* ck = clv_s + (size_t)k * 4 * plane + gslot;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ck[(size_t)i * plane] = a[i];
+        double2* ck = clv_s + (size_t)k * 2 * plane + gslot;
+        ck[0] = make_double2(a[0], a[1]);
+        ck[plane] = make_double2(a[2], a[3]);
       }
+      sa = sa_n;
+      sb = sb_n;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = y_n[i];
     }
 
-    // ---- downward pass
+    // ---- downward pass: the schedule in reverse; the children's CLVs of op k - 1 are requested while op k
+    // draws (their addresses do not depend on the states)
     int s_acc = 0;
+    double c_acc[4] = {0.0, 0.0, 0.0, 0.0}, c_pop[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+      const int k = n_ops - 1;
+      const int kind = __builtin_amdgcn_readfirstlane(ops_s[k].x & 15);
+      if (kind != OP_CHERRY) {
+        const double2* cj = clv_s + (size_t)(k - 1) * 2 * plane + gslot;
+        const double2 lo = cj[0], hi = cj[plane];
+        c_acc[0] = lo.x, c_acc[1] = lo.y, c_acc[2] = hi.x, c_acc[3] = hi.y;
+      }
+      if (kind == OP_POP_ACC) {
+        const double2* cq = clv_s + (size_t)__builtin_amdgcn_readfirstlane(popped_op[k]) * 2 * plane + gslot;
+        const double2 lo = cq[0], hi = cq[plane];
+        c_pop[0] = lo.x, c_pop[1] = lo.y, c_pop[2] = hi.x, c_pop[3] = hi.y;
+      }
+    }
     for (int k = n_ops - 1; k >= 0; --k) {
       const int4 op = ops_s[k];
       const int kind = __builtin_amdgcn_readfirstlane(op.x & 15);
+      double n_acc[4] = {0.0, 0.0, 0.0, 0.0}, n_pop[4] = {0.0, 0.0, 0.0, 0.0};
+      if (k > 0) {
+        const int kp = __builtin_amdgcn_readfirstlane(ops_s[k - 1].x & 15);
+        if (kp != OP_CHERRY) {
+          const double2* cj = clv_s + (size_t)(k - 2) * 2 * plane + gslot;
+          const double2 lo = cj[0], hi = cj[plane];
+          n_acc[0] = lo.x, n_acc[1] = lo.y, n_acc[2] = hi.x, n_acc[3] = hi.y;
+        }
+        if (kp == OP_POP_ACC) {
+          const double2* cq = clv_s + (size_t)__builtin_amdgcn_readfirstlane(popped_op[k - 1]) * 2 * plane + gslot;
+          const double2 lo = cq[0], hi = cq[plane];
+          n_pop[0] = lo.x, n_pop[1] = lo.y, n_pop[2] = hi.x, n_pop[3] = hi.y;
+        }
+      }
       int s_cur;
       if (k == n_ops - 1) {
         // root = naive's neighbour: pi_i * L_root(i) * P_naive[i][naive base]
-        const int b = nv[site];
         double down[4], w[4];
-        tip_col(tiptab, 0, b, down);
+        tip_col(tiptab, 0, b_naive, down);
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = p4[i] * a[i] * down[i];
         s_cur = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 1u));
@@ -334,15 +415,13 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
         const int nx = __builtin_amdgcn_readfirstlane(nxt.x), nw = __builtin_amdgcn_readfirstlane(nxt.w);
         s_cur = (nx & OP_PUSH_FLAG) ? (int)my_stack[nw * 256] : s_acc;
       }
-      if (kind == OP_CHERRY) continue;
-      {
+      if (kind != OP_CHERRY) {
         const int j = k - 1;  // the accumulator child
         const int node = __builtin_amdgcn_readfirstlane(node_of_op[j]);
-        const double* cj = clv_s + (size_t)j * 4 * plane + gslot;
         const double* prow = pin + (size_t)j * 16 + s_cur * 4;
         double w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = prow[i] * cj[(size_t)i * plane];
+        for (int i = 0; i < 4; ++i) w[i] = prow[i] * c_acc[i];
         s_acc = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)(node - T)));
         if (active) anc_s[(size_t)(node - T) * L + site] = (uint8_t)s_acc;
       }
@@ -350,14 +429,18 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
         const int q = __builtin_amdgcn_readfirstlane(popped_op[k]);
         const int node = __builtin_amdgcn_readfirstlane(node_of_op[q]);
         const int ow = __builtin_amdgcn_readfirstlane(op.w);
-        const double* cq = clv_s + (size_t)q * 4 * plane + gslot;
         const double* prow = pin + (size_t)q * 16 + s_cur * 4;
         double w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = prow[i] * cq[(size_t)i * plane];
+        for (int i = 0; i < 4; ++i) w[i] = prow[i] * c_pop[i];
         const int sq = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)(node - T)));
         if (active) anc_s[(size_t)(node - T) * L + site] = (uint8_t)sq;
         my_stack[ow * 256] = (uint8_t)sq;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        c_acc[i] = n_acc[i];
+        c_pop[i] = n_pop[i];
       }
     }
   }
@@ -369,12 +452,16 @@ int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, co
                uint8_t* rate_choice, hipStream_t stream) {
   const int L = fam.n_sites;
   const size_t lds = asr_lds_bytes(T, L);
-  if (lds > 160 * 1024) return 1;
+  if (lds > 160 * 1024 || L < 1) return 1;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(asr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
+  const long long cells = (long long)n * L;
+  hipLaunchKernelGGL(asr_rate_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, n, R, L,
+                     fam.n_prune, fam.site_pat, site_lik, site_scal, naive, seed, sample0, rate_choice);
   hipLaunchKernelGGL(asr_kernel, dim3(R, n), dim3(256), lds, stream, R, T, L, fam.n_prune, fam.msa, fam.site_pat, ops,
-                     brlen, rates, eig, pi, site_lik, site_scal, naive, seed, sample0, clv, anc, rate_choice);
+                     brlen, rates, eig, pi, (const uint8_t*)rate_choice, naive, seed, sample0,
+                     reinterpret_cast<double2*>(clv), (int)asr_slots(L, R), anc);
   return 0;
 }
 

@@ -42,6 +42,8 @@ struct ForwardWs {  // K2a -> K2b hand-off, sized by the largest batch seen
 struct AsrWs {  // K3's CLV area and the device copies of lh_asr_batch's host arrays (grow-only)
   size_t clv_cap = 0;
   double* clv = nullptr;
+  size_t choice_cap = 0;
+  uint8_t* choice = nullptr;  // K3a -> K3b when the caller does not ask for the rate categories
   size_t cap[8] = {0};
   void* ptr[8] = {nullptr};
   double ms = 0;          // K3 time of the profiled launches (lh_profile_enable)
@@ -517,6 +519,7 @@ void lh_family_destroy(lh_family* f) {
   for (void* p : f->st.ptr)
     if (p) (void)hipFree(p);
   if (f->asr.clv) (void)hipFree(f->asr.clv);
+  if (f->asr.choice) (void)hipFree(f->asr.choice);
   for (void* p : f->asr.ptr)
     if (p) (void)hipFree(p);
   for (auto& ev : f->asr.events) {
@@ -907,7 +910,7 @@ int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, c
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const size_t nodes = 2 * (size_t)T - 2, n_ops = (size_t)T - 2, L = f->host.n_sites;
   // launch groups: at most ~8 GB of CLV area (32 B per inner node and site) plus K1's workspace
-  const size_t clv_per_sample = sizeof(double) * n_ops * 4 * L;
+  const size_t clv_per_sample = sizeof(double) * n_ops * 4 * lh::asr_slots((int)L, R);
   const size_t k1_per_sample = sizeof(double) * R * (scratch_doubles(T) + 6 * (size_t)std::max(f->host.n_prune, 1));
   const int by_memory = (int)std::max<size_t>(64, ((size_t)8 << 30) / (clv_per_sample + k1_per_sample));
   const int chunk = std::min<int>(n, std::min(8192, by_memory));
@@ -920,6 +923,14 @@ int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, c
     aw.clv_cap = 0;
     LH_HIP(hipMalloc((void**)&aw.clv, clv_per_sample * chunk));
     aw.clv_cap = clv_per_sample * chunk;
+  }
+  if (!rate_choice && aw.choice_cap < L * (size_t)chunk) {
+    LH_HIP(hipDeviceSynchronize());
+    if (aw.choice) LH_HIP(hipFree(aw.choice));
+    aw.choice = nullptr;
+    aw.choice_cap = 0;
+    LH_HIP(hipMalloc((void**)&aw.choice, L * (size_t)chunk));
+    aw.choice_cap = L * (size_t)chunk;
   }
   Workspace& w = f->ws;
   for (int off = 0; off < n; off += chunk) {
@@ -941,7 +952,7 @@ int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, c
     }
     if (lh::launch_asr(f->host, m, R, T, ops_m, bl_m, r_m, w.eig, pi_m, w.site_lik, w.site_scal,
                        naive + (size_t)off * L, seed, first_sample + (uint64_t)off, aw.clv, anc + (size_t)off * n_ops * L,
-                       rate_choice ? rate_choice + (size_t)off * L : nullptr, stream))
+                       rate_choice ? rate_choice + (size_t)off * L : aw.choice, stream))
       return fail("lh_asr_batch: launch failed");
     if (f->profile) {
       LH_HIP(hipEventRecord(ev.second, stream));

@@ -118,14 +118,15 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
 void launch_gtr_setup(int n, const double* er, const double* pi, double* eig, hipStream_t stream);
 
 // K3: ancestral-sequence sampling (lh_asr.hip).  site_lik / site_scal are K1's UNMIXED per-rate planes
-// (launch_prune with allow_fused = false); clv[n][T-2][4][n_sites] is scratch; anc[n][T-2][n_sites] receives the
-// sampled state of inner node T + i at every site, rate_choice[n][n_sites] (optional) the drawn category.
+// (launch_prune with allow_fused = false); clv[n][T-2][2][asr_slots(L, R)][2] is scratch; anc[n][T-2][n_sites] receives the
+// sampled state of inner node T + i at every site, rate_choice[n][n_sites] the drawn category (K3a -> K3b).
 // Returns nonzero if the tree is too large for the kernel's LDS tables.
 int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, const double* brlen, const double* rates,
                const double* eig, const double* pi, const double* site_lik, const int32_t* site_scal,
                const uint8_t* naive, uint64_t seed, uint64_t sample0, double* clv, uint8_t* anc,
                uint8_t* rate_choice, hipStream_t stream);
 size_t asr_lds_bytes(int T, int L);
+size_t asr_slots(int L, int R);  // slots per sample in K3's CLV area: clv[n][T-2][2][asr_slots] double2
 
 // K2a + K2b.  site_lik != null: emissions are assembled from K1's output (rate mix and naive
 // correction; optionally written to em_out[n][C]); site_lik == null: emissions are taken from

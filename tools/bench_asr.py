@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Throughput of the ancestral-sequence sampling step (K3, lh_asr_batch_device) on the configs[2] family,
+inputs resident in HBM.  Not the headline metric (bench.py is); prints one JSON line.
+
+  python tools/bench_asr.py [--batch 2048] [--steps 5] [--warmup 1] [--preset config2|config4]
+
+K3 is the CLV-streaming kernel of SURVEY 8(d)'s byte model: per tree sample it writes and reads back
+32 B per (inner node, site) plus one state byte per (inner node, site)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--preset", default="config2", choices=["config2", "config4", "small"])
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import linearham_amd
+    from linearham_amd import host
+    from oracle import linearham_oracle as orc
+    from tools import synth_family as sf
+    dev = torch.device("cuda", 0)
+    spec = {"config2": sf.Spec(n_samples=256), "small": sf.Spec.small(n_samples=16),
+            "config4": sf.Spec(n_leaves=500, n_sites=600, n_samples=64)}[args.preset]
+    fam_dir = os.path.join(tempfile.gettempdir(), "lh_bench_%s_r0" % args.preset)
+    if not os.path.exists(os.path.join(fam_dir, "meta.json")):
+        sf.generate(spec, fam_dir)
+    hmm = host.PhyloHMM(os.path.join(fam_dir, "cluster.yaml"), 0, os.path.join(fam_dir, "hmm_params"), 0)
+    sizes = hmm.sizes()
+    n = args.batch
+    flat = hmm.flatten_tsv(os.path.join(fam_dir, "trees.tsv"), n)
+    T, depth, R, L = flat["n_tips"], flat["max_depth"], 4, sizes["n_sites"]
+    rng = np.random.default_rng(1)
+    rates = np.stack([orc.gamma_rates_mean(a, R) for a in flat["alpha"][:256]])
+    rates = rates[np.arange(n) % rates.shape[0]]
+    naive = rng.integers(0, 4, size=(n, L)).astype(np.uint8)
+    d = {k: torch.from_numpy(np.ascontiguousarray(flat[k])).to(dev) for k in ("ops", "brlen", "er", "pi")}
+    d_rates, d_naive = torch.from_numpy(rates).to(dev), torch.from_numpy(naive).to(dev)
+    anc = torch.zeros((n, T - 2, L), dtype=torch.uint8, device=dev)
+    lib = linearham_amd.load_library()
+    fam = C.c_void_p(flat["family"])
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(seed):
+        lib.check(lib.lib.lh_asr_batch_device(fam, n, T, depth, d["ops"].data_ptr(), d["brlen"].data_ptr(),
+                                              d["er"].data_ptr(), d["pi"].data_ptr(), d_rates.data_ptr(), R,
+                                              d_naive.data_ptr(), seed, 0, anc.data_ptr(), None, C.c_void_p(stream)))
+    for w in range(args.warmup):
+        step(w)
+    torch.cuda.synchronize()
+    lib.check(lib.lib.lh_profile_enable(fam, 1))
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(100 + s)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, k = C.c_double(), C.c_int64()
+    lib.check(lib.lib.lh_asr_profile_read(fam, C.byref(ms), C.byref(k)))
+    lib.check(lib.lib.lh_profile_enable(fam, 0))
+    launches = max(k.value, 1)
+    per_launch = n * args.steps / launches
+    k3_ms = ms.value / launches
+    bytes_per_sample = (T - 2) * L * (32 + 32 + 1)
+    achieved = bytes_per_sample * per_launch / (k3_ms * 1e-3) / 1e9
+    a = anc.cpu().numpy()
+    out = {"metric": "ancestral-sequence samples/sec (per-site rate draw + joint inner-state draw)",
+           "value": n * args.steps / dt, "unit": "tree samples/s", "ms_per_step": dt / args.steps * 1e3,
+           "config": {"workload": args.preset, "batch": n, "n_tips": T, "n_sites": L, "R": R},
+           "kernel_ms_per_launch": {"asr_K3": k3_ms, "samples_per_launch": per_launch},
+           "roofline": {"bound": "hbm", "kernel": "asr_kernel (K3)", "achieved": achieved, "peak": 8000.0,
+                        "unit": "GB/s", "frac": achieved / 8000.0, "algorithmic_bytes_per_sample": bytes_per_sample},
+           "state_histogram": [int(x) for x in np.bincount(a.ravel(), minlength=4)[:4]]}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
