@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="tree samples per GPU per step")
     ap.add_argument("--preset", default="config2", choices=["config2", "config4", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcie", action="store_true",
+                    help="also time the host-pointer entry point (PCIe-inclusive rate; its launch groups are "
+                         "sub-batches of 6144, so leave it off when profiling per-launch kernel durations)")
     ap.add_argument("--no-check", action="store_true", help="kernel timing experiments only")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
@@ -224,7 +227,7 @@ def main():
             "kernel_ms_per_step": {"model_K0": ms[0].value / launches, "prune_K1": prune_ms,
                                    "forward_K2": ms[2].value / launches},
         }
-        if world == 1:
+        if world == 1 and args.pcie:
             # PCIe-inclusive rate through the host-pointer entry point (never `value`): H2D of the
             # flattened inputs, the same kernels, D2H of the log-likelihoods, synchronous per call.
             ll_pcie = np.zeros(n)
