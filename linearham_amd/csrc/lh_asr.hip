@@ -15,11 +15,13 @@
 //    draw of all sites -- the draws are a pure function of (seed, sample, site) -- and compacts its own
 //    sites into a list; the list position plus the number of sites of lower categories is the site's slot
 //    in the sample's CLV area, so the R workgroups of a sample share one [T-2][4][L] area without holes.
-//  * Upward pass: the K1 schedule (lh_schedule_tree), one site per lane.  Every inner CLV is needed again
-//    by the downward pass, so it is stored: clv[n][op][4][slot], component planes, slot fastest -- a wave
-//    writes four 512-byte runs per op.  That makes the register stack of K1 unnecessary: a popped sibling is
-//    re-read from the CLV area.  This kernel is the CLV-streaming kernel of SURVEY 8(d)'s byte model:
-//    32 B written and 32 B read per (inner node, site).
+//  * Upward pass: the K1 schedule (lh_schedule_tree), one distinct alignment pattern of the category per lane
+//    (the CLVs do not depend on the naive base: naive hangs off the root).  Every inner CLV is needed again by
+//    the downward pass, so it is stored: clv[n][op][2][slot] of 16-byte entries, slot fastest -- a wave writes
+//    two contiguous runs of whole 128-byte lines per op.  That makes the register stack of K1 unnecessary: a
+//    popped sibling is re-read from the CLV area.  Cherry nodes are not stored (product of two tip-table
+//    columns, formed again where needed).  This kernel is the CLV-streaming kernel of SURVEY 8(d)'s byte
+//    model (32 B written and 32 B read per (inner node, site)), minus what patterns and cherries save.
 //  * P-matrices of the workgroup's (sample, rate) live in LDS: tip branches as the K1 tip table
 //    tiptab[tip][state][4] (column `state` of P), inner branches row-major, indexed by the op that produced
 //    the child.  The upward mat-vec reads them as wave-uniform (broadcast) ds_reads, the downward pass
@@ -30,6 +32,8 @@
 //  * Random numbers: Philox4x32-10, counter = (site, draw, sample), key = seed; draw 0 = rate category,
 //    1 = root, 2 + (v - T) = inner node v.  oracle/asr_oracle.py restates the same stream, so GPU and oracle
 //    agree draw by draw.
+#include <cstdlib>
+
 #include "lh_device.h"
 
 namespace lh {
@@ -90,16 +94,18 @@ __device__ __forceinline__ void matvec_lds(const double* p, const double (&a)[4]
 // slots per sample in the CLV area: every category's region starts on a multiple of 8 slots
 size_t asr_slots(int L, int R) { return (((size_t)L + 7) & ~(size_t)7) + 8 * (size_t)R + 8; }
 
-size_t asr_lds_bytes(int T, int L) {
-  const size_t n_ops = (size_t)T - 2;
+size_t asr_lds_bytes(int T, int L, int R, int n_prune) {
+  const size_t n_ops = (size_t)T - 2, NP = (size_t)n_prune + 1;
   size_t b = 0;
-  b += (size_t)T * 16 * sizeof(double);  // tiptab
-  b += n_ops * 16 * sizeof(double);      // pin
-  b += n_ops * sizeof(int4);             // ops
-  b += n_ops * 2 * sizeof(int32_t);      // popped_op, node_of_op
-  b += (size_t)L * sizeof(int32_t);      // list
-  b += 16 * 256;                         // state stack [16][256]
-  b += 16;                               // counters
+  b += (size_t)T * 16 * sizeof(double);          // tiptab
+  b += n_ops * 16 * sizeof(double);              // pin
+  b += n_ops * sizeof(int4);                     // ops
+  b += n_ops * 2 * sizeof(int32_t);              // popped_op, node_of_op
+  b += (size_t)L * sizeof(int32_t);              // list (sites of the category)
+  b += NP * 2 * sizeof(int32_t);                 // plist, pslot
+  b += 16 * 256;                                 // state stack [16][256]
+  b += (((size_t)R * NP + 15) & ~(size_t)15);    // flags[R][NP]
+  b += 16;                                       // counters
   return b;
 }
 
@@ -158,17 +164,21 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
                                                   const double* __restrict__ pi,
                                                   const uint8_t* __restrict__ choice_g,
                                                   const uint8_t* __restrict__ naive, uint64_t seed, uint64_t sample0,
-                                                  double2* clv, int Lp, uint8_t* __restrict__ anc) {
+                                                  double2* clv, int Lp, uint8_t* __restrict__ anc, int dbg_mode) {
   extern __shared__ double2 asr_smem[];
   const int n_ops = T - 2;
+  const int NP = n_prune + 1;  // patterns, the all-N one (id n_prune) included
   double* tiptab = reinterpret_cast<double*>(asr_smem);           // [T][4][4]
   double* pin = tiptab + (size_t)T * 16;                          // [n_ops][4][4] (entry n_ops-1 unused)
   int4* ops_s = reinterpret_cast<int4*>(pin + (size_t)n_ops * 16);  // [n_ops]
   int32_t* popped_op = reinterpret_cast<int32_t*>(ops_s + n_ops);  // [n_ops]
   int32_t* node_of_op = popped_op + n_ops;                         // [n_ops]
-  int32_t* list = node_of_op + n_ops;                              // [L]
-  uint8_t* st_stack = reinterpret_cast<uint8_t*>(list + L);        // [16][256]
-  int32_t* misc = reinterpret_cast<int32_t*>(st_stack + 16 * 256);  // cnt, base
+  int32_t* list = node_of_op + n_ops;                              // [L]  sites of this category
+  int32_t* plist = list + L;                                       // [NP] distinct patterns of those sites
+  int32_t* pslot = plist + NP;                                     // [NP] pattern -> position in plist
+  uint8_t* st_stack = reinterpret_cast<uint8_t*>(pslot + NP);      // [16][256]
+  uint8_t* flags = st_stack + 16 * 256;                            // [R][NP] pattern present in category
+  int32_t* misc = reinterpret_cast<int32_t*>(flags + (((size_t)R * NP + 15) & ~(size_t)15));  // counters
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -178,31 +188,55 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
   const int sample = blockIdx.y;
   const uint64_t sample_id = sample0 + (uint64_t)sample;
   const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
+  const uint8_t* __restrict__ ch = choice_g + (size_t)sample * L;
 
   for (int k = tid; k < n_ops; k += blockDim.x) ops_s[k] = op_ptr[k];
+  for (int i = tid; i < R * NP; i += blockDim.x) flags[i] = 0;
+  __syncthreads();
+  // which patterns occur among the sites of each category (same value from every writer)
+  for (int j = tid; j < L; j += blockDim.x) flags[(int)ch[j] * NP + min(site_pat[j], n_prune)] = 1;
+  __syncthreads();
 
-  // ---- the site list of this rate (last wave): deterministic slots, site order within a category
+  // ---- last wave: the site list of this category (site order) and its distinct patterns (pattern order).
+  // The CLVs of the upward pass depend on (category, pattern) only, so they are computed and stored once per
+  // distinct pattern; the category's region of the sample's slot space starts on a multiple of 8 slots (one
+  // 128-byte line of a 16-byte-per-slot plane) after the regions of the lower categories.
   if (wave == n_waves - 1) {
-    const uint8_t* __restrict__ ch = choice_g + (size_t)sample * L;
-    int run = 0, lower = 0;
+    int run = 0;
     for (int j0 = 0; j0 < L; j0 += 64) {
       const int j = j0 + lane;
       const int c = j < L ? (int)ch[j] : 255;
       const unsigned long long mine = __ballot(c == rate);
-      const unsigned long long low = __ballot(c < rate);
       if (c == rate) list[run + __popcll(mine & ((1ull << lane) - 1ull))] = j;
       run += __popcll(mine);
-      lower += __popcll(low);
+    }
+    int base = 0, prun = 0;
+    for (int k = 0; k <= rate; ++k) {
+      int cntk = 0;
+      for (int p0 = 0; p0 < NP; p0 += 64) {
+        const int p = p0 + lane;
+        const bool f = p < NP && flags[k * NP + p] != 0;
+        const unsigned long long m = __ballot(f);
+        if (k == rate && f) {
+          const int pos = cntk + __popcll(m & ((1ull << lane) - 1ull));
+          plist[pos] = p;
+          pslot[p] = pos;
+        }
+        cntk += __popcll(m);
+      }
+      if (k < rate)
+        base += (cntk + 7) & ~7;
+      else
+        prun = cntk;
     }
     if (lane == 0) {
       misc[0] = run;
-      // region of this category in the sample's slot space: starts on a multiple of 8 slots (one 128-byte
-      // line of a 16-byte-per-slot plane), disjoint from the other categories' regions (Lp >= L + 8 R + 7)
-      misc[1] = ((lower + 7) & ~7) + 8 * rate;
+      misc[1] = base;
+      misc[2] = prun;
     }
   }
   __syncthreads();
-  const int cnt = misc[0], base = misc[1];
+  const int cnt = misc[0], base = misc[1], cntp = misc[2];
   if (cnt == 0) return;  // no site of this sample drew this category (uniform over the workgroup)
 
   // ---- schedule bookkeeping (one thread): which op produced the sibling a pop op takes from the stack, and
@@ -285,162 +319,183 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
   const double* __restrict__ p4 = pi + (size_t)sample * 4;
   const uint8_t* __restrict__ nv = naive + (size_t)sample * L;
   // CLV area of the sample: [op][2][Lp] double2 -- components (0,1) and (2,3) of a slot are 16-byte entries of
-  // two planes, so a wave's store is one contiguous run of whole 128-byte lines per plane
+  // two planes, so a wave's store is one contiguous run of whole 128-byte lines per plane.  Cherry nodes are
+  // not stored: their CLV is the product of two tip-table columns and is formed again where it is needed.
   const size_t plane = (size_t)Lp;
   double2* clv_s = clv + (size_t)sample * n_ops * 2 * plane;
   uint8_t* anc_s = anc + (size_t)sample * n_ops * (size_t)L;
   uint8_t* my_stack = st_stack + tid;
 
-  // The walk is latency-bound (dependent loads per op), not lane-bound: the sites of this category are spread
-  // evenly over ALL waves of the workgroup (a category typically holds a quarter of the sites, fewer than two
-  // full waves), so that every resident wave carries a dependency chain.
-  const int per = min(64, (((cnt + n_waves - 1) / n_waves) + 15) & ~15);  // sites per wave and round
-  for (int s0 = wave * per; s0 < cnt; s0 += n_waves * per) {
-    const int slot = s0 + lane;
-    const bool active = lane < per && slot < cnt;
-    const int site = list[active ? slot : cnt - 1];
-    const int gslot = base + (active ? slot : cnt - 1);
-    const int pat = site_pat[site];
-    const bool all_n = pat >= n_prune;
-    const unsigned upat = all_n ? 0u : (unsigned)pat;
-    const int b_naive = nv[site];
-
-    // ---- upward pass: CLV of every op's node, stored for the way down.  What op k + 1 needs from memory
-    // (its tips' states, or the CLV of the sibling it pops, stored at least two ops earlier) is requested
-    // while op k computes.
-    double a[4] = {1.0, 1.0, 1.0, 1.0};
-    int sa, sb = 4;
-    double y[4] = {0.0, 0.0, 0.0, 0.0};
-    {
-      const int4 op0 = ops_s[0];  // the first op is a cherry
-      sa = all_n ? 4 : (int)msa[(unsigned)((op0.y - 1) * n_prune) + upat];
-      sb = all_n ? 4 : (int)msa[(unsigned)((op0.z - 1) * n_prune) + upat];
-    }
-    for (int k = 0; k < n_ops; ++k) {
-      const int4 op = ops_s[k];
-      const int kind = __builtin_amdgcn_readfirstlane(op.x & 15);
-      const int oy = __builtin_amdgcn_readfirstlane(op.y), oz = __builtin_amdgcn_readfirstlane(op.z);
-      int sa_n = 4, sb_n = 4;
-      double y_n[4] = {0.0, 0.0, 0.0, 0.0};
-      if (k + 1 < n_ops) {
-        const int4 on = ops_s[k + 1];
-        const int kn = __builtin_amdgcn_readfirstlane(on.x & 15);
-        const int ny = __builtin_amdgcn_readfirstlane(on.y), nz = __builtin_amdgcn_readfirstlane(on.z);
-        if (kn == OP_POP_ACC) {
-          const int q = __builtin_amdgcn_readfirstlane(popped_op[k + 1]);
-          const double2* cq = clv_s + (size_t)q * 2 * plane + gslot;
-          const double2 lo = cq[0], hi = cq[plane];
-          y_n[0] = lo.x, y_n[1] = lo.y, y_n[2] = hi.x, y_n[3] = hi.y;
-        } else {
-          if (!all_n) sa_n = (int)msa[(unsigned)((ny - 1) * n_prune) + upat];
-          if (kn == OP_CHERRY && !all_n) sb_n = (int)msa[(unsigned)((nz - 1) * n_prune) + upat];
-        }
-      }
+  if (dbg_mode == 1) return;
+  // CLV of the node that op j produced, for the pattern `upat` (all_n: the all-N padding column) in slot gslot
+  auto node_clv = [&](int j, unsigned upat, bool all_n, int gslot, double (&c)[4]) {
+    const int4 oj = ops_s[j];
+    const int kj = __builtin_amdgcn_readfirstlane(oj.x & 15);
+    if (kj == OP_CHERRY) {
+      const int jy = __builtin_amdgcn_readfirstlane(oj.y), jz = __builtin_amdgcn_readfirstlane(oj.z);
+      const int s1 = all_n ? 4 : (int)msa[(unsigned)((jy - 1) * n_prune) + upat];
+      const int s2 = all_n ? 4 : (int)msa[(unsigned)((jz - 1) * n_prune) + upat];
       double u[4], v[4];
-      if (kind == OP_CHERRY) {
-        tip_col(tiptab, oy, sa, u);
-        tip_col(tiptab, oz, sb, v);
-      } else {
-        matvec_lds(pin + (size_t)(k - 1) * 16, a, v);
-        if (kind == OP_TIP_ACC) {
-          tip_col(tiptab, oy, sa, u);
-        } else {
-          const int q = __builtin_amdgcn_readfirstlane(popped_op[k]);
-          matvec_lds(pin + (size_t)q * 16, y, u);
-        }
-      }
+      tip_col(tiptab, jy, s1, u);
+      tip_col(tiptab, jz, s2, v);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = u[i] * v[i];
-      if (fmax(fmax(a[0], a[1]), fmax(a[2], a[3])) < kScaleThreshold) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] *= kScaleFactor;
-      }
-      if (active) {
-        double2* ck = clv_s + (size_t)k * 2 * plane + gslot;
-        ck[0] = make_double2(a[0], a[1]);
-        ck[plane] = make_double2(a[2], a[3]);
-      }
-      sa = sa_n;
-      sb = sb_n;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) y[i] = y_n[i];
+      for (int i = 0; i < 4; ++i) c[i] = u[i] * v[i];
+    } else {
+      const double2* cj = clv_s + (size_t)j * 2 * plane + gslot;
+      const double2 lo = cj[0], hi = cj[plane];
+      c[0] = lo.x, c[1] = lo.y, c[2] = hi.x, c[3] = hi.y;
     }
+  };
 
-    // ---- downward pass: the schedule in reverse; the children's CLVs of op k - 1 are requested while op k
-    // draws (their addresses do not depend on the states)
-    int s_acc = 0;
-    double c_acc[4] = {0.0, 0.0, 0.0, 0.0}, c_pop[4] = {0.0, 0.0, 0.0, 0.0};
-    {
-      const int k = n_ops - 1;
-      const int kind = __builtin_amdgcn_readfirstlane(ops_s[k].x & 15);
-      if (kind != OP_CHERRY) {
-        const double2* cj = clv_s + (size_t)(k - 1) * 2 * plane + gslot;
-        const double2 lo = cj[0], hi = cj[plane];
-        c_acc[0] = lo.x, c_acc[1] = lo.y, c_acc[2] = hi.x, c_acc[3] = hi.y;
+  // ---- upward pass over the category's distinct patterns, spread evenly over ALL waves of the workgroup (the
+  // walk is bound by its dependent memory round trips, not by lanes).  What op k + 1 needs from memory (its
+  // tips' states, or the CLV of the sibling it pops, stored at least two ops earlier) is requested while op k
+  // computes.
+  {
+    const int per = min(64, (((cntp + n_waves - 1) / n_waves) + 15) & ~15);
+    for (int s0 = wave * per; s0 < cntp; s0 += n_waves * per) {
+      const int slot = s0 + lane;
+      const bool active = lane < per && slot < cntp;
+      const int pat = plist[active ? slot : cntp - 1];
+      const int gslot = base + (active ? slot : cntp - 1);
+      const bool all_n = pat >= n_prune;
+      const unsigned upat = all_n ? 0u : (unsigned)pat;
+      double a[4] = {1.0, 1.0, 1.0, 1.0};
+      int sa, sb = 4;
+      double y[4] = {0.0, 0.0, 0.0, 0.0};
+      {
+        const int4 op0 = ops_s[0];  // the first op is a cherry
+        sa = all_n ? 4 : (int)msa[(unsigned)((op0.y - 1) * n_prune) + upat];
+        sb = all_n ? 4 : (int)msa[(unsigned)((op0.z - 1) * n_prune) + upat];
       }
-      if (kind == OP_POP_ACC) {
-        const double2* cq = clv_s + (size_t)__builtin_amdgcn_readfirstlane(popped_op[k]) * 2 * plane + gslot;
-        const double2 lo = cq[0], hi = cq[plane];
-        c_pop[0] = lo.x, c_pop[1] = lo.y, c_pop[2] = hi.x, c_pop[3] = hi.y;
+      for (int k = 0; k < n_ops; ++k) {
+        const int4 op = ops_s[k];
+        const int kind = __builtin_amdgcn_readfirstlane(op.x & 15);
+        const int oy = __builtin_amdgcn_readfirstlane(op.y), oz = __builtin_amdgcn_readfirstlane(op.z);
+        int sa_n = 4, sb_n = 4;
+        double y_n[4] = {0.0, 0.0, 0.0, 0.0};
+        if (k + 1 < n_ops) {
+          const int4 on = ops_s[k + 1];
+          const int kn = __builtin_amdgcn_readfirstlane(on.x & 15);
+          const int ny = __builtin_amdgcn_readfirstlane(on.y), nz = __builtin_amdgcn_readfirstlane(on.z);
+          if (kn == OP_POP_ACC) {
+            node_clv(__builtin_amdgcn_readfirstlane(popped_op[k + 1]), upat, all_n, gslot, y_n);
+          } else {
+            if (!all_n) sa_n = (int)msa[(unsigned)((ny - 1) * n_prune) + upat];
+            if (kn == OP_CHERRY && !all_n) sb_n = (int)msa[(unsigned)((nz - 1) * n_prune) + upat];
+          }
+        }
+        double u[4], v[4];
+        if (kind == OP_CHERRY) {
+          tip_col(tiptab, oy, sa, u);
+          tip_col(tiptab, oz, sb, v);
+        } else {
+          matvec_lds(pin + (size_t)(k - 1) * 16, a, v);
+          if (kind == OP_TIP_ACC) {
+            tip_col(tiptab, oy, sa, u);
+          } else {
+            const int q = __builtin_amdgcn_readfirstlane(popped_op[k]);
+            matvec_lds(pin + (size_t)q * 16, y, u);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = u[i] * v[i];
+        if (kind != OP_CHERRY) {
+          if (fmax(fmax(a[0], a[1]), fmax(a[2], a[3])) < kScaleThreshold) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] *= kScaleFactor;
+          }
+          if (active) {
+            double2* ck = clv_s + (size_t)k * 2 * plane + gslot;
+            ck[0] = make_double2(a[0], a[1]);
+            ck[plane] = make_double2(a[2], a[3]);
+          }
+        }
+        sa = sa_n;
+        sb = sb_n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = y_n[i];
       }
     }
-    for (int k = n_ops - 1; k >= 0; --k) {
-      const int4 op = ops_s[k];
-      const int kind = __builtin_amdgcn_readfirstlane(op.x & 15);
-      double n_acc[4] = {0.0, 0.0, 0.0, 0.0}, n_pop[4] = {0.0, 0.0, 0.0, 0.0};
-      if (k > 0) {
-        const int kp = __builtin_amdgcn_readfirstlane(ops_s[k - 1].x & 15);
-        if (kp != OP_CHERRY) {
-          const double2* cj = clv_s + (size_t)(k - 2) * 2 * plane + gslot;
-          const double2 lo = cj[0], hi = cj[plane];
-          n_acc[0] = lo.x, n_acc[1] = lo.y, n_acc[2] = hi.x, n_acc[3] = hi.y;
+  }
+  if (dbg_mode == 2) return;
+  // the sites' lanes below read CLVs that other lanes and waves of this workgroup stored above
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- downward pass over the category's sites: the schedule in reverse; the children's CLVs of op k - 1 are
+  // requested while op k draws (their addresses do not depend on the states)
+  {
+    const int per = min(64, (((cnt + n_waves - 1) / n_waves) + 15) & ~15);
+    for (int s0 = wave * per; s0 < cnt; s0 += n_waves * per) {
+      const int slot = s0 + lane;
+      const bool active = lane < per && slot < cnt;
+      const int site = list[active ? slot : cnt - 1];
+      const int pat = min(site_pat[site], n_prune);
+      const bool all_n = pat >= n_prune;
+      const unsigned upat = all_n ? 0u : (unsigned)pat;
+      const int gslot = base + pslot[pat];
+      const int b_naive = nv[site];
+      int s_acc = 0;
+      double c_acc[4] = {0.0, 0.0, 0.0, 0.0}, c_pop[4] = {0.0, 0.0, 0.0, 0.0}, c_root[4];
+      node_clv(n_ops - 1, upat, all_n, gslot, c_root);
+      {
+        const int k = n_ops - 1;
+        const int kind = __builtin_amdgcn_readfirstlane(ops_s[k].x & 15);
+        if (kind != OP_CHERRY) node_clv(k - 1, upat, all_n, gslot, c_acc);
+        if (kind == OP_POP_ACC) node_clv(__builtin_amdgcn_readfirstlane(popped_op[k]), upat, all_n, gslot, c_pop);
+      }
+      for (int k = n_ops - 1; k >= 0; --k) {
+        const int4 op = ops_s[k];
+        const int kind = __builtin_amdgcn_readfirstlane(op.x & 15);
+        double n_acc[4] = {0.0, 0.0, 0.0, 0.0}, n_pop[4] = {0.0, 0.0, 0.0, 0.0};
+        if (k > 0) {
+          const int kp = __builtin_amdgcn_readfirstlane(ops_s[k - 1].x & 15);
+          if (kp != OP_CHERRY) node_clv(k - 2, upat, all_n, gslot, n_acc);
+          if (kp == OP_POP_ACC)
+            node_clv(__builtin_amdgcn_readfirstlane(popped_op[k - 1]), upat, all_n, gslot, n_pop);
         }
-        if (kp == OP_POP_ACC) {
-          const double2* cq = clv_s + (size_t)__builtin_amdgcn_readfirstlane(popped_op[k - 1]) * 2 * plane + gslot;
-          const double2 lo = cq[0], hi = cq[plane];
-          n_pop[0] = lo.x, n_pop[1] = lo.y, n_pop[2] = hi.x, n_pop[3] = hi.y;
+        int s_cur;
+        if (k == n_ops - 1) {
+          // root = naive's neighbour: pi_i * L_root(i) * P_naive[i][naive base]
+          double down[4], w[4];
+          tip_col(tiptab, 0, b_naive, down);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) w[i] = p4[i] * c_root[i] * down[i];
+          s_cur = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 1u));
+          if (active) anc_s[(size_t)(node_of_op[k] - T) * L + site] = (uint8_t)s_cur;
+        } else {
+          const int4 nxt = ops_s[k + 1];
+          const int nx = __builtin_amdgcn_readfirstlane(nxt.x), nw = __builtin_amdgcn_readfirstlane(nxt.w);
+          s_cur = (nx & OP_PUSH_FLAG) ? (int)my_stack[nw * 256] : s_acc;
         }
-      }
-      int s_cur;
-      if (k == n_ops - 1) {
-        // root = naive's neighbour: pi_i * L_root(i) * P_naive[i][naive base]
-        double down[4], w[4];
-        tip_col(tiptab, 0, b_naive, down);
+        if (kind != OP_CHERRY) {
+          const int j = k - 1;  // the accumulator child
+          const int node = __builtin_amdgcn_readfirstlane(node_of_op[j]);
+          const double* prow = pin + (size_t)j * 16 + s_cur * 4;
+          double w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = p4[i] * a[i] * down[i];
-        s_cur = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 1u));
-        if (active) anc_s[(size_t)(node_of_op[k] - T) * L + site] = (uint8_t)s_cur;
-      } else {
-        const int4 nxt = ops_s[k + 1];
-        const int nx = __builtin_amdgcn_readfirstlane(nxt.x), nw = __builtin_amdgcn_readfirstlane(nxt.w);
-        s_cur = (nx & OP_PUSH_FLAG) ? (int)my_stack[nw * 256] : s_acc;
-      }
-      if (kind != OP_CHERRY) {
-        const int j = k - 1;  // the accumulator child
-        const int node = __builtin_amdgcn_readfirstlane(node_of_op[j]);
-        const double* prow = pin + (size_t)j * 16 + s_cur * 4;
-        double w[4];
+          for (int i = 0; i < 4; ++i) w[i] = prow[i] * c_acc[i];
+          s_acc = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)(node - T)));
+          if (active) anc_s[(size_t)(node - T) * L + site] = (uint8_t)s_acc;
+        }
+        if (kind == OP_POP_ACC) {
+          const int q = __builtin_amdgcn_readfirstlane(popped_op[k]);
+          const int node = __builtin_amdgcn_readfirstlane(node_of_op[q]);
+          const int ow = __builtin_amdgcn_readfirstlane(op.w);
+          const double* prow = pin + (size_t)q * 16 + s_cur * 4;
+          double w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = prow[i] * c_acc[i];
-        s_acc = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)(node - T)));
-        if (active) anc_s[(size_t)(node - T) * L + site] = (uint8_t)s_acc;
-      }
-      if (kind == OP_POP_ACC) {
-        const int q = __builtin_amdgcn_readfirstlane(popped_op[k]);
-        const int node = __builtin_amdgcn_readfirstlane(node_of_op[q]);
-        const int ow = __builtin_amdgcn_readfirstlane(op.w);
-        const double* prow = pin + (size_t)q * 16 + s_cur * 4;
-        double w[4];
+          for (int i = 0; i < 4; ++i) w[i] = prow[i] * c_pop[i];
+          const int sq = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)(node - T)));
+          if (active) anc_s[(size_t)(node - T) * L + site] = (uint8_t)sq;
+          my_stack[ow * 256] = (uint8_t)sq;
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = prow[i] * c_pop[i];
-        const int sq = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)(node - T)));
-        if (active) anc_s[(size_t)(node - T) * L + site] = (uint8_t)sq;
-        my_stack[ow * 256] = (uint8_t)sq;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        c_acc[i] = n_acc[i];
-        c_pop[i] = n_pop[i];
+        for (int i = 0; i < 4; ++i) {
+          c_acc[i] = n_acc[i];
+          c_pop[i] = n_pop[i];
+        }
       }
     }
   }
@@ -451,7 +506,7 @@ int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, co
                const uint8_t* naive, uint64_t seed, uint64_t sample0, double* clv, uint8_t* anc,
                uint8_t* rate_choice, hipStream_t stream) {
   const int L = fam.n_sites;
-  const size_t lds = asr_lds_bytes(T, L);
+  const size_t lds = asr_lds_bytes(T, L, R, fam.n_prune);
   if (lds > 160 * 1024 || L < 1) return 1;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(asr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -461,7 +516,8 @@ int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, co
                      fam.n_prune, fam.site_pat, site_lik, site_scal, naive, seed, sample0, rate_choice);
   hipLaunchKernelGGL(asr_kernel, dim3(R, n), dim3(256), lds, stream, R, T, L, fam.n_prune, fam.msa, fam.site_pat, ops,
                      brlen, rates, eig, pi, (const uint8_t*)rate_choice, naive, seed, sample0,
-                     reinterpret_cast<double2*>(clv), (int)asr_slots(L, R), anc);
+                     reinterpret_cast<double2*>(clv), (int)asr_slots(L, R), anc,
+                     getenv("LH_ASR_DBG") ? atoi(getenv("LH_ASR_DBG")) : 0);
   return 0;
 }
 

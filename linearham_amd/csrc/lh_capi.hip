@@ -904,7 +904,7 @@ int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, c
   if (R < 1 || R > 64) return fail("lh_asr_batch: num_rates out of range");
   if (max_depth < 0 || max_depth > 16) return fail("lh_asr_batch: max_depth out of range");
   if ((size_t)T * 128 > 160 * 1024) return fail("lh_asr_batch: too many tips for the LDS tip table");
-  if (lh::asr_lds_bytes(T, f->host.n_sites) > 160 * 1024)
+  if (lh::asr_lds_bytes(T, f->host.n_sites, R, f->host.n_prune) > 160 * 1024)
     return fail("lh_asr_batch: tree / alignment too large for the sampling kernel's LDS tables");
   if (!ops || !brlen || !er || !pi || !rates || !naive || !anc) return fail("lh_asr_batch: null array");
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);

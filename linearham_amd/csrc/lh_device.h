@@ -125,7 +125,7 @@ int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, co
                const double* eig, const double* pi, const double* site_lik, const int32_t* site_scal,
                const uint8_t* naive, uint64_t seed, uint64_t sample0, double* clv, uint8_t* anc,
                uint8_t* rate_choice, hipStream_t stream);
-size_t asr_lds_bytes(int T, int L);
+size_t asr_lds_bytes(int T, int L, int R, int n_prune);
 size_t asr_slots(int L, int R);  // slots per sample in K3's CLV area: clv[n][T-2][2][asr_slots] double2
 
 // K2a + K2b.  site_lik != null: emissions are assembled from K1's output (rate mix and naive
