@@ -99,8 +99,6 @@ size_t asr_lds_bytes(int T, int L, int R, int n_prune) {
   size_t b = 0;
   b += (size_t)T * 16 * sizeof(double);          // tiptab
   b += n_ops * 16 * sizeof(double);              // pin
-  b += n_ops * sizeof(int4);                     // ops
-  b += n_ops * 2 * sizeof(int32_t);              // popped_op, node_of_op
   b += (size_t)L * sizeof(int32_t);              // list (sites of the category)
   b += NP * 2 * sizeof(int32_t);                 // plist, pslot
   b += 16 * 256;                                 // state stack [16][256]
@@ -108,6 +106,17 @@ size_t asr_lds_bytes(int T, int L, int R, int n_prune) {
   b += 16;                                       // counters
   return b;
 }
+
+// One schedule op as the sampling kernel reads it (two int4, fetched with scalar loads): everything that K3b
+// would otherwise have to derive per op from the K1 schedule with dependent look-ups.
+//   a.x  kind | stack slot of the op << 4 | (slot + 1 the NEXT op pushes the accumulator to, or 0) << 8
+//   a.y  MSA row of tip child y (cherry, tip-acc), else 0        a.z  MSA row of tip child z (cherry), else 0
+//   a.w  op that produced the sibling a pop op takes from the stack, else 0
+//   b.x  tip id y (tip table row)   b.y  tip id z   b.z  inner node (minus T) this op produces
+//   b.w  inner node (minus T) of the popped sibling (pop), else 0
+struct AsrOp {
+  int4 a, b;
+};
 
 // K3a: the rate category of every (sample, site): one thread each.  Weights = K1's per-rate column
 // likelihoods for the site's naive base, scalers aligned to the smallest (the arithmetic of K2a's mixture).
@@ -157,9 +166,80 @@ __global__ void __launch_bounds__(256) asr_rate_kernel(int n, int R, int L, int 
   choice[gid] = (uint8_t)pick;
 }
 
+// K3s: per sample, the schedule in the form K3b walks it (one thread does the stack bookkeeping out of LDS,
+// then a thread per op writes its descriptor).
+__global__ void __launch_bounds__(64) asr_sched_kernel(int T, const int32_t* __restrict__ ops,
+                                                       AsrOp* __restrict__ desc) {
+  extern __shared__ double2 sched_smem[];
+  const int n_ops = T - 2;
+  int4* ops_s = reinterpret_cast<int4*>(sched_smem);               // [n_ops]
+  int32_t* popped_op = reinterpret_cast<int32_t*>(ops_s + n_ops);  // [n_ops]
+  int32_t* node_of_op = popped_op + n_ops;                         // [n_ops]
+  const int tid = threadIdx.x;
+  const int sample = blockIdx.x;
+  const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
+  for (int k = tid; k < n_ops; k += blockDim.x) {
+    ops_s[k] = op_ptr[k];
+    popped_op[k] = 0;
+  }
+  __syncthreads();
+  // which op produced the sibling a pop op takes from the stack, and which tree node every op produces; the 16
+  // stack slots' op numbers sit in four 64-bit registers
+  if (tid == 0) {
+    unsigned long long so[4] = {0, 0, 0, 0};
+    long long named = 0;
+    for (int k = 0; k < n_ops; ++k) {
+      const int4 op = ops_s[k];
+      const int kind = op.x & 15;
+      const int sh = (op.w & 3) * 16, wi = (op.w >> 2) & 3;
+      if (op.x & OP_PUSH_FLAG) {
+        const unsigned long long v = (unsigned long long)(unsigned)(k - 1) << sh, m = ~(0xffffull << sh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i == wi) so[i] = (so[i] & m) | v;
+      }
+      if (kind == OP_TIP_ACC) {
+        node_of_op[k - 1] = op.z;
+        named += op.z;
+      } else if (kind == OP_POP_ACC) {
+        unsigned long long word = so[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+          if (i == wi) word = so[i];
+        const int q = (int)((word >> sh) & 0xffffull);
+        popped_op[k] = q;
+        node_of_op[k - 1] = op.z;
+        node_of_op[q] = op.y;
+        named += op.z + op.y;
+      }
+    }
+    // the root (naive's neighbour) is the one inner node no op names as a child
+    const long long all = (long long)n_ops * T + (long long)n_ops * (n_ops - 1) / 2;
+    node_of_op[n_ops - 1] = (int)(all - named);
+  }
+  __syncthreads();
+  AsrOp* out = desc + (size_t)sample * n_ops;
+  for (int k = tid; k < n_ops; k += blockDim.x) {
+    const int4 op = ops_s[k];
+    const int kind = op.x & 15;
+    int take = 0;
+    if (k + 1 < n_ops && (ops_s[k + 1].x & OP_PUSH_FLAG)) take = ops_s[k + 1].w + 1;
+    AsrOp d;
+    d.a.x = kind | ((op.w & 15) << 4) | (take << 8);
+    d.a.y = kind != OP_POP_ACC ? op.y - 1 : 0;
+    d.a.z = kind == OP_CHERRY ? op.z - 1 : 0;
+    d.a.w = kind == OP_POP_ACC ? popped_op[k] : 0;
+    d.b.x = kind != OP_POP_ACC ? op.y : 0;
+    d.b.y = kind == OP_CHERRY ? op.z : 0;
+    d.b.z = node_of_op[k] - T;
+    d.b.w = kind == OP_POP_ACC ? node_of_op[popped_op[k]] - T : 0;
+    out[k] = d;
+  }
+}
+
 __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_prune, const uint8_t* __restrict__ msa,
                                                   const int32_t* __restrict__ site_pat,
-                                                  const int32_t* __restrict__ ops, const double* __restrict__ brlen,
+                                                  const AsrOp* __restrict__ desc, const double* __restrict__ brlen,
                                                   const double* __restrict__ rates, const double* __restrict__ eig,
                                                   const double* __restrict__ pi,
                                                   const uint8_t* __restrict__ choice_g,
@@ -170,10 +250,7 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
   const int NP = n_prune + 1;  // patterns, the all-N one (id n_prune) included
   double* tiptab = reinterpret_cast<double*>(asr_smem);           // [T][4][4]
   double* pin = tiptab + (size_t)T * 16;                          // [n_ops][4][4] (entry n_ops-1 unused)
-  int4* ops_s = reinterpret_cast<int4*>(pin + (size_t)n_ops * 16);  // [n_ops]
-  int32_t* popped_op = reinterpret_cast<int32_t*>(ops_s + n_ops);  // [n_ops]
-  int32_t* node_of_op = popped_op + n_ops;                         // [n_ops]
-  int32_t* list = node_of_op + n_ops;                              // [L]  sites of this category
+  int32_t* list = reinterpret_cast<int32_t*>(pin + (size_t)n_ops * 16);  // [L]  sites of this category
   int32_t* plist = list + L;                                       // [NP] distinct patterns of those sites
   int32_t* pslot = plist + NP;                                     // [NP] pattern -> position in plist
   uint8_t* st_stack = reinterpret_cast<uint8_t*>(pslot + NP);      // [16][256]
@@ -187,10 +264,9 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
   const int rate = blockIdx.x;
   const int sample = blockIdx.y;
   const uint64_t sample_id = sample0 + (uint64_t)sample;
-  const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
+  const AsrOp* __restrict__ dsc = desc + (size_t)sample * n_ops;
   const uint8_t* __restrict__ ch = choice_g + (size_t)sample * L;
 
-  for (int k = tid; k < n_ops; k += blockDim.x) ops_s[k] = op_ptr[k];
   for (int i = tid; i < R * NP; i += blockDim.x) flags[i] = 0;
   __syncthreads();
   // which patterns occur among the sites of each category (same value from every writer)
@@ -235,186 +311,112 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
       misc[2] = prun;
     }
   }
-  __syncthreads();
-  const int cnt = misc[0], base = misc[1], cntp = misc[2];
-  if (cnt == 0) return;  // no site of this sample drew this category (uniform over the workgroup)
 
-  // ---- schedule bookkeeping (one thread): which op produced the sibling a pop op takes from the stack, and
-  // which tree node every op produces.  The 16 stack slots' op numbers sit in four 64-bit registers.
-  if (tid == 0) {
-    unsigned long long so[4] = {0, 0, 0, 0};
-    long long named = 0;
-    for (int k = 0; k < n_ops; ++k) {
-      const int4 op = ops_s[k];
-      const int kind = op.x & 15;
-      const int sh = (op.w & 3) * 16, wi = (op.w >> 2) & 3;
-      if (op.x & OP_PUSH_FLAG) {
-        const unsigned long long v = (unsigned long long)(unsigned)(k - 1) << sh, m = ~(0xffffull << sh);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (i == wi) so[i] = (so[i] & m) | v;
-      }
-      if (kind == OP_TIP_ACC) {
-        node_of_op[k - 1] = op.z;
-        named += op.z;
-      } else if (kind == OP_POP_ACC) {
-        unsigned long long word = so[0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i)
-          if (i == wi) word = so[i];
-        const int q = (int)((word >> sh) & 0xffffull);
-        popped_op[k] = q;
-        node_of_op[k - 1] = op.z;
-        node_of_op[q] = op.y;
-        named += op.z + op.y;
-      }
-    }
-    // the root (naive's neighbour) is the one inner node no op names as a child
-    const long long all = (long long)n_ops * T + (long long)n_ops * (n_ops - 1) / 2;
-    node_of_op[n_ops - 1] = (int)(all - named);
-  }
-
-  // ---- P-matrices of the tip branches of this (sample, rate) -> tip table (columns of P)
+  // ---- P-matrices of this (sample, rate): tip branches -> tip table (columns of P); inner branches row-major,
+  // indexed by the op that produced the child
   const double* __restrict__ e = eig + (size_t)sample * 36;
   const double rt = rates[(size_t)sample * R + rate];
   const double* __restrict__ bl = brlen + (size_t)sample * (2 * (size_t)T - 2);
   {
     double P[4][4];
-    for (int j = tid; j < T; j += blockDim.x) {
-      compute_pmatrix(e, bl[j] * rt, P);
-      double* o = tiptab + j * 16;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
-    }
-  }
-  __syncthreads();
-
-  // ---- inner-branch P-matrices, indexed by the op that produced the child
-  {
-    double P[4][4];
-    for (int k = tid; k < n_ops; k += blockDim.x) {
-      const int4 op = ops_s[k];
-      const int kind = op.x & 15;
-      if (kind == OP_CHERRY) continue;
-      compute_pmatrix(e, bl[op.z] * rt, P);
-      double* o = pin + (size_t)(k - 1) * 16;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[i * 4 + q] = P[i][q];
-      if (kind == OP_POP_ACC) {
-        compute_pmatrix(e, bl[op.y] * rt, P);
-        double* o2 = pin + (size_t)popped_op[k] * 16;
+    for (int j = tid; j < T + n_ops - 1; j += blockDim.x) {
+      if (j < T) {
+        compute_pmatrix(e, bl[j] * rt, P);
+        double* o = tiptab + j * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o2[i * 4 + q] = P[i][q];
+          for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
+      } else {
+        const int k = j - T;  // op k < n_ops - 1 produced inner node T + b.z, whose branch this is
+        compute_pmatrix(e, bl[T + dsc[k].b.z] * rt, P);
+        double* o = pin + (size_t)k * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[i * 4 + q] = P[i][q];
       }
     }
   }
   __syncthreads();
+  const int cnt = misc[0], base = misc[1], cntp = misc[2];
+  if (cnt == 0 || dbg_mode == 1) return;  // no site of this sample drew this category (uniform)
 
   const double* __restrict__ p4 = pi + (size_t)sample * 4;
   const uint8_t* __restrict__ nv = naive + (size_t)sample * L;
   // CLV area of the sample: [op][2][Lp] double2 -- components (0,1) and (2,3) of a slot are 16-byte entries of
-  // two planes, so a wave's store is one contiguous run of whole 128-byte lines per plane.  Cherry nodes are
-  // not stored: their CLV is the product of two tip-table columns and is formed again where it is needed.
+  // two planes, so a wave's store is one contiguous run of whole 128-byte lines per plane.
   const size_t plane = (size_t)Lp;
   double2* clv_s = clv + (size_t)sample * n_ops * 2 * plane;
   uint8_t* anc_s = anc + (size_t)sample * n_ops * (size_t)L;
   uint8_t* my_stack = st_stack + tid;
 
-  if (dbg_mode == 1) return;
-  // CLV of the node that op j produced, for the pattern `upat` (all_n: the all-N padding column) in slot gslot
-  auto node_clv = [&](int j, unsigned upat, bool all_n, int gslot, double (&c)[4]) {
-    const int4 oj = ops_s[j];
-    const int kj = __builtin_amdgcn_readfirstlane(oj.x & 15);
-    if (kj == OP_CHERRY) {
-      const int jy = __builtin_amdgcn_readfirstlane(oj.y), jz = __builtin_amdgcn_readfirstlane(oj.z);
-      const int s1 = all_n ? 4 : (int)msa[(unsigned)((jy - 1) * n_prune) + upat];
-      const int s2 = all_n ? 4 : (int)msa[(unsigned)((jz - 1) * n_prune) + upat];
-      double u[4], v[4];
-      tip_col(tiptab, jy, s1, u);
-      tip_col(tiptab, jz, s2, v);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) c[i] = u[i] * v[i];
-    } else {
-      const double2* cj = clv_s + (size_t)j * 2 * plane + gslot;
-      const double2 lo = cj[0], hi = cj[plane];
-      c[0] = lo.x, c[1] = lo.y, c[2] = hi.x, c[3] = hi.y;
-    }
-  };
-
-  // ---- upward pass over the category's distinct patterns, spread evenly over ALL waves of the workgroup (the
-  // walk is bound by its dependent memory round trips, not by lanes).  What op k + 1 needs from memory (its
-  // tips' states, or the CLV of the sibling it pops, stored at least two ops earlier) is requested while op k
-  // computes.
+  // ---- upward pass over the category's distinct patterns, spread evenly over ALL waves of the workgroup.
+  // Software pipeline: everything op k + 1 needs from memory -- its tips' states and the CLV of the sibling it
+  // pops (stored at least two ops earlier) -- is requested while op k computes, with loads that do not
+  // depend on the op's kind (descriptor fields an op does not use point at valid dummies), so that no branch
+  // stands between a load and the next iteration.
   {
     const int per = min(64, (((cntp + n_waves - 1) / n_waves) + 15) & ~15);
     for (int s0 = wave * per; s0 < cntp; s0 += n_waves * per) {
-      const int slot = s0 + lane;
-      const bool active = lane < per && slot < cntp;
-      const int pat = plist[active ? slot : cntp - 1];
-      const int gslot = base + (active ? slot : cntp - 1);
+      // Lanes past the end of the wave's share repeat its last pattern: they compute and store the very same
+      // values, so no store needs a predicate (a predicated store is a branch, and a branch between the
+      // prefetch loads and their use makes the wait for them a wait for everything outstanding).
+      const int slot = min(s0 + min(lane, per - 1), cntp - 1);
+      const int pat = plist[slot];
+      const int gslot = base + slot;
       const bool all_n = pat >= n_prune;
       const unsigned upat = all_n ? 0u : (unsigned)pat;
+      const double2* cbase = clv_s + gslot;
       double a[4] = {1.0, 1.0, 1.0, 1.0};
-      int sa, sb = 4;
-      double y[4] = {0.0, 0.0, 0.0, 0.0};
-      {
-        const int4 op0 = ops_s[0];  // the first op is a cherry
-        sa = all_n ? 4 : (int)msa[(unsigned)((op0.y - 1) * n_prune) + upat];
-        sb = all_n ? 4 : (int)msa[(unsigned)((op0.z - 1) * n_prune) + upat];
-      }
-      for (int k = 0; k < n_ops; ++k) {
-        const int4 op = ops_s[k];
-        const int kind = __builtin_amdgcn_readfirstlane(op.x & 15);
-        const int oy = __builtin_amdgcn_readfirstlane(op.y), oz = __builtin_amdgcn_readfirstlane(op.z);
-        int sa_n = 4, sb_n = 4;
-        double y_n[4] = {0.0, 0.0, 0.0, 0.0};
-        if (k + 1 < n_ops) {
-          const int4 on = ops_s[k + 1];
-          const int kn = __builtin_amdgcn_readfirstlane(on.x & 15);
-          const int ny = __builtin_amdgcn_readfirstlane(on.y), nz = __builtin_amdgcn_readfirstlane(on.z);
-          if (kn == OP_POP_ACC) {
-            node_clv(__builtin_amdgcn_readfirstlane(popped_op[k + 1]), upat, all_n, gslot, y_n);
-          } else {
-            if (!all_n) sa_n = (int)msa[(unsigned)((ny - 1) * n_prune) + upat];
-            if (kn == OP_CHERRY && !all_n) sb_n = (int)msa[(unsigned)((nz - 1) * n_prune) + upat];
-          }
-        }
+      // What one op needs from memory.  Two such sets alternate (the loop is unrolled by two) so that the set
+      // being filled for op k + 1 is never copied: a register copy at the end of an iteration would be a use,
+      // and the wait for the loads would land in the iteration that issued them.
+      struct Pre {
+        int4 da, db;
+        int sa, sb;
+        double2 ylo, yhi;
+      };
+      auto fetch = [&](int k, Pre& p) {
+        p.da = dsc[k].a;
+        p.db = dsc[k].b;
+        p.sa = msa[(unsigned)(p.da.y * n_prune) + upat];
+        p.sb = msa[(unsigned)(p.da.z * n_prune) + upat];
+        const double2* cq = cbase + (size_t)p.da.w * 2 * plane;
+        p.ylo = cq[0];
+        p.yhi = cq[plane];
+      };
+      auto step = [&](int k, const Pre& c, Pre& n) {
+        fetch(k + 1 < n_ops ? k + 1 : k, n);
+        const int kind = c.da.x & 15;
         double u[4], v[4];
         if (kind == OP_CHERRY) {
-          tip_col(tiptab, oy, sa, u);
-          tip_col(tiptab, oz, sb, v);
+          tip_col(tiptab, c.db.x, all_n ? 4 : c.sa, u);
+          tip_col(tiptab, c.db.y, all_n ? 4 : c.sb, v);
         } else {
           matvec_lds(pin + (size_t)(k - 1) * 16, a, v);
           if (kind == OP_TIP_ACC) {
-            tip_col(tiptab, oy, sa, u);
+            tip_col(tiptab, c.db.x, all_n ? 4 : c.sa, u);
           } else {
-            const int q = __builtin_amdgcn_readfirstlane(popped_op[k]);
-            matvec_lds(pin + (size_t)q * 16, y, u);
+            const double y[4] = {c.ylo.x, c.ylo.y, c.yhi.x, c.yhi.y};
+            matvec_lds(pin + (size_t)c.da.w * 16, y, u);
           }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = u[i] * v[i];
-        if (kind != OP_CHERRY) {
-          if (fmax(fmax(a[0], a[1]), fmax(a[2], a[3])) < kScaleThreshold) {
+        if (fmax(fmax(a[0], a[1]), fmax(a[2], a[3])) < kScaleThreshold) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] *= kScaleFactor;
-          }
-          if (active) {
-            double2* ck = clv_s + (size_t)k * 2 * plane + gslot;
-            ck[0] = make_double2(a[0], a[1]);
-            ck[plane] = make_double2(a[2], a[3]);
-          }
+          for (int i = 0; i < 4; ++i) a[i] *= kScaleFactor;
         }
-        sa = sa_n;
-        sb = sb_n;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = y_n[i];
+        double2* ck = clv_s + (size_t)k * 2 * plane + gslot;
+        ck[0] = make_double2(a[0], a[1]);
+        ck[plane] = make_double2(a[2], a[3]);
+      };
+      Pre A, B;
+      fetch(0, A);
+      for (int k = 0; k < n_ops; k += 2) {
+        step(k, A, B);
+        if (k + 1 < n_ops) step(k + 1, B, A);
       }
     }
   }
@@ -423,87 +425,83 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
   __threadfence_block();
   __syncthreads();
 
-  // ---- downward pass over the category's sites: the schedule in reverse; the children's CLVs of op k - 1 are
-  // requested while op k draws (their addresses do not depend on the states)
+  // ---- downward pass over the category's sites: the schedule in reverse.  The CLVs of op k - 1's children
+  // are requested while op k draws (their addresses depend on the schedule only, not on the states).
   {
     const int per = min(64, (((cnt + n_waves - 1) / n_waves) + 15) & ~15);
     for (int s0 = wave * per; s0 < cnt; s0 += n_waves * per) {
-      const int slot = s0 + lane;
-      const bool active = lane < per && slot < cnt;
-      const int site = list[active ? slot : cnt - 1];
+      const int slot = min(s0 + min(lane, per - 1), cnt - 1);  // surplus lanes repeat the last site (same draws)
+      const int site = list[slot];
       const int pat = min(site_pat[site], n_prune);
-      const bool all_n = pat >= n_prune;
-      const unsigned upat = all_n ? 0u : (unsigned)pat;
-      const int gslot = base + pslot[pat];
+      const double2* cbase = clv_s + base + pslot[pat];
       const int b_naive = nv[site];
+      // children of op k: the accumulator child is op k - 1, the popped one op da.w (dummies: op 0); two sets
+      // alternate as on the way up
+      struct Pre {
+        int4 da, db;
+        int node_acc;
+        double2 alo, ahi, plo, phi;
+      };
+      auto fetch = [&](int k, Pre& p) {
+        p.da = dsc[k].a;
+        p.db = dsc[k].b;
+        const int j = k > 0 ? k - 1 : 0;
+        p.node_acc = dsc[j].b.z;  // the accumulator child is the node op k - 1 produced
+        const double2* ca = cbase + (size_t)j * 2 * plane;
+        p.alo = ca[0];
+        p.ahi = ca[plane];
+        const double2* cp = cbase + (size_t)p.da.w * 2 * plane;
+        p.plo = cp[0];
+        p.phi = cp[plane];
+      };
       int s_acc = 0;
-      double c_acc[4] = {0.0, 0.0, 0.0, 0.0}, c_pop[4] = {0.0, 0.0, 0.0, 0.0}, c_root[4];
-      node_clv(n_ops - 1, upat, all_n, gslot, c_root);
-      {
-        const int k = n_ops - 1;
-        const int kind = __builtin_amdgcn_readfirstlane(ops_s[k].x & 15);
-        if (kind != OP_CHERRY) node_clv(k - 1, upat, all_n, gslot, c_acc);
-        if (kind == OP_POP_ACC) node_clv(__builtin_amdgcn_readfirstlane(popped_op[k]), upat, all_n, gslot, c_pop);
-      }
-      for (int k = n_ops - 1; k >= 0; --k) {
-        const int4 op = ops_s[k];
-        const int kind = __builtin_amdgcn_readfirstlane(op.x & 15);
-        double n_acc[4] = {0.0, 0.0, 0.0, 0.0}, n_pop[4] = {0.0, 0.0, 0.0, 0.0};
-        if (k > 0) {
-          const int kp = __builtin_amdgcn_readfirstlane(ops_s[k - 1].x & 15);
-          if (kp != OP_CHERRY) node_clv(k - 2, upat, all_n, gslot, n_acc);
-          if (kp == OP_POP_ACC)
-            node_clv(__builtin_amdgcn_readfirstlane(popped_op[k - 1]), upat, all_n, gslot, n_pop);
-        }
-        int s_cur;
-        if (k == n_ops - 1) {
-          // root = naive's neighbour: pi_i * L_root(i) * P_naive[i][naive base]
-          double down[4], w[4];
-          tip_col(tiptab, 0, b_naive, down);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) w[i] = p4[i] * c_root[i] * down[i];
-          s_cur = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 1u));
-          if (active) anc_s[(size_t)(node_of_op[k] - T) * L + site] = (uint8_t)s_cur;
-        } else {
-          const int4 nxt = ops_s[k + 1];
-          const int nx = __builtin_amdgcn_readfirstlane(nxt.x), nw = __builtin_amdgcn_readfirstlane(nxt.w);
-          s_cur = (nx & OP_PUSH_FLAG) ? (int)my_stack[nw * 256] : s_acc;
-        }
+      auto step = [&](int k, const Pre& c, Pre& n) {
+        fetch(k > 0 ? k - 1 : 0, n);
+        const int kind = c.da.x & 15;
+        const int take = (c.da.x >> 8) & 31;
+        const int s_cur = take ? (int)my_stack[(take - 1) * 256] : s_acc;
         if (kind != OP_CHERRY) {
-          const int j = k - 1;  // the accumulator child
-          const int node = __builtin_amdgcn_readfirstlane(node_of_op[j]);
-          const double* prow = pin + (size_t)j * 16 + s_cur * 4;
-          double w[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) w[i] = prow[i] * c_acc[i];
-          s_acc = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)(node - T)));
-          if (active) anc_s[(size_t)(node - T) * L + site] = (uint8_t)s_acc;
+          const double* prow = pin + (size_t)(k - 1) * 16 + s_cur * 4;
+          const double w[4] = {prow[0] * c.alo.x, prow[1] * c.alo.y, prow[2] * c.ahi.x, prow[3] * c.ahi.y};
+          s_acc = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)c.node_acc));
+          anc_s[(size_t)c.node_acc * L + site] = (uint8_t)s_acc;
         }
         if (kind == OP_POP_ACC) {
-          const int q = __builtin_amdgcn_readfirstlane(popped_op[k]);
-          const int node = __builtin_amdgcn_readfirstlane(node_of_op[q]);
-          const int ow = __builtin_amdgcn_readfirstlane(op.w);
-          const double* prow = pin + (size_t)q * 16 + s_cur * 4;
-          double w[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) w[i] = prow[i] * c_pop[i];
-          const int sq = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)(node - T)));
-          if (active) anc_s[(size_t)(node - T) * L + site] = (uint8_t)sq;
-          my_stack[ow * 256] = (uint8_t)sq;
+          const int node = c.db.w;
+          const double* prow = pin + (size_t)c.da.w * 16 + s_cur * 4;
+          const double w[4] = {prow[0] * c.plo.x, prow[1] * c.plo.y, prow[2] * c.phi.x, prow[3] * c.phi.y};
+          const int sq = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)node));
+          anc_s[(size_t)node * L + site] = (uint8_t)sq;
+          my_stack[((c.da.x >> 4) & 15) * 256] = (uint8_t)sq;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          c_acc[i] = n_acc[i];
-          c_pop[i] = n_pop[i];
-        }
+      };
+      Pre A, B;
+      fetch(n_ops - 1, A);
+      {
+        // root = naive's neighbour: pi_i * L_root(i) * P_naive[i][naive base]; the root op pushes nothing, so
+        // its state travels to step n_ops - 1 as "the accumulator's state"
+        const double2* cr = cbase + (size_t)(n_ops - 1) * 2 * plane;
+        const double2 rlo = cr[0], rhi = cr[plane];
+        double down[4];
+        tip_col(tiptab, 0, b_naive, down);
+        const double w[4] = {p4[0] * rlo.x * down[0], p4[1] * rlo.y * down[1], p4[2] * rhi.x * down[2],
+                             p4[3] * rhi.y * down[3]};
+        s_acc = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 1u));
+        anc_s[(size_t)A.db.z * L + site] = (uint8_t)s_acc;
+      }
+      for (int k = n_ops - 1; k >= 0; k -= 2) {
+        step(k, A, B);
+        if (k >= 1) step(k - 1, B, A);
       }
     }
   }
 }
 
+size_t asr_desc_bytes(int T) { return sizeof(AsrOp) * (size_t)(T - 2); }
+
 int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, const double* brlen, const double* rates,
                const double* eig, const double* pi, const double* site_lik, const int32_t* site_scal,
-               const uint8_t* naive, uint64_t seed, uint64_t sample0, double* clv, uint8_t* anc,
+               const uint8_t* naive, uint64_t seed, uint64_t sample0, double* clv, void* desc, uint8_t* anc,
                uint8_t* rate_choice, hipStream_t stream) {
   const int L = fam.n_sites;
   const size_t lds = asr_lds_bytes(T, L, R, fam.n_prune);
@@ -514,10 +512,12 @@ int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, co
   const long long cells = (long long)n * L;
   hipLaunchKernelGGL(asr_rate_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, n, R, L,
                      fam.n_prune, fam.site_pat, site_lik, site_scal, naive, seed, sample0, rate_choice);
-  hipLaunchKernelGGL(asr_kernel, dim3(R, n), dim3(256), lds, stream, R, T, L, fam.n_prune, fam.msa, fam.site_pat, ops,
-                     brlen, rates, eig, pi, (const uint8_t*)rate_choice, naive, seed, sample0,
-                     reinterpret_cast<double2*>(clv), (int)asr_slots(L, R), anc,
-                     getenv("LH_ASR_DBG") ? atoi(getenv("LH_ASR_DBG")) : 0);
+  const size_t sched_lds = (size_t)(T - 2) * (sizeof(int4) + 2 * sizeof(int32_t));
+  hipLaunchKernelGGL(asr_sched_kernel, dim3(n), dim3(64), sched_lds, stream, T, ops, static_cast<AsrOp*>(desc));
+  static const int dbg = getenv("LH_ASR_DBG") ? atoi(getenv("LH_ASR_DBG")) : 0;  // phase-timing hook
+  hipLaunchKernelGGL(asr_kernel, dim3(R, n), dim3(256), lds, stream, R, T, L, fam.n_prune, fam.msa, fam.site_pat,
+                     static_cast<const AsrOp*>(desc), brlen, rates, eig, pi, (const uint8_t*)rate_choice, naive, seed,
+                     sample0, reinterpret_cast<double2*>(clv), (int)asr_slots(L, R), anc, dbg);
   return 0;
 }
 

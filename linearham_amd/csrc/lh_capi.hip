@@ -44,6 +44,8 @@ struct AsrWs {  // K3's CLV area and the device copies of lh_asr_batch's host ar
   double* clv = nullptr;
   size_t choice_cap = 0;
   uint8_t* choice = nullptr;  // K3a -> K3b when the caller does not ask for the rate categories
+  size_t desc_cap = 0;
+  void* desc = nullptr;       // K3s -> K3b schedule descriptors
   size_t cap[8] = {0};
   void* ptr[8] = {nullptr};
   double ms = 0;          // K3 time of the profiled launches (lh_profile_enable)
@@ -520,6 +522,7 @@ void lh_family_destroy(lh_family* f) {
     if (p) (void)hipFree(p);
   if (f->asr.clv) (void)hipFree(f->asr.clv);
   if (f->asr.choice) (void)hipFree(f->asr.choice);
+  if (f->asr.desc) (void)hipFree(f->asr.desc);
   for (void* p : f->asr.ptr)
     if (p) (void)hipFree(p);
   for (auto& ev : f->asr.events) {
@@ -924,6 +927,14 @@ int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, c
     LH_HIP(hipMalloc((void**)&aw.clv, clv_per_sample * chunk));
     aw.clv_cap = clv_per_sample * chunk;
   }
+  if (aw.desc_cap < lh::asr_desc_bytes(T) * chunk) {
+    LH_HIP(hipDeviceSynchronize());
+    if (aw.desc) LH_HIP(hipFree(aw.desc));
+    aw.desc = nullptr;
+    aw.desc_cap = 0;
+    LH_HIP(hipMalloc(&aw.desc, lh::asr_desc_bytes(T) * chunk));
+    aw.desc_cap = lh::asr_desc_bytes(T) * chunk;
+  }
   if (!rate_choice && aw.choice_cap < L * (size_t)chunk) {
     LH_HIP(hipDeviceSynchronize());
     if (aw.choice) LH_HIP(hipFree(aw.choice));
@@ -951,7 +962,8 @@ int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, c
       LH_HIP(hipEventRecord(ev.first, stream));
     }
     if (lh::launch_asr(f->host, m, R, T, ops_m, bl_m, r_m, w.eig, pi_m, w.site_lik, w.site_scal,
-                       naive + (size_t)off * L, seed, first_sample + (uint64_t)off, aw.clv, anc + (size_t)off * n_ops * L,
+                       naive + (size_t)off * L, seed, first_sample + (uint64_t)off, aw.clv, aw.desc,
+                       anc + (size_t)off * n_ops * L,
                        rate_choice ? rate_choice + (size_t)off * L : aw.choice, stream))
       return fail("lh_asr_batch: launch failed");
     if (f->profile) {

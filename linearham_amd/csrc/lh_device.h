@@ -123,8 +123,9 @@ void launch_gtr_setup(int n, const double* er, const double* pi, double* eig, hi
 // Returns nonzero if the tree is too large for the kernel's LDS tables.
 int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, const double* brlen, const double* rates,
                const double* eig, const double* pi, const double* site_lik, const int32_t* site_scal,
-               const uint8_t* naive, uint64_t seed, uint64_t sample0, double* clv, uint8_t* anc,
+               const uint8_t* naive, uint64_t seed, uint64_t sample0, double* clv, void* desc, uint8_t* anc,
                uint8_t* rate_choice, hipStream_t stream);
+size_t asr_desc_bytes(int T);  // per sample, of the schedule descriptors `desc` (scratch, K3s -> K3b)
 size_t asr_lds_bytes(int T, int L, int R, int n_prune);
 size_t asr_slots(int L, int R);  // slots per sample in K3's CLV area: clv[n][T-2][2][asr_slots] double2
 
