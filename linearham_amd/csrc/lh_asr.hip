@@ -42,8 +42,11 @@ namespace {
 
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
                                              uint32_t k1) {
-  const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-  const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+  // full 64-bit products: one v_mad_u64_u32 each instead of a mul_hi / mul_lo pair (32-bit integer multiplies
+  // issue at a quarter of the VALU rate, and the draws are most of the downward pass's instructions)
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+  const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
   const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
   c0 = n0;
   c1 = lo1;
@@ -351,13 +354,13 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
   uint8_t* anc_s = anc + (size_t)sample * n_ops * (size_t)L;
   uint8_t* my_stack = st_stack + tid;
 
-  // ---- upward pass over the category's distinct patterns, spread evenly over ALL waves of the workgroup.
+  // ---- upward pass over the category's distinct patterns, full waves first.
   // Software pipeline: everything op k + 1 needs from memory -- its tips' states and the CLV of the sibling it
   // pops (stored at least two ops earlier) -- is requested while op k computes, with loads that do not
   // depend on the op's kind (descriptor fields an op does not use point at valid dummies), so that no branch
   // stands between a load and the next iteration.
   {
-    const int per = min(64, (((cntp + n_waves - 1) / n_waves) + 15) & ~15);
+    const int per = 64;
     for (int s0 = wave * per; s0 < cntp; s0 += n_waves * per) {
       // Lanes past the end of the wave's share repeat its last pattern: they compute and store the very same
       // values, so no store needs a predicate (a predicated store is a branch, and a branch between the
@@ -369,54 +372,70 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
       const unsigned upat = all_n ? 0u : (unsigned)pat;
       const double2* cbase = clv_s + gslot;
       double a[4] = {1.0, 1.0, 1.0, 1.0};
-      // What one op needs from memory.  Two such sets alternate (the loop is unrolled by two) so that the set
-      // being filled for op k + 1 is never copied: a register copy at the end of an iteration would be a use,
-      // and the wait for the loads would land in the iteration that issued them.
-      struct Pre {
+      // Software pipeline.  A ring of four entries holds, per op, its descriptor and its tips' states, requested
+      // four ops ahead (the alignment is constant); the CLV of a popped sibling can only be requested one op
+      // ahead (it may have been stored two ops before it is popped) and alternates between two registers
+      // sets.  The loop is unrolled by four, so ring positions are compile-time and no entry is ever copied: a
+      // register copy would be a use, and the wait for the loads would land where they were issued.
+      struct Up {
         int4 da, db;
         int sa, sb;
-        double2 ylo, yhi;
       };
-      auto fetch = [&](int k, Pre& p) {
-        p.da = dsc[k].a;
-        p.db = dsc[k].b;
+      Up ring[4];
+      double2 ylo[2], yhi[2];
+      auto tips = [&](Up& p) {
         p.sa = msa[(unsigned)(p.da.y * n_prune) + upat];
         p.sb = msa[(unsigned)(p.da.z * n_prune) + upat];
-        const double2* cq = cbase + (size_t)p.da.w * 2 * plane;
-        p.ylo = cq[0];
-        p.yhi = cq[plane];
       };
-      auto step = [&](int k, const Pre& c, Pre& n) {
-        fetch(k + 1 < n_ops ? k + 1 : k, n);
-        const int kind = c.da.x & 15;
-        double u[4], v[4];
-        if (kind == OP_CHERRY) {
-          tip_col(tiptab, c.db.x, all_n ? 4 : c.sa, u);
-          tip_col(tiptab, c.db.y, all_n ? 4 : c.sb, v);
-        } else {
-          matvec_lds(pin + (size_t)(k - 1) * 16, a, v);
-          if (kind == OP_TIP_ACC) {
-            tip_col(tiptab, c.db.x, all_n ? 4 : c.sa, u);
-          } else {
-            const double y[4] = {c.ylo.x, c.ylo.y, c.yhi.x, c.yhi.y};
-            matvec_lds(pin + (size_t)c.da.w * 16, y, u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kk = i < n_ops ? i : n_ops - 1;
+        ring[i].da = dsc[kk].a;
+        ring[i].db = dsc[kk].b;
+        tips(ring[i]);
+      }
+      ylo[0] = yhi[0] = ylo[1] = yhi[1] = make_double2(0.0, 0.0);
+      for (int k = 0; k < n_ops; k += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kk = k + i;
+          if (kk < n_ops) {
+            Up& c = ring[i];
+            if ((ring[(i + 1) & 3].da.x & 15) == OP_POP_ACC) {  // the sibling op kk + 1 pops
+              const double2* cq = cbase + (size_t)ring[(i + 1) & 3].da.w * 2 * plane;
+              ylo[(i + 1) & 1] = cq[0];
+              yhi[(i + 1) & 1] = cq[plane];
+            }
+            const int kf = kk + 4 < n_ops ? kk + 4 : n_ops - 1;
+            const int4 fa = dsc[kf].a, fb = dsc[kf].b;
+            const int kind = c.da.x & 15;
+            double u[4], v[4];
+            if (kind == OP_CHERRY) {
+              tip_col(tiptab, c.db.x, all_n ? 4 : c.sa, u);
+              tip_col(tiptab, c.db.y, all_n ? 4 : c.sb, v);
+            } else {
+              matvec_lds(pin + (size_t)(kk - 1) * 16, a, v);
+              if (kind == OP_TIP_ACC) {
+                tip_col(tiptab, c.db.x, all_n ? 4 : c.sa, u);
+              } else {
+                const double y[4] = {ylo[i & 1].x, ylo[i & 1].y, yhi[i & 1].x, yhi[i & 1].y};
+                matvec_lds(pin + (size_t)c.da.w * 16, y, u);
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = u[q] * v[q];
+            if (fmax(fmax(a[0], a[1]), fmax(a[2], a[3])) < kScaleThreshold) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) a[q] *= kScaleFactor;
+            }
+            double2* ck = clv_s + (size_t)kk * 2 * plane + gslot;
+            ck[0] = make_double2(a[0], a[1]);
+            ck[plane] = make_double2(a[2], a[3]);
+            c.da = fa;
+            c.db = fb;
+            tips(c);
           }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = u[i] * v[i];
-        if (fmax(fmax(a[0], a[1]), fmax(a[2], a[3])) < kScaleThreshold) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) a[i] *= kScaleFactor;
-        }
-        double2* ck = clv_s + (size_t)k * 2 * plane + gslot;
-        ck[0] = make_double2(a[0], a[1]);
-        ck[plane] = make_double2(a[2], a[3]);
-      };
-      Pre A, B;
-      fetch(0, A);
-      for (int k = 0; k < n_ops; k += 2) {
-        step(k, A, B);
-        if (k + 1 < n_ops) step(k + 1, B, A);
       }
     }
   }
@@ -428,25 +447,28 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
   // ---- downward pass over the category's sites: the schedule in reverse.  The CLVs of op k - 1's children
   // are requested while op k draws (their addresses depend on the schedule only, not on the states).
   {
-    const int per = min(64, (((cnt + n_waves - 1) / n_waves) + 15) & ~15);
+    const int per = 64;
     for (int s0 = wave * per; s0 < cnt; s0 += n_waves * per) {
       const int slot = min(s0 + min(lane, per - 1), cnt - 1);  // surplus lanes repeat the last site (same draws)
       const int site = list[slot];
       const int pat = min(site_pat[site], n_prune);
       const double2* cbase = clv_s + base + pslot[pat];
       const int b_naive = nv[site];
-      // children of op k: the accumulator child is op k - 1, the popped one op da.w (dummies: op 0); two sets
-      // alternate as on the way up
-      struct Pre {
+      // Children of op k: the accumulator child is op k - 1, the popped one op da.w (dummies: op 0).  All CLVs
+      // are final here, so everything an op needs is requested four ops ahead: a ring of four entries at
+      // compile-time positions (loop unrolled by four), as on the way up.
+      struct Dn {
         int4 da, db;
         int node_acc;
         double2 alo, ahi, plo, phi;
       };
-      auto fetch = [&](int k, Pre& p) {
+      auto fetch = [&](int k, Dn& p) {
         p.da = dsc[k].a;
         p.db = dsc[k].b;
         const int j = k > 0 ? k - 1 : 0;
         p.node_acc = dsc[j].b.z;  // the accumulator child is the node op k - 1 produced
+        // (loads that do not depend on the op's kind: with branches around them the waits got coarser and the
+        // pass 30 % slower, although a third of these loads fetch a dummy)
         const double2* ca = cbase + (size_t)j * 2 * plane;
         p.alo = ca[0];
         p.ahi = ca[plane];
@@ -454,29 +476,10 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
         p.plo = cp[0];
         p.phi = cp[plane];
       };
-      int s_acc = 0;
-      auto step = [&](int k, const Pre& c, Pre& n) {
-        fetch(k > 0 ? k - 1 : 0, n);
-        const int kind = c.da.x & 15;
-        const int take = (c.da.x >> 8) & 31;
-        const int s_cur = take ? (int)my_stack[(take - 1) * 256] : s_acc;
-        if (kind != OP_CHERRY) {
-          const double* prow = pin + (size_t)(k - 1) * 16 + s_cur * 4;
-          const double w[4] = {prow[0] * c.alo.x, prow[1] * c.alo.y, prow[2] * c.ahi.x, prow[3] * c.ahi.y};
-          s_acc = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)c.node_acc));
-          anc_s[(size_t)c.node_acc * L + site] = (uint8_t)s_acc;
-        }
-        if (kind == OP_POP_ACC) {
-          const int node = c.db.w;
-          const double* prow = pin + (size_t)c.da.w * 16 + s_cur * 4;
-          const double w[4] = {prow[0] * c.plo.x, prow[1] * c.plo.y, prow[2] * c.phi.x, prow[3] * c.phi.y};
-          const int sq = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)node));
-          anc_s[(size_t)node * L + site] = (uint8_t)sq;
-          my_stack[((c.da.x >> 4) & 15) * 256] = (uint8_t)sq;
-        }
-      };
-      Pre A, B;
-      fetch(n_ops - 1, A);
+      Dn ring[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fetch(n_ops - 1 - i > 0 ? n_ops - 1 - i : 0, ring[i]);
+      int s_acc;
       {
         // root = naive's neighbour: pi_i * L_root(i) * P_naive[i][naive base]; the root op pushes nothing, so
         // its state travels to step n_ops - 1 as "the accumulator's state"
@@ -487,11 +490,34 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
         const double w[4] = {p4[0] * rlo.x * down[0], p4[1] * rlo.y * down[1], p4[2] * rhi.x * down[2],
                              p4[3] * rhi.y * down[3]};
         s_acc = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 1u));
-        anc_s[(size_t)A.db.z * L + site] = (uint8_t)s_acc;
+        anc_s[(size_t)ring[0].db.z * L + site] = (uint8_t)s_acc;
       }
-      for (int k = n_ops - 1; k >= 0; k -= 2) {
-        step(k, A, B);
-        if (k >= 1) step(k - 1, B, A);
+      for (int k = n_ops - 1; k >= 0; k -= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kk = k - i;
+          if (kk >= 0) {
+            Dn& c = ring[i];
+            const int kind = c.da.x & 15;
+            const int take = (c.da.x >> 8) & 31;
+            const int s_cur = take ? (int)my_stack[(take - 1) * 256] : s_acc;
+            if (kind != OP_CHERRY) {
+              const double* prow = pin + (size_t)(kk - 1) * 16 + s_cur * 4;
+              const double w[4] = {prow[0] * c.alo.x, prow[1] * c.alo.y, prow[2] * c.ahi.x, prow[3] * c.ahi.y};
+              s_acc = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)c.node_acc));
+              anc_s[(size_t)c.node_acc * L + site] = (uint8_t)s_acc;
+            }
+            if (kind == OP_POP_ACC) {
+              const int node = c.db.w;
+              const double* prow = pin + (size_t)c.da.w * 16 + s_cur * 4;
+              const double w[4] = {prow[0] * c.plo.x, prow[1] * c.plo.y, prow[2] * c.phi.x, prow[3] * c.phi.y};
+              const int sq = draw4(w, asr_uniform(seed, sample_id, (uint32_t)site, 2u + (uint32_t)node));
+              anc_s[(size_t)node * L + site] = (uint8_t)sq;
+              my_stack[((c.da.x >> 4) & 15) * 256] = (uint8_t)sq;
+            }
+            fetch(kk - 4 > 0 ? kk - 4 : 0, c);
+          }
+        }
       }
     }
   }
