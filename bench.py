@@ -89,6 +89,9 @@ def main():
                          "sub-batches of 6144, so leave it off when profiling per-launch kernel durations)")
     ap.add_argument("--no-check", action="store_true", help="kernel timing experiments only")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo (through host copies) only to rehearse the multi-rank path on "
+                         "a box with fewer GPUs than ranks -- ranks then share devices (LOCAL_RANK modulo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,10 +109,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
 
     # ---- synthetic family in the reference's file formats (deterministic; same on every rank) -----
     spec = {"config2": sf.Spec(n_samples=256), "small": sf.Spec.small(n_samples=16),
@@ -142,7 +150,14 @@ def main():
                                                d["alpha"].data_ptr(), R, loglik.data_ptr(), None,
                                                C.c_void_p(stream)))
         if world > 1:   # the single collective of the path: gather log-likelihoods on rank 0
-            dist.gather(loglik, gather_list=list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+            if args.backend == "nccl":
+                dist.gather(loglik, gather_list=list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+            else:       # rehearsal: the same gather through host memory
+                host_ll = loglik.cpu()
+                parts = [torch.empty_like(host_ll) for _ in range(world)] if rank == 0 else None
+                dist.gather(host_ll, gather_list=parts, dst=0)
+                if rank == 0:
+                    gathered.copy_(torch.cat(parts))
 
     def barrier():
         if world > 1:
@@ -158,7 +173,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
