@@ -79,3 +79,13 @@ def test_site_likelihoods_are_the_pinned_pruning_values(data_dir):
     for k, r in enumerate(rates):
         ref = orc.per_site_loglik(tree, rows, tips, er, pi, [r])
         np.testing.assert_allclose(detail["loglik_per_rate"][k], ref, rtol=1e-11, atol=1e-12)
+
+
+def test_committed_oracle_vectors_reproduce():
+    """tests/golden/asr_goldens.json (oracle-derived) is what the oracle computes today."""
+    import json
+    import os
+    from tests.golden import make_asr_goldens as mk
+    want = json.load(open(os.path.join(os.path.dirname(mk.__file__), "asr_goldens.json")))
+    got = json.loads(json.dumps(mk.case()))
+    assert got == want

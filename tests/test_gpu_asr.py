@@ -121,3 +121,25 @@ def test_asr_error_paths(hip, data_dir):
     with pytest.raises(RuntimeError, match="malformed schedule op"):
         fam.asr_batch(T, depth, bad_ops[None], good["brlen"], good["er"], good["pi"], good["rates"], good["naive"], 1)
     fam.close()
+
+
+def test_asr_committed_vectors(hip, data_dir):
+    """The HIP path against the committed oracle-derived vectors (tests/golden/asr_goldens.json)."""
+    import json
+    import linearham_amd
+    g = json.load(open(os.path.join(os.path.dirname(data_dir), "asr_goldens.json")))
+    h = orc.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input.yaml"), 0, os.path.join(data_dir, "hmm_params"), 0)
+    fam = linearham_amd.Family(db.build_family_desc(h), hip)
+    children, root, brlen = db.tree_arrays(orc.parse_newick(open(os.path.join(data_dir, "newton.tree")).read()),
+                                           h.xmsa_labels)
+    assert [int(x) for x in children] == g["children"] and int(root) == g["root"]
+    ops, depth = hip.schedule_tree(4, children, root)
+    n = len(g["samples"])
+    naive = np.tile(np.array(g["naive"], dtype=np.uint8), (n, 1))
+    rates = np.tile(orc.gamma_rates_mean(1.0, 4), (n, 1))
+    anc, choice = fam.asr_batch(4, depth, np.tile(ops, (n, 1, 1)), np.tile(brlen, (n, 1)), [[1.0] * 6] * n,
+                                [[0.17, 0.19, 0.25, 0.39]] * n, rates, naive, g["seed"], 0)
+    fam.close()
+    for i, smp in enumerate(g["samples"]):
+        assert choice[i].tolist() == smp["rate_choice"]
+        assert anc[i].tolist() == smp["anc"]
