@@ -75,12 +75,35 @@ def main():
     bytes_per_sample = (T - 2) * L * (32 + 32 + 1)
     achieved = bytes_per_sample * per_launch / (k3_ms * 1e-3) / 1e9
     a = anc.cpu().numpy()
+    # CPU baseline: the numpy restatement of the R step (oracle/asr_oracle.py) on a few samples of the same
+    # batch, one core (the R script runs one tree per core); its draws must equal the GPU's
+    from oracle import asr_oracle as ao
+    from linearham_amd import host as _host
+    rows = sf.read_trees_tsv(os.path.join(fam_dir, "trees.tsv"))
+    o = orc.PhyloHMM(os.path.join(fam_dir, "cluster.yaml"), 0, os.path.join(fam_dir, "hmm_params"), 0)
+    labels = list(o.xmsa_labels)
+    n_cpu = 4 if args.preset != "config4" else 1
+    t_cpu = time.perf_counter()
+    mism = 0
+    last_seed = 100 + args.steps - 1
+    for i in range(n_cpu):
+        r = rows[i % len(rows)]
+        children, root, brlen = _host.newick_arrays(r["tree"], labels)
+        _, anc_ref, _ = ao.asr_sample(children, root, brlen, T, o.msa, naive[i], r["er"], np.asarray(r["pi"]),
+                                      rates[i], last_seed, i)
+        mism += int((anc_ref != a[i]).sum())
+    t_cpu = time.perf_counter() - t_cpu
+    if mism:
+        raise SystemExit("parity failure: %d sampled states differ from the CPU oracle" % mism)
     out = {"metric": "ancestral-sequence samples/sec (per-site rate draw + joint inner-state draw)",
            "value": n * args.steps / dt, "unit": "tree samples/s", "ms_per_step": dt / args.steps * 1e3,
            "config": {"workload": args.preset, "batch": n, "n_tips": T, "n_sites": L, "R": R},
            "kernel_ms_per_launch": {"asr_K3": k3_ms, "samples_per_launch": per_launch},
            "roofline": {"bound": "hbm", "kernel": "asr_kernel (K3)", "achieved": achieved, "peak": 8000.0,
                         "unit": "GB/s", "frac": achieved / 8000.0, "algorithmic_bytes_per_sample": bytes_per_sample},
+           "cpu_baseline": {"value": n_cpu / t_cpu, "unit": "tree samples/s", "cores": 1, "kind": "port",
+                            "sample": "%d samples of the same batch through oracle/asr_oracle.py (numpy); sampled "
+                                      "states identical to the GPU's" % n_cpu},
            "state_histogram": [int(x) for x in np.bincount(a.ravel(), minlength=4)[:4]]}
     print(json.dumps(out), flush=True)
 
