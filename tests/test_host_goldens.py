@@ -102,6 +102,21 @@ def test_host_errors(data_dir, tmp_path):
                  "((0:0.2,1:0.4):0.6,naive:0.3,2:0.5"]:           # truncated
         with pytest.raises(RuntimeError):
             h.initialize_phylo_parameters(tree, [1.0] * 6, [0.25] * 4, 1.0, 4, is_path=False)
+    # --asr input checks (all before any device work)
+    with pytest.raises(RuntimeError, match="Can't open linearham output file"):
+        h.run_asr(str(tmp_path / "missing.tsv"), str(tmp_path / "o.trees"), 0)
+    cols = "er[1]\ter[2]\ter[3]\ter[4]\ter[5]\ter[6]\tpi[1]\tpi[2]\tpi[3]\tpi[4]\ttree"
+    tsv = tmp_path / "bad.tsv"
+    tsv.write_text(cols + "\tsr[1]\n")
+    with pytest.raises(RuntimeError, match='Missing column "NaiveSequence"'):
+        h.run_asr(str(tsv), str(tmp_path / "o.trees"), 0)
+    tsv.write_text(cols + "\tNaiveSequence\n")
+    with pytest.raises(RuntimeError, match="Missing column .sr.1.."):
+        h.run_asr(str(tsv), str(tmp_path / "o.trees"), 0)
+    tsv.write_text(cols + "\tsr[1]\tNaiveSequence\n"
+                   "1\t1\t1\t1\t1\t1\t.25\t.25\t.25\t.25\t((0:0.2,1:0.4):0.6,naive:0.3,2:0.5);\t1\tACGT\n")
+    with pytest.raises(RuntimeError, match="NaiveSequence length differs"):
+        h.run_asr(str(tsv), str(tmp_path / "o.trees"), 0)
 
 
 def test_yaml_reader_dialects(tmp_path, data_dir):
