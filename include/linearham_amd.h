@@ -121,6 +121,14 @@ int64_t lh_scaler_size(const lh_family* fam);
  * xMSA column / per site all the same. */
 int lh_family_info(const lh_family* fam, int32_t* n_patterns, int32_t* n_unique_columns);
 
+/* Which germline / padding sets lh_family_create put into consensus form (bit 0 vpadding, 1 vgerm, 2 dgerm,
+ * 3 jgerm, 4 jpadding): when the alleles of a set are site-aligned and alike, a gene's emission product
+ * (FillGermlinePaddingEmission, src/PhyloHMM.cpp:158-193) is formed from the prefix products of the set's
+ * consensus columns and the few factors where the gene departs from it, instead of factor by factor; values
+ * agree to rounding, ScaleMatrix counts exactly.  Environment variable LH_K2A_DIRECT (read at create time)
+ * turns the form off. */
+int lh_family_consensus_sets(const lh_family* fam);
+
 /* Tree in rooted-at-naive form: tips are nodes 0..T-1 (0 = `naive`, i = MSA row i-1), inner nodes
  * T..2T-3.  children[2*(v-T)+{0,1}] are the two children of inner node v when the tree is rooted at
  * `root`, the inner node adjacent to `naive`.  Writes the kernel's post-order schedule:

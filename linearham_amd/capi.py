@@ -41,7 +41,7 @@ class _EvalOutputs(C.Structure):
 
 
 EXPORTS = ["lh_last_error", "lh_device_count", "lh_family_create", "lh_family_destroy",
-           "lh_forward_size", "lh_scaler_size", "lh_family_info", "lh_schedule_tree", "lh_eval_batch",
+           "lh_forward_size", "lh_scaler_size", "lh_family_info", "lh_family_consensus_sets", "lh_schedule_tree", "lh_eval_batch",
            "lh_eval_batch_device", "lh_forward_batch", "lh_asr_batch", "lh_asr_batch_device",
            "lh_profile_enable", "lh_profile_read", "lh_asr_profile_read"]
 
@@ -68,6 +68,8 @@ class HipLibrary:
         lib.lh_scaler_size.restype = C.c_int64
         lib.lh_family_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         lib.lh_family_info.restype = C.c_int
+        lib.lh_family_consensus_sets.argtypes = [C.c_void_p]
+        lib.lh_family_consensus_sets.restype = C.c_int
         lib.lh_schedule_tree.argtypes = [C.c_int32, c_i32p, C.c_int32, c_i32p, c_i32p]
         lib.lh_eval_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f64p, c_f64p,
                                       c_f64p, c_f64p, C.c_int32, c_f64p, C.POINTER(_EvalOutputs)]
@@ -209,6 +211,7 @@ class Family:
         self.forward_size = self.hip.lib.lh_forward_size(h)
         self.scaler_size = self.hip.lib.lh_scaler_size(h)
         self.n_xmsa = desc.n_xmsa
+        self.consensus_sets = self.hip.lib.lh_family_consensus_sets(h)
 
     def close(self):
         if self.handle:

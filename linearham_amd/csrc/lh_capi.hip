@@ -126,11 +126,85 @@ int upload(lh_family* f, const T* src, size_t count, const T** dst) {
 
 // `ucol` translates the caller's xMSA column indices into u-columns (lh_device.h); the sentinel column
 // whose emission is 1.0 sits at position n_ucol.
+template <typename T>
+int upload_vec(lh_family* f, const std::vector<T>& v, const T** out);
+
+// Consensus form of a segment set (DevSegments): only when every gene's factors sit on consecutive alignment
+// sites (xmsa_site known), the set spans at most 510 sites, and the form at least halves the factor count.
+int upload_consensus(lh_family* f, const lh_segments& s, const std::vector<int32_t>& ucol, int n_ucol,
+                     const int32_t* xmsa_site, int scale, lh::DevSegments* d) {
+  const bool off = getenv("LH_K2A_DIRECT") != nullptr;  // test hook: always the factor-by-factor walk
+  if (off || !xmsa_site || s.n_genes < 1) return 0;
+  const int n = s.n_genes;
+  int lo = INT32_MAX, hi = -1;
+  long long total = 0;
+  for (int g = 0; g < n; ++g) {
+    const int a = s.offsets[g], b = s.offsets[g + 1];
+    if (a == b) continue;
+    for (int j = a + 1; j < b; ++j)
+      if (xmsa_site[s.xmsa_inds[j]] != xmsa_site[s.xmsa_inds[j - 1]] + 1) return 0;  // not site-aligned
+    lo = std::min(lo, xmsa_site[s.xmsa_inds[a]]);
+    hi = std::max(hi, xmsa_site[s.xmsa_inds[b - 1]] + 1);
+    total += b - a;
+  }
+  if (hi < 0 || total < 4096) return 0;  // nothing to gain on a small set: the scan and its barriers cost more
+  const int ns = hi - lo;
+  if (ns > 510) return 0;
+  // consensus column per site: the most frequent u-column among the genes covering it (ties: smallest)
+  std::vector<std::map<int32_t, int>> votes(ns);
+  for (int g = 0; g < n; ++g)
+    for (int j = s.offsets[g]; j < s.offsets[g + 1]; ++j) ++votes[xmsa_site[s.xmsa_inds[j]] - lo][ucol[s.xmsa_inds[j]]];
+  std::vector<int32_t> cons(ns, n_ucol);  // uncovered sites (gaps between genes): the sentinel, emission 1
+  for (int p = 0; p < ns; ++p) {
+    int best = 0;
+    for (const auto& kv : votes[p])
+      if (kv.second > best) {
+        best = kv.second;
+        cons[p] = kv.first;
+      }
+  }
+  std::vector<std::vector<uint32_t>> diffs(n);
+  std::vector<uint32_t> rng(n, 0);
+  size_t max_diff = 0;
+  for (int g = 0; g < n; ++g) {
+    const int a = s.offsets[g], b = s.offsets[g + 1];
+    if (a == b) continue;
+    const int first = xmsa_site[s.xmsa_inds[a]] - lo;
+    rng[g] = (uint32_t)first | ((uint32_t)(first + (b - a)) << 16);
+    for (int j = a; j < b; ++j) {
+      const int p = first + (j - a);
+      const int32_t u = ucol[s.xmsa_inds[j]];
+      if (u != cons[p]) diffs[g].push_back((uint32_t)p | ((uint32_t)(u * scale) << 16));
+    }
+    max_diff = std::max(max_diff, diffs[g].size());
+  }
+  max_diff = (max_diff + 7) & ~(size_t)7;  // the kernel takes the departures eight at a time
+  // worth it?  work of the consensus form (scan + per gene a division and its diffs) against the plain walk
+  if ((long long)ns + (long long)n * (long long)(max_diff + 8) > total / 2) return 0;
+  std::vector<uint16_t> col(ns);
+  for (int p = 0; p < ns; ++p) col[p] = (uint16_t)(cons[p] * scale);
+  const uint32_t pad = (uint32_t)ns | ((uint32_t)(n_ucol * scale) << 16);
+  std::vector<uint32_t> dif(std::max<size_t>(max_diff, 8) * n, pad);
+  for (int g = 0; g < n; ++g)
+    for (size_t k = 0; k < diffs[g].size(); ++k) dif[k * n + g] = diffs[g][k];
+  if (upload_vec(f, col, &d->cons_col)) return 1;
+  if (upload_vec(f, rng, &d->cons_rng)) return 1;
+  if (upload_vec(f, dif, &d->cons_dif)) return 1;
+  d->cons_sites = ns;
+  d->cons_diffs = (int32_t)max_diff;
+  return 0;
+}
+
 int upload_segments(lh_family* f, const lh_segments& s, int n_xmsa, const std::vector<int32_t>& ucol, int n_ucol,
-                    lh::DevSegments* d) {
+                    const int32_t* xmsa_site, lh::DevSegments* d) {
   const int scale = f->host.idx_byte_offsets ? 8 : 1;  // byte offsets into the LDS emission vector
   if (s.n_genes < 0) return fail("segments: negative gene count");
   d->n_genes = s.n_genes;
+  d->cons_sites = 0;
+  d->cons_diffs = 0;
+  d->cons_col = nullptr;
+  d->cons_rng = nullptr;
+  d->cons_dif = nullptr;
   if (s.n_genes > 0) {
     if (!s.offsets) return fail("segments: null offsets");
     if (s.offsets[0] != 0) return fail("segments: offsets[0] != 0");
@@ -153,6 +227,7 @@ int upload_segments(lh_family* f, const lh_segments& s, int n_xmsa, const std::v
     const uint16_t* dev = nullptr;
     if (upload(f, t.data(), t.size(), &dev)) return 1;
     d->inds_c = reinterpret_cast<const uint4*>(dev);
+    if (upload_consensus(f, s, ucol, n_ucol, xmsa_site, scale, d)) return 1;
   } else {
     d->n_chunks = 0;
     const uint16_t* dev = nullptr;
@@ -435,10 +510,11 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
     rc = rc || upload(f, ucol.data(), C, &h.col_of_ucol);
   }
   h.idx_byte_offsets = ((int64_t)h.n_ucol + 1) * 8 <= 0xffff ? 1 : 0;
-  rc = rc || upload_segments(f, desc->vpadding, desc->n_xmsa, ucol, h.n_ucol, &h.vpadding);
-  rc = rc || upload_segments(f, desc->vgerm, desc->n_xmsa, ucol, h.n_ucol, &h.vgerm);
-  rc = rc || upload_segments(f, desc->jgerm, desc->n_xmsa, ucol, h.n_ucol, &h.jgerm);
-  rc = rc || upload_segments(f, desc->jpadding, desc->n_xmsa, ucol, h.n_ucol, &h.jpadding);
+  const int32_t* seg_site = (desc->n_seqs > 0 && !rc) ? desc->xmsa_site : nullptr;  // alignment site of a column
+  rc = rc || upload_segments(f, desc->vpadding, desc->n_xmsa, ucol, h.n_ucol, seg_site, &h.vpadding);
+  rc = rc || upload_segments(f, desc->vgerm, desc->n_xmsa, ucol, h.n_ucol, seg_site, &h.vgerm);
+  rc = rc || upload_segments(f, desc->jgerm, desc->n_xmsa, ucol, h.n_ucol, seg_site, &h.jgerm);
+  rc = rc || upload_segments(f, desc->jpadding, desc->n_xmsa, ucol, h.n_ucol, seg_site, &h.jpadding);
   const size_t nV = desc->vgerm.n_genes, nJ = desc->jgerm.n_genes;
   if (!rc && (desc->vpadding.n_genes != (int)nV || desc->jpadding.n_genes != (int)nJ))
     rc = fail("lh_family_create: padding/germline gene counts differ");
@@ -466,14 +542,14 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
   rc = rc || upload_junction(f, desc->vd, remap, h.n_jcols, &h.vd);
   if (!rc && desc->vd.n_left != (int)nV) rc = fail("lh_family_create: vd.n_left != number of V genes");
   if (h.has_d) {
-    rc = rc || upload_segments(f, desc->dgerm, desc->n_xmsa, ucol, h.n_ucol, &h.dgerm);
+    rc = rc || upload_segments(f, desc->dgerm, desc->n_xmsa, ucol, h.n_ucol, seg_site, &h.dgerm);
     rc = rc || upload_junction(f, desc->dj, remap, h.n_jcols, &h.dj);
     if (!rc && (desc->vd.n_right != desc->dgerm.n_genes || desc->dj.n_left != desc->dgerm.n_genes ||
                 desc->dj.n_right != (int)nJ))
       rc = fail("lh_family_create: junction gene counts do not match the germline regions");
   } else {
     lh_segments empty{0, nullptr, nullptr};
-    rc = rc || upload_segments(f, empty, desc->n_xmsa, ucol, h.n_ucol, &h.dgerm);
+    rc = rc || upload_segments(f, empty, desc->n_xmsa, ucol, h.n_ucol, seg_site, &h.dgerm);
     memset(&h.dj, 0, sizeof(h.dj));
     if (!rc && desc->vd.n_right != (int)nJ) rc = fail("lh_family_create: vd.n_right != number of J genes");
   }
@@ -541,6 +617,13 @@ void lh_family_destroy(lh_family* f) {
 }
 
 int64_t lh_forward_size(const lh_family* f) { return f ? f->host.forward_size : 0; }
+
+int lh_family_consensus_sets(const lh_family* f) {
+  if (!f) return 0;
+  const lh::DevFamily& h = f->host;
+  return (h.vpadding.cons_sites > 0) | (h.vgerm.cons_sites > 0) << 1 | (h.dgerm.cons_sites > 0) << 2 |
+         (h.jgerm.cons_sites > 0) << 3 | (h.jpadding.cons_sites > 0) << 4;
+}
 
 int lh_family_info(const lh_family* f, int32_t* n_patterns, int32_t* n_unique_columns) {
   if (!f) return fail("lh_family_info: null family");

@@ -18,6 +18,16 @@ enum : int { OP_CHERRY = 0, OP_TIP_ACC = 1, OP_POP_ACC = 2, OP_PUSH_FLAG = 16 };
 struct DevSegments {
   int32_t n_genes;
   int32_t n_chunks;      // ceil(longest segment / 8)
+  // Consensus form (lh_family_create builds it when the genes of the set are site-aligned and alike, as the
+  // Smith-Waterman candidates of one rearrangement are): per covered alignment site the u-column most genes
+  // take there; a gene's product is then (prefix product of the consensus up to its last site) / (prefix up to
+  // its first site) x the few factors where it departs from the consensus.  cons_sites == 0: not available.
+  int32_t cons_sites;        // covered sites (<= 510)
+  int32_t cons_diffs;        // diff entries per gene (padded)
+  const uint16_t* cons_col;  // [cons_sites] consensus u-column (index or byte offset like inds_c)
+  const uint32_t* cons_rng;  // [n_genes] first | (last + 1) << 16, in consensus positions
+  const uint32_t* cons_dif;  // [cons_diffs][n_genes] position | own u-column << 16; padding = position
+                             // cons_sites (reciprocal 1.0) | the sentinel column (emission 1.0)
   const uint4* inds_c;   // [n_chunks][n_genes] eight 16-bit u-column indices (or byte offsets, see
                          // DevFamily::idx_byte_offsets) per entry (lane g's next
                          // eight factors in one coalesced 16-byte load), padded with the sentinel

@@ -137,6 +137,154 @@ __device__ static int fill_segments(const DevSegments& seg, const double* em, in
   return mx;
 }
 
+// (v, k) = the reference's running product after ScaleMatrix: value v * 2^(-256 k), v kept in [2^-256, 1]
+struct ScaledProd {
+  double v;
+  int k;
+};
+__device__ static inline ScaledProd sp_mul(ScaledProd a, ScaledProd b) {
+  ScaledProd r{a.v * b.v, a.k + b.k};  // both factors >= 2^-256: no underflow
+  if (r.v < kScaleThreshold) {
+    r.v *= kScaleFactor;
+    ++r.k;
+  }
+  return r;
+}
+
+__device__ static inline ScaledProd sp_from(double e) {  // e in (0, 1]
+  ScaledProd r{e, 0};
+  while (r.v < kScaleThreshold) {
+    r.v *= kScaleFactor;
+    ++r.k;
+  }
+  return r;
+}
+
+// FillGermlinePaddingEmission through the set's consensus (DevSegments::cons_*).  All emissions are in (0, 1]
+// here (checked by the caller), so a gene's running product falls monotonically and the reference's pair
+// (value, ScaleMatrix count) is a function of the product alone: count = the fewest 2^256 factors that bring it
+// back to >= 2^-256.  The product itself is formed as
+//     prefix(last site + 1) / prefix(first site)  x  prod over the gene's departures  em[own] / em[consensus]
+// with prefix = exclusive product scan of the consensus emissions over the set's sites, carried as (v, k)
+// pairs.  A fifth to a twentieth of the factor-by-factor walk's multiplications for allele sets as alike as the
+// candidates of one rearrangement.  lds: cons_inv[513] | cons_pv[512] | cons_pk[512].
+template <int kG, bool kByteOff>
+__device__ static int fill_consensus(const DevSegments& seg, const double* em, int tid, double* __restrict__ out,
+                                     int* redi, int phase, double* cons_inv, double* cons_pv, int* cons_pk) {
+  const int ns = seg.cons_sites, n = seg.n_genes;
+  auto em_at = [&](unsigned x) {
+    return kByteOff ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(em) + x) : em[x];
+  };
+  // exclusive prefix products: thread t owns sites 2t, 2t+1
+  ScaledProd x0{1.0, 0}, x1{1.0, 0};
+  const int j0 = 2 * tid;
+  if (j0 < ns) {
+    const double e = em_at(seg.cons_col[j0]);
+    cons_inv[j0] = 1.0 / e;
+    x0 = sp_from(e);
+  }
+  if (j0 + 1 < ns) {
+    const double e = em_at(seg.cons_col[j0 + 1]);
+    cons_inv[j0 + 1] = 1.0 / e;
+    x1 = sp_from(e);
+  }
+  if (tid == 0) cons_inv[ns] = 1.0;  // the diff lists' padding position
+  ScaledProd incl = sp_mul(x0, x1);  // inclusive scan of the per-thread products across the block
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double ov = __shfl_up(incl.v, off, 64);
+    const int ok = __shfl_up(incl.k, off, 64);
+    if (lane >= off) incl = sp_mul(ScaledProd{ov, ok}, incl);
+  }
+  // wave totals through the tail of the prefix arrays (positions 508..511 are never a site's prefix)
+  if (lane == 63) {
+    cons_pv[508 + wave] = incl.v;
+    cons_pk[508 + wave] = incl.k;
+  }
+  __syncthreads();
+  ScaledProd excl = incl;  // -> exclusive: shift by one thread
+  {
+    const double ov = __shfl_up(incl.v, 1, 64);
+    const int ok = __shfl_up(incl.k, 1, 64);
+    excl = lane == 0 ? ScaledProd{1.0, 0} : ScaledProd{ov, ok};
+    for (int w = 0; w < wave; ++w) excl = sp_mul(ScaledProd{cons_pv[508 + w], cons_pk[508 + w]}, excl);
+  }
+  __syncthreads();  // the wave totals have been read: the tail may now be overwritten by prefixes (ns <= 510)
+  if (j0 <= ns) {
+    cons_pv[j0] = excl.v;
+    cons_pk[j0] = excl.k;
+  }
+  if (j0 + 1 <= ns) {
+    const ScaledProd p1 = sp_mul(excl, x0);
+    cons_pv[j0 + 1] = p1.v;
+    cons_pk[j0 + 1] = p1.k;
+  }
+  __syncthreads();
+
+  double v[kG];
+  int c[kG];
+#pragma unroll
+  for (int q = 0; q < kG; ++q) {
+    v[q] = 1.0;
+    c[q] = 0;
+    const int g = tid + kFwdThreads * q;
+    if (g < n) {
+      const unsigned rng = seg.cons_rng[g];
+      const int a = rng & 0xffffu, b = rng >> 16;
+      double r = cons_pv[b] / cons_pv[a];  // in (2^-256, 2^256)
+      int k = cons_pk[b] - cons_pk[a];     // value = r * 2^(-256 k)
+      const uint32_t* dp = seg.cons_dif + g;
+      for (int d = 0; d < seg.cons_diffs; d += 8) {  // eight departures at a time: their loads overlap
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = dp[(size_t)(d + i) * n];
+        double fct[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fct[i] = em_at(w[i] >> 16) * cons_inv[w[i] & 0xffffu];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          r *= fct[i];
+          // keep r within [2^-256, 2^256): a ratio of two emissions can be far from 1
+          if (r < kScaleThreshold) {
+            r *= kScaleFactor;
+            ++k;
+          } else if (r >= kScaleFactor) {
+            r *= kScaleThreshold;
+            --k;
+          }
+        }
+      }
+      // the reference's form: the fewest rescalings k >= 0 with value * 2^(256 k) >= 2^-256
+      while (r < kScaleThreshold) {
+        r *= kScaleFactor;
+        ++k;
+      }
+      while (k > 0 && r >= 1.0) {
+        r *= kScaleThreshold;
+        --k;
+      }
+      while (k < 0) {  // cannot happen for products of factors <= 1; keeps the pair consistent anyway
+        r *= kScaleFactor;
+        ++k;
+      }
+      v[q] = r;
+      c[q] = k;
+    }
+  }
+  int local_max = 0;
+#pragma unroll
+  for (int q = 0; q < kG; ++q)
+    if (tid + kFwdThreads * q < n) local_max = max(local_max, c[q]);
+  const int mx = block_max_int(local_max, redi, phase);
+#pragma unroll
+  for (int q = 0; q < kG; ++q) {
+    const int g = tid + kFwdThreads * q;
+    if (g < n) out[g] = v[q] * pow_scale(mx - c[q]);
+  }
+  return mx;
+}
+
 template <int kG, bool kFromSiteLik, bool kByteOff>
 __global__ void __launch_bounds__(kFwdThreads)
     emission_kernel(const DevFamily fam, int R, const double* __restrict__ site_lik,
@@ -147,7 +295,14 @@ __global__ void __launch_bounds__(kFwdThreads)
   const size_t s = blockIdx.x;
   const int tid = threadIdx.x;
   const int C = fam.n_ucol;  // u-columns (lh_device.h); the caller's columns only appear in em_in / em_out
-  int* redi = reinterpret_cast<int*>(em + ((C + 2) & ~1));  // 2 * kFwdWaves ints
+  int* redi = reinterpret_cast<int*>(em + ((C + 2) & ~1));  // 2 * kFwdWaves ints, then one flag word
+  int* em_bad = redi + 2 * kFwdWaves;                        // some emission outside (0, 1]
+  double* cons_inv = reinterpret_cast<double*>(redi + 2 * kFwdWaves + 2);  // [513] (consensus form only)
+  double* cons_pv = cons_inv + 514;                                         // [512]
+  int* cons_pk = reinterpret_cast<int*>(cons_pv + 512);                     // [512]
+  if (tid == 0) *em_bad = 0;
+  __syncthreads();
+  bool my_bad = false;
 
   if constexpr (kFromSiteLik) {
     // PhyloHMM::FillXmsaEmission tail: mix the rate categories (equal weights, scalers aligned to the
@@ -179,10 +334,18 @@ __global__ void __launch_bounds__(kFwdThreads)
       if (b != 4) e /= pi[s * 4 + b];
       for (int q = 0; q < smin && e != 0.0; ++q) e *= kScaleThreshold;
       em[u] = e;
+      my_bad |= !(e > 0.0 && e <= 1.0 + 1e-9);
     }
   } else {
-    for (int u = tid; u < C; u += kFwdThreads) em[u] = em_in[s * fam.n_xmsa + fam.col_of_ucol[u]];
+    for (int u = tid; u < C; u += kFwdThreads) {
+      const double e = em_in[s * fam.n_xmsa + fam.col_of_ucol[u]];
+      em[u] = e;
+      my_bad |= !(e > 0.0 && e <= 1.0 + 1e-9);
+    }
   }
+  // The consensus form of the germline products needs every emission in (0, 1] (see fill_consensus); a sample
+  // with a zero (underflow), a NaN or an emission above 1 walks its products factor by factor as the reference.
+  if (my_bad) *em_bad = 1;
   if (tid == 0) em[C] = 1.0;
   __syncthreads();
   if (em_out) {  // the caller's view: one value per xMSA column
@@ -199,16 +362,22 @@ __global__ void __launch_bounds__(kFwdThreads)
   // [vpadding nV | vgerm nV | dgerm nD | jgerm nJ | jpadding nJ]
   const int nV = fam.vgerm.n_genes, nD = fam.dgerm.n_genes, nJ = fam.jgerm.n_genes;
   double* gem = gem_all + s * fam.gem_size;
-  int cv = fill_segments<kG, kByteOff>(fam.vpadding, em, tid, gem, redi, 0);
-  cv += fill_segments<kG, kByteOff>(fam.vgerm, em, tid, gem + nV, redi, 1);
+  const bool direct = *em_bad != 0;  // (written before the barrier that followed the emission assembly)
+  auto fill = [&](const DevSegments& seg, double* out, int phase) {
+    if (seg.cons_sites > 0 && !direct)
+      return fill_consensus<kG, kByteOff>(seg, em, tid, out, redi, phase, cons_inv, cons_pv, cons_pk);
+    return fill_segments<kG, kByteOff>(seg, em, tid, out, redi, phase);
+  };
+  int cv = fill(fam.vpadding, gem, 0);
+  cv += fill(fam.vgerm, gem + nV, 1);
   int cd = 0, cj;
   if (fam.has_d) {
-    cd = fill_segments<kG, kByteOff>(fam.dgerm, em, tid, gem + 2 * (size_t)nV, redi, 0);
-    cj = fill_segments<kG, kByteOff>(fam.jgerm, em, tid, gem + 2 * (size_t)nV + nD, redi, 1);
-    cj += fill_segments<kG, kByteOff>(fam.jpadding, em, tid, gem + 2 * (size_t)nV + nD + nJ, redi, 0);
+    cd = fill(fam.dgerm, gem + 2 * (size_t)nV, 0);
+    cj = fill(fam.jgerm, gem + 2 * (size_t)nV + nD, 1);
+    cj += fill(fam.jpadding, gem + 2 * (size_t)nV + nD + nJ, 0);
   } else {
-    cj = fill_segments<kG, kByteOff>(fam.jgerm, em, tid, gem + 2 * (size_t)nV, redi, 0);
-    cj += fill_segments<kG, kByteOff>(fam.jpadding, em, tid, gem + 2 * (size_t)nV + nJ, redi, 1);
+    cj = fill(fam.jgerm, gem + 2 * (size_t)nV, 0);
+    cj += fill(fam.jpadding, gem + 2 * (size_t)nV + nJ, 1);
   }
   if (tid == 0) {
     gcnt_all[s * 3 + 0] = cv;
@@ -603,7 +772,10 @@ static size_t junction_lds_bytes(const DevFamily& fam) {
 }
 
 static size_t emission_lds_bytes(const DevFamily& fam) {
-  return (((size_t)fam.n_ucol + 2) & ~(size_t)1) * sizeof(double) + 2 * kFwdWaves * sizeof(int);
+  const bool cons = fam.vpadding.cons_sites || fam.vgerm.cons_sites || fam.dgerm.cons_sites ||
+                    fam.jgerm.cons_sites || fam.jpadding.cons_sites;
+  return (((size_t)fam.n_ucol + 2) & ~(size_t)1) * sizeof(double) + (2 * kFwdWaves + 2) * sizeof(int) +
+         (cons ? (514 + 512) * sizeof(double) + 512 * sizeof(int) : 0);
 }
 
 size_t forward_lds_bytes(const DevFamily& fam) {

@@ -325,3 +325,31 @@ def test_error_paths(hip, data_dir):
     with pytest.raises(RuntimeError):   # wrong tip count for this family
         fam.eval_batch(5, 0, np.zeros((1, 3, 4), dtype=np.int32), np.full((1, 8), 0.1), [ER], [PI], [1.0], 4)
     fam.close()
+
+
+def test_consensus_products_equal_the_factor_walk(hip, tmp_path, monkeypatch):
+    """FillGermlinePaddingEmission (src/PhyloHMM.cpp:158-193) in consensus form (prefix products of the set's
+    consensus columns x the gene's departures) against the factor-by-factor walk of the same kernel
+    (LH_K2A_DIRECT) and against the oracle: values to rounding, ScaleMatrix counts exactly.  The family has
+    24 V alleles of 296 sites on a 120-leaf tree, so the V products cross the 2^-256 threshold."""
+    import linearham_amd
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec(n_leaves=120, n_sites=400, n_v=24, n_d=6, n_j=4, n_samples=4, seed=123), out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    probe = linearham_amd.Family(db.build_family_desc(h), hip)
+    assert probe.consensus_sets & 2, "the V germline set of this family should be in consensus form"
+    probe.close()
+    desc, ll, res, ref = run_family(hip, h, rows, 4)
+    assert all(np.isfinite(r["loglik"]) for r in ref)
+    compare(h, desc, ll, res, ref)
+    assert any(r["vgerm_scaler_count"] > 0 for r in ref)
+    monkeypatch.setenv("LH_K2A_DIRECT", "1")
+    probe = linearham_amd.Family(db.build_family_desc(h), hip)
+    assert probe.consensus_sets == 0
+    probe.close()
+    desc2, ll2, res2, _ = run_family(hip, h, rows, 4)
+    np.testing.assert_allclose(ll, ll2, rtol=1e-12)
+    np.testing.assert_array_equal(res["scaler_counts"], res2["scaler_counts"])
+    np.testing.assert_allclose(res["forward"], res2["forward"], rtol=1e-11)
