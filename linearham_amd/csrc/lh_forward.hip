@@ -334,17 +334,18 @@ __global__ void __launch_bounds__(kFwdThreads)
       if (b != 4) e /= pi[s * 4 + b];
       for (int q = 0; q < smin && e != 0.0; ++q) e *= kScaleThreshold;
       em[u] = e;
-      my_bad |= !(e > 0.0 && e <= 1.0 + 1e-9);
+      my_bad |= !(e >= 0x1p-1000 && e <= 1.0 + 1e-9);
     }
   } else {
     for (int u = tid; u < C; u += kFwdThreads) {
       const double e = em_in[s * fam.n_xmsa + fam.col_of_ucol[u]];
       em[u] = e;
-      my_bad |= !(e > 0.0 && e <= 1.0 + 1e-9);
+      my_bad |= !(e >= 0x1p-1000 && e <= 1.0 + 1e-9);
     }
   }
-  // The consensus form of the germline products needs every emission in (0, 1] (see fill_consensus); a sample
-  // with a zero (underflow), a NaN or an emission above 1 walks its products factor by factor as the reference.
+  // The consensus form of the germline products needs every emission in (0, 1] (see fill_consensus) and its
+  // reciprocal finite; a sample with a zero or nearly subnormal emission (underflow), a NaN or an emission above 1
+  // walks its products factor by factor as the reference does.
   if (my_bad) *em_bad = 1;
   if (tid == 0) em[C] = 1.0;
   __syncthreads();
