@@ -327,7 +327,8 @@ def test_error_paths(hip, data_dir):
     fam.close()
 
 
-def test_consensus_products_equal_the_factor_walk(hip, tmp_path, monkeypatch):
+@pytest.mark.parametrize("locus", ["igh", "igk"])
+def test_consensus_products_equal_the_factor_walk(hip, tmp_path, monkeypatch, locus):
     """FillGermlinePaddingEmission (src/PhyloHMM.cpp:158-193) in consensus form (prefix products of the set's
     consensus columns x the gene's departures) against the factor-by-factor walk of the same kernel
     (LH_K2A_DIRECT) and against the oracle: values to rounding, ScaleMatrix counts exactly.  The family has
@@ -335,7 +336,7 @@ def test_consensus_products_equal_the_factor_walk(hip, tmp_path, monkeypatch):
     import linearham_amd
     from tools import synth_family as sf
     out = str(tmp_path / "fam")
-    sf.generate(sf.Spec(n_leaves=120, n_sites=400, n_v=24, n_d=6, n_j=4, n_samples=4, seed=123), out)
+    sf.generate(sf.Spec(n_leaves=120, n_sites=400, n_v=24, n_d=6, n_j=4, n_samples=4, seed=123, locus=locus), out)
     h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
     rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
     probe = linearham_amd.Family(db.build_family_desc(h), hip)
