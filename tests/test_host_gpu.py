@@ -182,6 +182,9 @@ def test_cli_compute_logl(data_dir):
     """`linearham --compute-logl` prints the log-likelihood with 6 significant digits
     (src/linearham.cpp:341-348)."""
     exe = os.path.join(os.path.dirname(host.host_library_path()), "linearham")
+    if not os.path.exists(exe):   # a built artefact (not in history): g++ is enough to make it
+        from linearham_amd import build as lb
+        lb.build_host(verbose=False)
     cmd = [exe, "--compute-logl", "--yaml-path", os.path.join(data_dir, "phylo_hmm_input.yaml"), "--cluster-ind", "0",
            "--hmm-param-dir", os.path.join(data_dir, "hmm_params"), "--newick-path",
            os.path.join(data_dir, "newton.tree"), "--num-rates", "4"]
