@@ -137,6 +137,17 @@ __device__ static int fill_segments(const DevSegments& seg, const double* em, in
   return mx;
 }
 
+// capacity of the consensus form's LDS arrays: the largest set's sites + 2 (the prefix past the last site and
+// the reciprocal of the padding position), even
+__host__ __device__ static inline int cons_capacity(const DevFamily& fam) {
+  int m = fam.vpadding.cons_sites;
+  m = m > fam.vgerm.cons_sites ? m : fam.vgerm.cons_sites;
+  m = m > fam.dgerm.cons_sites ? m : fam.dgerm.cons_sites;
+  m = m > fam.jgerm.cons_sites ? m : fam.jgerm.cons_sites;
+  m = m > fam.jpadding.cons_sites ? m : fam.jpadding.cons_sites;
+  return m > 0 ? (m + 3) & ~1 : 0;
+}
+
 // (v, k) = the reference's running product after ScaleMatrix: value v * 2^(-256 k), v kept in [2^-256, 1]
 struct ScaledProd {
   double v;
@@ -167,10 +178,12 @@ __device__ static inline ScaledProd sp_from(double e) {  // e in (0, 1]
 //     prefix(last site + 1) / prefix(first site)  x  prod over the gene's departures  em[own] / em[consensus]
 // with prefix = exclusive product scan of the consensus emissions over the set's sites, carried as (v, k)
 // pairs.  A fifth to a twentieth of the factor-by-factor walk's multiplications for allele sets as alike as the
-// candidates of one rearrangement.  lds: cons_inv[513] | cons_pv[512] | cons_pk[512].
+// candidates of one rearrangement.  lds: cons_inv[cap] | cons_pv[cap + 4] | cons_pk[cap + 4], cap = the largest
+// set's sites + 2, even (emission_lds_bytes).
 template <int kG, bool kByteOff>
 __device__ static int fill_consensus(const DevSegments& seg, const double* em, int tid, double* __restrict__ out,
-                                     int* redi, int phase, double* cons_inv, double* cons_pv, int* cons_pk) {
+                                     int* redi, int phase, double* cons_inv, double* cons_pv, int* cons_pk,
+                                     int cap) {  // cap: capacity of the prefix arrays; 4 more slots follow
   const int ns = seg.cons_sites, n = seg.n_genes;
   auto em_at = [&](unsigned x) {
     return kByteOff ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(em) + x) : em[x];
@@ -197,10 +210,10 @@ __device__ static int fill_consensus(const DevSegments& seg, const double* em, i
     const int ok = __shfl_up(incl.k, off, 64);
     if (lane >= off) incl = sp_mul(ScaledProd{ov, ok}, incl);
   }
-  // wave totals through the tail of the prefix arrays (positions 508..511 are never a site's prefix)
+  // wave totals through the four slots behind the prefixes
   if (lane == 63) {
-    cons_pv[508 + wave] = incl.v;
-    cons_pk[508 + wave] = incl.k;
+    cons_pv[cap + wave] = incl.v;
+    cons_pk[cap + wave] = incl.k;
   }
   __syncthreads();
   ScaledProd excl = incl;  // -> exclusive: shift by one thread
@@ -208,9 +221,8 @@ __device__ static int fill_consensus(const DevSegments& seg, const double* em, i
     const double ov = __shfl_up(incl.v, 1, 64);
     const int ok = __shfl_up(incl.k, 1, 64);
     excl = lane == 0 ? ScaledProd{1.0, 0} : ScaledProd{ov, ok};
-    for (int w = 0; w < wave; ++w) excl = sp_mul(ScaledProd{cons_pv[508 + w], cons_pk[508 + w]}, excl);
+    for (int w = 0; w < wave; ++w) excl = sp_mul(ScaledProd{cons_pv[cap + w], cons_pk[cap + w]}, excl);
   }
-  __syncthreads();  // the wave totals have been read: the tail may now be overwritten by prefixes (ns <= 510)
   if (j0 <= ns) {
     cons_pv[j0] = excl.v;
     cons_pk[j0] = excl.k;
@@ -297,9 +309,10 @@ __global__ void __launch_bounds__(kFwdThreads)
   const int C = fam.n_ucol;  // u-columns (lh_device.h); the caller's columns only appear in em_in / em_out
   int* redi = reinterpret_cast<int*>(em + ((C + 2) & ~1));  // 2 * kFwdWaves ints, then one flag word
   int* em_bad = redi + 2 * kFwdWaves;                        // some emission outside (0, 1]
-  double* cons_inv = reinterpret_cast<double*>(redi + 2 * kFwdWaves + 2);  // [513] (consensus form only)
-  double* cons_pv = cons_inv + 514;                                         // [512]
-  int* cons_pk = reinterpret_cast<int*>(cons_pv + 512);                     // [512]
+  const int cons_cap = cons_capacity(fam);                                  // 0: no set in consensus form
+  double* cons_inv = reinterpret_cast<double*>(redi + 2 * kFwdWaves + 2);  // [cap]
+  double* cons_pv = cons_inv + cons_cap;                                    // [cap + 4]
+  int* cons_pk = reinterpret_cast<int*>(cons_pv + cons_cap + 4);            // [cap + 4]
   if (tid == 0) *em_bad = 0;
   __syncthreads();
   bool my_bad = false;
@@ -366,7 +379,7 @@ __global__ void __launch_bounds__(kFwdThreads)
   const bool direct = *em_bad != 0;  // (written before the barrier that followed the emission assembly)
   auto fill = [&](const DevSegments& seg, double* out, int phase) {
     if (seg.cons_sites > 0 && !direct)
-      return fill_consensus<kG, kByteOff>(seg, em, tid, out, redi, phase, cons_inv, cons_pv, cons_pk);
+      return fill_consensus<kG, kByteOff>(seg, em, tid, out, redi, phase, cons_inv, cons_pv, cons_pk, cons_cap);
     return fill_segments<kG, kByteOff>(seg, em, tid, out, redi, phase);
   };
   int cv = fill(fam.vpadding, gem, 0);
@@ -773,10 +786,9 @@ static size_t junction_lds_bytes(const DevFamily& fam) {
 }
 
 static size_t emission_lds_bytes(const DevFamily& fam) {
-  const bool cons = fam.vpadding.cons_sites || fam.vgerm.cons_sites || fam.dgerm.cons_sites ||
-                    fam.jgerm.cons_sites || fam.jpadding.cons_sites;
+  const size_t cap = (size_t)cons_capacity(fam);
   return (((size_t)fam.n_ucol + 2) & ~(size_t)1) * sizeof(double) + (2 * kFwdWaves + 2) * sizeof(int) +
-         (cons ? (514 + 512) * sizeof(double) + 512 * sizeof(int) : 0);
+         (cap ? (2 * cap + 4) * sizeof(double) + (cap + 4) * sizeof(int) : 0);
 }
 
 size_t forward_lds_bytes(const DevFamily& fam) {
