@@ -34,7 +34,7 @@ WORKLOADS = {
                "germline set, R=4 rate categories (not the headline workload)",
     "small": "small synthetic family (development only, not the headline workload)",
 }
-PMC_PROFILE = "r01_v12_bench_pmc_per_launch.json"   # committed PMC passes of the default command
+PMC_PROFILE = "r01_v13_bench_pmc_per_launch.json"   # committed PMC passes of the default command
 
 
 def log(*a):
