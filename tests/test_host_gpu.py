@@ -197,3 +197,61 @@ def test_cli_compute_logl(data_dir):
     assert out.stdout.strip() == "-75.8136"
     bad = subprocess.run([exe, "--nonsense", "--yaml-path", "x"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "ERROR:" in bad.stderr
+
+
+def test_full_size_family_properties(tmp_path):
+    """BASELINE.json configs[2] at full size (100 leaves x 400 sites, 200 V / 30 D / 12 J alleles) through the C++
+    host and the C ABI -- properties that need no oracle run: rows repeated in a batch give identical bits wherever
+    they sit (launch layout independence); swapping the two children of every inner node (another schedule of the
+    same tree) changes the log-likelihood by rounding only; the host-pointer and a second call agree bit for bit;
+    a handful of rows agree with the dense C oracle to 1e-10."""
+    import ctypes as C
+    import linearham_amd
+    from linearham_amd import host as hst
+    from oracle import oracle_c
+    from tests import desc_builder as db
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec(n_samples=48), out)
+    hmm = hst.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    n = 3000                                    # 62 copies of each row, interleaved
+    flat = hmm.flatten_tsv(os.path.join(out, "trees.tsv"), n)
+    lib = linearham_amd.load_library()
+    T, depth = flat["n_tips"], flat["max_depth"]
+
+    def run(ops):
+        ll = np.zeros(n)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        lib.check(lib.lib.lh_eval_batch(C.c_void_p(flat["family"]), n, T, 16, p(np.ascontiguousarray(ops), C.c_int32),
+                                        p(flat["brlen"], C.c_double), p(flat["er"], C.c_double),
+                                        p(flat["pi"], C.c_double), p(flat["alpha"], C.c_double), 4,
+                                        p(ll, C.c_double), None))
+        return ll
+    ll = run(flat["ops"])
+    assert np.all(np.isfinite(ll))
+    rows = flat["n_rows"]
+    for r in range(rows):
+        assert len(set(ll[r::rows].tolist())) == 1, r          # identical bits for identical rows
+    assert np.array_equal(ll, run(flat["ops"]))
+    # the same trees scheduled with every inner node's children swapped
+    rows_tsv = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    o = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    labels = list(o.xmsa_labels)
+    ops2 = flat["ops"].copy()
+    trees = []
+    for r in range(rows):
+        children, root, brlen = hst.newick_arrays(rows_tsv[r]["tree"], labels)
+        trees.append((children, root, brlen))
+        swapped = children.reshape(-1, 2)[:, ::-1].ravel().copy()
+        sched, d = lib.schedule_tree(T, swapped, root)
+        assert d <= 16
+        ops2[r::rows] = sched
+    ll2 = run(ops2)
+    np.testing.assert_allclose(ll2, ll, rtol=1e-12)
+    # a few rows against the dense reference algorithm (C oracle)
+    oracle_c.build()
+    fam = oracle_c.COracleFamily(o, 4)
+    idx = [0, 7, 23]
+    ref = fam.eval([trees[i] for i in idx], [rows_tsv[i]["er"] for i in idx], [rows_tsv[i]["pi"] for i in idx],
+                   [rows_tsv[i]["alpha"] for i in idx], n_threads=3)
+    np.testing.assert_allclose(ll[idx], ref, rtol=1e-10)
