@@ -143,3 +143,41 @@ def test_asr_committed_vectors(hip, data_dir):
     for i, smp in enumerate(g["samples"]):
         assert choice[i].tolist() == smp["rate_choice"]
         assert anc[i].tolist() == smp["anc"]
+
+
+def test_asr_full_size_known_answer(hip, tmp_path):
+    """BASELINE.json configs[2] shape (100 leaves x 400 sites), 256 tree samples: with every branch at 1e-6 the
+    posterior of a constant alignment column is concentrated on that base at every inner node (each node differs
+    with probability ~1e-6), so the sampled ancestral states are known without an oracle run; and a second call
+    reproduces the first bit for bit."""
+    import linearham_amd
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec(n_samples=8), out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    fam = linearham_amd.Family(db.build_family_desc(h), hip)
+    T, L = h.msa.shape[0] + 1, h.msa.shape[1]
+    n = 256
+    ops, brl, depth = [], [], 0
+    for i in range(n):
+        children, root, brlen = db.tree_arrays(orc.parse_newick(rows[i % len(rows)]["tree"]), h.xmsa_labels)
+        o, d = hip.schedule_tree(T, children, root)
+        ops.append(o)
+        brl.append(np.full_like(brlen, 1e-6))
+        depth = max(depth, d)
+    const = np.all(h.msa == h.msa[0:1], axis=0) & (h.msa[0] < 4)
+    assert const.sum() > 50
+    naive = np.where(const, h.msa[0], 4).astype(np.uint8)
+    er, pi = [[1.0] * 6] * n, [[0.25] * 4] * n
+    rates = np.tile(orc.gamma_rates_mean(0.5, 4), (n, 1))
+    args = (T, depth, np.stack(ops), np.stack(brl), er, pi, rates, np.tile(naive, (n, 1)), 2026)
+    anc, choice = fam.asr_batch(*args)
+    anc2, choice2 = fam.asr_batch(*args)
+    fam.close()
+    assert np.array_equal(anc, anc2) and np.array_equal(choice, choice2)
+    want = h.msa[0][const].astype(np.uint8)
+    got = anc[:, :, const]                                   # [n][T-2][constant sites]
+    wrong = int((got != want[None, None, :]).sum())
+    assert wrong <= 5, (wrong, got.size)                     # expectation ~ got.size * 1e-6 * 3 (< 1)
+    assert choice.max() < 4 and len(np.unique(choice)) == 4  # all four categories occur over 256 x 400 draws
