@@ -2,7 +2,10 @@
 """Throughput of the ancestral-sequence sampling step (K3, lh_asr_batch_device) on the configs[2] family,
 inputs resident in HBM.  Not the headline metric (bench.py is); prints one JSON line.
 
-  python tools/bench_asr.py [--batch 2048] [--steps 5] [--warmup 1] [--preset config2|config4]
+  python bench_asr.py [--batch 2048] [--steps 5] [--warmup 1] [--preset config2|config4]
+
+Like bench.py, the only use of oracle/ here is the `cpu_baseline` leg (the checker timed beside the kernel); the
+measured path and its inputs come from the product (C++ host + C ABI; the site rates are K0's).
 
 K3 is the CLV-streaming kernel of SURVEY 8(d)'s byte model: per tree sample it writes and reads back
 32 B per (inner node, site) plus one state byte per (inner node, site)."""
@@ -14,7 +17,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
@@ -29,7 +32,6 @@ def main():
     import torch
     import linearham_amd
     from linearham_amd import host
-    from oracle import linearham_oracle as orc
     from tools import synth_family as sf
     dev = torch.device("cuda", 0)
     spec = {"config2": sf.Spec(n_samples=256), "small": sf.Spec.small(n_samples=16),
@@ -43,14 +45,24 @@ def main():
     flat = hmm.flatten_tsv(os.path.join(fam_dir, "trees.tsv"), n)
     T, depth, R, L = flat["n_tips"], flat["max_depth"], 4, sizes["n_sites"]
     rng = np.random.default_rng(1)
-    rates = np.stack([orc.gamma_rates_mean(a, R) for a in flat["alpha"][:256]])
-    rates = rates[np.arange(n) % rates.shape[0]]
+    lib = linearham_amd.load_library()
+    fam = C.c_void_p(flat["family"])
+    # the samples' site rates: K0's discrete-Gamma means, through the C ABI
+    rates = np.zeros((n, R))
+    _ll = np.zeros(n)
+
+    from linearham_amd.capi import _EvalOutputs, c_f64p, c_i32p
+    outs = _EvalOutputs()
+    outs.rates = rates.ctypes.data_as(c_f64p)
+    lib.check(lib.lib.lh_eval_batch(fam, n, T, depth, np.ascontiguousarray(flat["ops"]).ctypes.data_as(c_i32p),
+                                    np.ascontiguousarray(flat["brlen"]).ctypes.data_as(c_f64p),
+                                    flat["er"].ctypes.data_as(c_f64p), flat["pi"].ctypes.data_as(c_f64p),
+                                    flat["alpha"].ctypes.data_as(c_f64p), R, _ll.ctypes.data_as(c_f64p),
+                                    C.byref(outs)))
     naive = rng.integers(0, 4, size=(n, L)).astype(np.uint8)
     d = {k: torch.from_numpy(np.ascontiguousarray(flat[k])).to(dev) for k in ("ops", "brlen", "er", "pi")}
     d_rates, d_naive = torch.from_numpy(rates).to(dev), torch.from_numpy(naive).to(dev)
     anc = torch.zeros((n, T - 2, L), dtype=torch.uint8, device=dev)
-    lib = linearham_amd.load_library()
-    fam = C.c_void_p(flat["family"])
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(seed):
@@ -78,6 +90,7 @@ def main():
     # CPU baseline: the numpy restatement of the R step (oracle/asr_oracle.py) on a few samples of the same
     # batch, one core (the R script runs one tree per core); its draws must equal the GPU's
     from oracle import asr_oracle as ao
+    from oracle import linearham_oracle as orc
     from linearham_amd import host as _host
     rows = sf.read_trees_tsv(os.path.join(fam_dir, "trees.tsv"))
     o = orc.PhyloHMM(os.path.join(fam_dir, "cluster.yaml"), 0, os.path.join(fam_dir, "hmm_params"), 0)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Scratch performance probe (NOT bench.py): times the HIP kernels on a synthetic family using the
-test-infrastructure descriptor builder.  Usage: python tools/perf_probe.py [preset] [n_samples] [reps]"""
+test-infrastructure descriptor builder.  Usage: python tests/dev_tools/perf_probe.py [preset] [n_samples] [reps]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import linearham_amd
