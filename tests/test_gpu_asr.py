@@ -181,3 +181,25 @@ def test_asr_full_size_known_answer(hip, tmp_path):
     wrong = int((got != want[None, None, :]).sum())
     assert wrong <= 5, (wrong, got.size)                     # expectation ~ got.size * 1e-6 * 3 (< 1)
     assert choice.max() < 4 and len(np.unique(choice)) == 4  # all four categories occur over 256 x 400 draws
+
+
+@pytest.mark.parametrize("seed", [201, 202, 203, 204, 205, 206])
+def test_asr_random_small_families(hip, tmp_path, seed):
+    """Differently shaped small families (locus, leaves 3..40, allele counts, divergence, R drawn from the seed):
+    every one gives K3 another tree shape, pattern set and category split; draws must equal the oracle's."""
+    from tools import synth_family as sf
+    rng = np.random.default_rng(seed)
+    locus = ["igh", "igh", "igk", "igl"][int(rng.integers(4))]
+    kw = dict(locus=locus, seed=seed, n_leaves=int(rng.integers(3, 41)), n_samples=3,
+              n_v=int(rng.integers(1, 9)), n_j=int(rng.integers(1, 6)), n_nni=int(rng.integers(0, 4)),
+              divergence=float(rng.choice([0.0, 0.05, 0.3])))
+    if locus == "igh":
+        kw["n_d"] = int(rng.integers(1, 6))
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(**kw), out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    R = int(rng.choice([1, 2, 3, 4, 6]))
+    mism, total, anc, choice = _run(hip, h, rows, R, seed=seed, first_sample=int(rng.integers(0, 1 << 40)), rng=rng)
+    assert mism == 0, (mism, total)
+    assert choice.max() < R
