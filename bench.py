@@ -198,12 +198,13 @@ def main():
         bytes_per_eval = Cx * (2 * I * R * 32 + T + 8)         # CLV-streaming model
         launches = max(groups.value, 1)
         prune_ms = ms[1].value / launches                        # average duration of one K1 launch
-        achieved = bytes_per_eval * n / (prune_ms * 1e-3) / 1e9
+        per_launch = n * args.steps / launches                   # evaluations one launch group processes
+        achieved = bytes_per_eval * per_launch / (prune_ms * 1e-3) / 1e9
         # HBM traffic of one K1 launch from the committed PMC passes of this same command (counters need
         # their own rocprofv3 runs; gfx950 correction: FETCH_SIZE counts wide coalesced reads at half).
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", PMC_PROFILE)
-        if args.preset == "config2" and n == DEFAULT_BATCH and os.path.exists(pmc_file):
+        if args.preset == "config2" and per_launch == DEFAULT_BATCH and os.path.exists(pmc_file):
             with open(pmc_file) as f:
                 pmc = json.load(f)
             k1 = next((v for k, v in pmc.items() if "prune_kernel" in k), {})
@@ -216,7 +217,7 @@ def main():
         flop_per_site_rate = (4 * kinds[0] + 36 * kinds[1] + 68 * kinds[2]) / float(flat["ops"].shape[0]) + 60
         n_pat, n_ucol = C.c_int32(), C.c_int32()
         lib.check(lib.lib.lh_family_info(C.c_void_p(fam_handle), C.byref(n_pat), C.byref(n_ucol)))
-        k1_flops = flop_per_site_rate * n_pat.value * R * n   # executed: identical columns are pruned once
+        k1_flops = flop_per_site_rate * n_pat.value * R * per_launch   # executed: identical columns are pruned once
         k1_tflops = k1_flops / (prune_ms * 1e-3) / 1e12
         out = {
             "metric": "phylo-HMM log-likelihood evals/sec (100-leaf x 400-site family)",
@@ -232,15 +233,16 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "prune_kernel (K1, Felsenstein pruning)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
-                         "algorithmic_bytes_per_eval": bytes_per_eval, "evals_per_launch": n,
+                         "algorithmic_bytes_per_eval": bytes_per_eval, "evals_per_launch": per_launch,
                          "avg_launch_ms": prune_ms,
                          "fp64_valu": {"achieved": k1_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                        "frac": k1_tflops / FP64_VALU_PEAK_TFLOPS},
                          "note": "achieved = CLV-streaming model bytes (SURVEY 8(d)) / measured K1 time; the kernel "
                                  "keeps CLVs in registers and shares the tree across the naive states of a site, so it "
                                  "moves far fewer HBM bytes than the model and is FP64-VALU bound, see DESIGN.md"},
-            "kernel_ms_per_step": {"model_K0": ms[0].value / launches, "prune_K1": prune_ms,
-                                   "forward_K2": ms[2].value / launches},
+            "kernel_ms_per_step": {"model_K0": ms[0].value / args.steps, "prune_K1": ms[1].value / args.steps,
+                                   "forward_K2": ms[2].value / args.steps,
+                                   "launch_groups_per_step": launches / args.steps},
         }
         if world == 1 and args.pcie:
             # PCIe-inclusive rate through the host-pointer entry point (never `value`): H2D of the
