@@ -262,7 +262,7 @@ def main():
             if not args.no_check and not np.array_equal(ll_pcie, ll_host, equal_nan=True):
                 raise SystemExit("host-pointer and device-pointer entry points disagree")
         if world == 1 and not args.no_cpu_baseline:
-            base, ref_ll = cpu_baseline(fam_dir, 64, args.cpu_budget_s)
+            base, ref_ll = cpu_baseline(fam_dir, 192, args.cpu_budget_s)
             out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
             both = [(ll_host[i], v) for i, v in ref_ll.items() if i < n]
             if any(np.isfinite(g) != np.isfinite(v) for g, v in both):
