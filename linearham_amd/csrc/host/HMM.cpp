@@ -502,31 +502,16 @@ void FillTransition(const GermlineGene& from_ggene, const GermlineGene& to_ggene
         }
     }
     if (germ_row_length > 0 && germ_col_length > 0) {
-      int match_row_diff = 0, match_col_diff = 0;
-      bool match_found = false;
-      for (int from_site_ind = site_ind_row_start;
-           from_site_ind < site_ind_row_start + germ_row_length && !match_found; from_site_ind++) {
-        if (from_site_ind == site_ind_col_start - 1) {
-          match_row_diff = from_site_ind - site_ind_row_start;
-          match_col_diff = 0;
-          match_found = true;
-        }
-      }
-      for (int to_site_ind = site_ind_col_start + 1;
-           to_site_ind < site_ind_col_start + germ_col_length && !match_found; to_site_ind++) {
-        if (site_ind_row_start == to_site_ind - 1) {
-          match_row_diff = 0;
-          match_col_diff = to_site_ind - site_ind_col_start;
-          match_found = true;
-        }
-      }
-      if (match_found) {
-        const int match_length = std::min(germ_row_length - match_row_diff, germ_col_length - match_col_diff);
-        for (int k = 0; k < match_length; ++k)
-          T(row_off + germ_row_start + match_row_diff + k, col_off + germ_col_start + match_col_diff + k) =
-              from.landing_out()[germ_ind_row_start + match_row_diff + k] * to.gene_prob() *
-              to.landing_in()[germ_ind_col_start + match_col_diff + k];
-      }
+      // Germline-to-germline entries across two genes exist only between states on consecutive alignment
+      // sites: row a sits on site site_ind_row_start + a, column b on site site_ind_col_start + b, so the
+      // nonzeros lie on the one diagonal b - a = shift, clipped to the block.
+      const int shift = site_ind_row_start + 1 - site_ind_col_start;
+      const int a0 = shift < 0 ? -shift : 0, b0 = shift > 0 ? shift : 0;
+      const int run = std::min(germ_row_length - a0, germ_col_length - b0);
+      const double gp = to.gene_prob();
+      for (int k = 0; k < run; ++k)
+        T(row_off + germ_row_start + a0 + k, col_off + germ_col_start + b0 + k) =
+            from.landing_out()[germ_ind_row_start + a0 + k] * gp * to.landing_in()[germ_ind_col_start + b0 + k];
     }
   }
 }

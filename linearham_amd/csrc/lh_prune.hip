@@ -67,12 +67,36 @@ namespace {
   _Pragma("unroll") for (int s_ = 0; s_ < S; ++s_) matvec(pa, st##d[s_], z[s_]);
 #define LH_DECL(d) double st##d[S][4];
 
-// x = P * a for a wave-uniform row-major 4x4 P (scalar operands)
-__device__ __forceinline__ void matvec(const double* __restrict__ p, const double (&a)[4], double (&x)[4]) {
-  x[0] = fma(p[3], a[3], fma(p[2], a[2], fma(p[1], a[1], p[0] * a[0])));
-  x[1] = fma(p[7], a[3], fma(p[6], a[2], fma(p[5], a[1], p[4] * a[0])));
-  x[2] = fma(p[11], a[3], fma(p[10], a[2], fma(p[9], a[1], p[8] * a[0])));
-  x[3] = fma(p[15], a[3], fma(p[14], a[2], fma(p[13], a[1], p[12] * a[0])));
+// A wave-uniform row-major 4x4 P-matrix held in 32 SGPRs (rows 0-1 | rows 2-3).
+typedef double sgpr8d __attribute__((ext_vector_type(8)));
+struct SMat {
+  sgpr8d lo, hi;
+};
+
+// The walk's P-matrices were written to the scratch area by THIS workgroup's prologue (vector stores, drained
+// and followed by the workgroup barrier) and are wanted as SCALAR operands.  The compiler only selects scalar
+// loads for memory it can prove the kernel never writes, so the loads are spelled out: volatile asm is never
+// moved across the barrier (or across another volatile asm), the wait for the data sits in the same statement,
+// and the registers come back as plain values.  No pointer is declared read-only or unaliased to get here.
+// (The scalar cache cannot hold a stale copy: it is invalidated at kernel boundaries, and inside a launch a
+// scratch line is never read before the workgroup that reads it has written it.)
+__device__ __forceinline__ SMat load_pmat(const double* p /* wave-uniform, 64-byte aligned */) {
+  SMat m;
+  asm volatile(
+      "s_load_dwordx16 %0, %2, 0x0\n\t"
+      "s_load_dwordx16 %1, %2, 0x40\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(m.lo), "=&s"(m.hi)
+      : "s"(p));
+  return m;
+}
+
+// x = P * a (scalar operands)
+__device__ __forceinline__ void matvec(const SMat& p, const double (&a)[4], double (&x)[4]) {
+  x[0] = fma(p.lo[3], a[3], fma(p.lo[2], a[2], fma(p.lo[1], a[1], p.lo[0] * a[0])));
+  x[1] = fma(p.lo[7], a[3], fma(p.lo[6], a[2], fma(p.lo[5], a[1], p.lo[4] * a[0])));
+  x[2] = fma(p.hi[3], a[3], fma(p.hi[2], a[2], fma(p.hi[1], a[1], p.hi[0] * a[0])));
+  x[3] = fma(p.hi[7], a[3], fma(p.hi[6], a[2], fma(p.hi[5], a[1], p.hi[4] * a[0])));
 }
 
 // Column `st` of a tip branch's P (= P * onehot(st)) from the LDS table tiptab[tip][4][4]; a tip whose
@@ -98,7 +122,7 @@ __device__ __forceinline__ void tip_column(const double* tiptab, int tip, int st
 template <int kDepth, int S, bool kN>
 __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_t* __restrict__ msa, int L,
                                            int n_ops, const int4* __restrict__ op_ptr,
-                                           const double* __restrict__ pm, const double* tiptab,
+                                           const double* pm, const double* tiptab,
                                            const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
   unsigned usite[S];  // MSA byte offsets are 32-bit: (tip row) * L + site
 #pragma unroll
@@ -157,7 +181,7 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
         tip_column<kN>(tiptab, op.z, sb[s], v[s]);
       }
     } else {
-      const double* __restrict__ pb = pm + (size_t)k * 32;
+      const SMat pb = load_pmat(pm + (size_t)k * 32);
 #pragma unroll
       for (int s = 0; s < S; ++s) matvec(pb, a[s], v[s]);
       if (kind == OP_TIP_ACC) {
@@ -166,7 +190,7 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
           tip_column<kN>(tiptab, op.y, sa[s], u[s]);
         }
       } else {  // OP_POP_ACC
-        const double* __restrict__ pa = pm + (size_t)k * 32 + 16;
+        const SMat pa = load_pmat(pm + (size_t)k * 32 + 16);
         double(&z)[S][4] = u;
         if (op.w == 0) {
           LH_POP_SLOT(0)
@@ -277,7 +301,7 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
                                            int T, int n_ops, const int32_t* __restrict__ ops,
                                            const double* __restrict__ brlen, const double* __restrict__ rates,
                                            const double* __restrict__ eig, double* pmat_w,
-                                           const double* __restrict__ pmat, const double* __restrict__ pi,
+                                           const double* __restrict__ pi,
                                            double* __restrict__ site_lik, int32_t* __restrict__ site_scal) {
   extern __shared__ double2 smem2[];
   const int tid = threadIdx.x;
@@ -346,12 +370,15 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
       }
     }
   }
-  __threadfence_block();  // the stores above have reached L2 before any wave passes the barrier
+  // every storing wave's stores have reached L2 (which is where the scalar cache fills from) before any
+  // wave passes the barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __threadfence_block();
   __syncthreads();
 
-  // P-matrices in schedule order, now through the read-only alias: the scalar loads of the walk stream
-  // through memory and their addresses do not depend on the op descriptor.
-  const double* __restrict__ pm = pmat + pm_off;
+  // P-matrices in schedule order: the walk reads them with explicit scalar loads (load_pmat), whose
+  // addresses depend on the op number only.
+  const double* pm = pmat_w + pm_off;
   const int lane = tid & 63;
   const int tile0 = blockIdx.x * tile;
   const int site_end = min(tile0 + tile, L);
@@ -428,16 +455,14 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
   }
 }
 
-// pmat_w and pmat are the same buffer: written through the first in the prologue, read through the
-// second (declared read-only and unaliased, which is what lets the compiler keep the walk's P-matrix
-// loads on the scalar unit) after the barrier.
+// pmat_w: the scratch area (see prune_body); written in the prologue, read back after the barrier.
 #define LH_PRUNE_PARAMS                                                                                     \
   int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, int n_ops,               \
       const int32_t *__restrict__ ops,                                                                      \
       const double *__restrict__ brlen, const double *__restrict__ rates, const double *__restrict__ eig,  \
-      double *pmat_w, const double *__restrict__ pmat, const double *__restrict__ pi,                      \
+      double *pmat_w, const double *__restrict__ pi,                                                       \
       double *__restrict__ site_lik, int32_t *__restrict__ site_scal
-#define LH_PRUNE_ARGS n2, tile, R, wpr, msa, L, T, n_ops, ops, brlen, rates, eig, pmat_w, pmat, pi, site_lik, site_scal
+#define LH_PRUNE_ARGS n2, tile, R, wpr, msa, L, T, n_ops, ops, brlen, rates, eig, pmat_w, pi, site_lik, site_scal
 
 // Shallow stacks (depth <= 4, any tree up to a few hundred tips): two sites per lane.  The walk needs
 // ~100 VGPRs; resident waves matter more to it than a few spilled registers, as long as the LDS tip
@@ -517,7 +542,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                    \
     hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, R, wpr, fam.msa, L, T, n_ops, ops, brlen, rates, \
-                       eig, pmat, (const double*)pmat, pi, site_lik, site_scal);                              \
+                       eig, pmat, pi, site_lik, site_scal);                                                   \
   }
   // waves per SIMD that the LDS of the resident workgroups allows (160 KB per CU, 4 SIMDs)
   const int lds_waves = lds == 0 ? 8 : (int)((160 * 1024 / lds) * wg_waves / 4);

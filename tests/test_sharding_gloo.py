@@ -1,56 +1,61 @@
-"""World-size-2 gloo rehearsal (CPU) of bench.py's multi-GPU scheme: tree samples shard over ranks with
-no data-path collective, and ONE gather of the per-sample log-likelihoods reaches rank 0 in rank order.
-The evaluation itself is replaced by a deterministic stand-in (the HIP path needs a GPU); what is under
-test is the sharding, the gather layout and the max-over-ranks timing reduction."""
+"""World-size-2/3 gloo runs (CPU) of the product's multi-GPU scheme, linearham_amd/sharding.py -- the
+module bench.py uses: sample i -> rank i mod N, no data-path collective, ONE gather of the per-sample
+log-likelihoods to rank 0, MAX-over-ranks timing, and the launcher that starts the rank processes.  Only
+the evaluation is a stand-in (the HIP path needs a GPU)."""
+import json
 import os
-import socket
+import sys
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
+
+from linearham_amd import sharding
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "sharding_worker.py")
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def test_shard_ids_partition_every_sample_once():
+    for n_total, world in ((10, 1), (10, 3), (7, 8), (24576 * 8, 8), (10000, 8)):
+        seen = np.concatenate([sharding.shard_ids(n_total, world, r) for r in range(world)])
+        assert sorted(seen.tolist()) == list(range(n_total))
+        for r in range(world):
+            ids = sharding.shard_ids(n_total, world, r)
+            assert len(ids) == sharding.shard_size(n_total, world, r)
+            assert all(int(i) % world == r for i in ids)          # sample i -> GPU i mod N
+    with pytest.raises(ValueError):
+        sharding.shard_ids(4, 2, 2)
 
 
-def _shard(n_total, world, rank):
-    """Contiguous weak-scaling shards: rank r owns samples [r*n, (r+1)*n)."""
-    n = n_total // world
-    return rank * n, n
+def test_unshard_inverts_sharding_with_padding():
+    n_total, world = 11, 4
+    vals = np.arange(n_total) * 1.5
+    m = sharding.shard_size(n_total, world, 0)
+    parts = []
+    for r in range(world):
+        p = np.full(m, np.nan)
+        ids = sharding.shard_ids(n_total, world, r)
+        p[:len(ids)] = vals[ids]
+        parts.append(p)
+    np.testing.assert_array_equal(sharding.unshard(parts, n_total, world), vals)
 
 
-def _fake_loglik(sample_ids):
-    return -1000.0 - 0.25 * sample_ids.to(torch.float64)
+@pytest.mark.parametrize("world,n_rows,n_total", [(2, 37, 37), (2, 16, 41), (3, 10, 10)])
+def test_ranks_shard_gather_in_sample_order(world, n_rows, n_total):
+    status, out = sharding.spawn_ranks([sys.executable, WORKER, str(n_rows), str(n_total)], world, timeout_s=240)
+    assert status == 0, out
+    got = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    sys.path.insert(0, HERE)
+    import sharding_worker as sw
+    flat = sw.table(n_rows)
+    rows = sharding.table_rows(np.arange(n_total), n_rows)       # the table is reused cyclically
+    want = sw.fake_loglik({k: flat[k][rows] for k in ("ops", "brlen", "er", "pi", "alpha")})
+    assert got["world"] == world
+    np.testing.assert_array_equal(np.asarray(got["loglik"]), want)   # global sample order, nothing lost
+    assert got["t_max"] == pytest.approx(0.010 * world)              # MAX over ranks
+    assert got["n_rank0"] == sharding.shard_size(n_total, world, 0)
 
 
-def _worker(rank, world, port, n_per_rank, out_path):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    start, n = _shard(world * n_per_rank, world, rank)
-    ids = torch.arange(start, start + n)
-    ll = _fake_loglik(ids)
-    gathered = [torch.zeros(n, dtype=torch.float64) for _ in range(world)] if rank == 0 else None
-    dist.gather(ll, gather_list=gathered, dst=0)
-    t = torch.tensor([0.010 * (rank + 1)], dtype=torch.float64)   # pretend rank 1 is the slowest
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    if rank == 0:
-        np.save(out_path, np.concatenate([g.numpy() for g in gathered] + [t.numpy()]))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_two_rank_shard_and_gather(tmp_path):
-    world, n = 2, 37
-    out = str(tmp_path / "gathered.npy")
-    mp.spawn(_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
-    got = np.load(out)
-    want = _fake_loglik(torch.arange(world * n)).numpy()
-    np.testing.assert_array_equal(got[:-1], want)      # rank order == sample order, nothing lost
-    assert got[-1] == pytest.approx(0.020)             # MAX over ranks
+def test_failed_rank_fails_the_launch():
+    status, out = sharding.spawn_ranks([sys.executable, WORKER, "8", "8", "1"], 2, timeout_s=120)
+    assert status != 0

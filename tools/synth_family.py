@@ -394,13 +394,15 @@ def generate(spec, outdir):
     return meta
 
 
-def read_trees_tsv(path):
+def read_trees_tsv(path, max_rows=None):
     """Minimal reader of the RevBayes table (columns by name, extra columns ignored)."""
     rows = []
     with open(path) as f:
         header = f.readline().rstrip("\n").split("\t")
         ix = {h: i for i, h in enumerate(header)}
         for line in f:
+            if max_rows is not None and len(rows) >= max_rows:
+                break
             p = line.rstrip("\n").split("\t")
             rows.append({"iteration": int(p[ix["Iteration"]]), "likelihood": float(p[ix["Likelihood"]]),
                          "prior": float(p[ix["Prior"]]), "alpha": float(p[ix["alpha"]]),
@@ -413,10 +415,10 @@ def read_trees_tsv(path):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("outdir")
-    ap.add_argument("--preset", default="config2", choices=["config2", "config4", "small"])
+    ap.add_argument("--preset", default="config2", choices=["config2", "config3", "config4", "small"])
     ap.add_argument("--n-samples", type=int, default=None)
     a = ap.parse_args()
-    spec = {"config2": Spec(), "small": Spec.small(),
+    spec = {"config2": Spec(), "config3": Spec(n_samples=10000), "small": Spec.small(),
             "config4": Spec(n_leaves=500, n_sites=600)}[a.preset]
     if a.n_samples:
         spec.n_samples = a.n_samples
