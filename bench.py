@@ -92,6 +92,29 @@ def prepare_family(preset, batch, may_generate, wait_s=600):
     return d, spec
 
 
+def usable_cores():
+    """Cores this process may really use: its affinity mask, capped by the cgroup CPU quota (a one-GPU box
+    shows every core of the host in the mask but grants a share of them)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = int(f.read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -117,7 +140,7 @@ def cpu_oracle(fam_dir, row_ids, budget_s=None, n_timed=0):
     fam = oracle_c.COracleFamily(h, 4)
     rows = sf.read_trees_tsv(os.path.join(fam_dir, "trees.tsv"), max_rows=max(max(row_ids) + 1, n_timed, 2))
     log("[cpu oracle] family set-up %.1fs" % (time.time() - t0))
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     cache = {}
 
     def tree(i):
@@ -143,8 +166,8 @@ def cpu_oracle(fam_dir, row_ids, budget_s=None, n_timed=0):
         tN, llN = run(idx, cores)
         ref.update({i: float(llN[k]) for k, i in enumerate(idx)})
         base = {"value": n_all / tN, "unit": "evals/s", "cores": cores, "kind": "port",
-                "sample": "%d evaluations (the first rows of the same tree table) on %d threads = every core of this "
-                          "process's affinity mask; dense reference algorithm restated in C (oracle/oracle_kernels.c, "
+                "sample": "%d evaluations (the first rows of the same tree table) on %d threads = every core this "
+                          "process may use (affinity mask capped by the cgroup CPU quota); dense reference algorithm restated in C (oracle/oracle_kernels.c, "
                           "-O3 AVX2; upstream builds without -O); single thread: %.3f evals/s; CPU: %s"
                           % (n_all, cores, 1.0 / per_eval, cpu_model()),
                 "single_thread_evals_per_s": 1.0 / per_eval, "cpu_model": cpu_model()}

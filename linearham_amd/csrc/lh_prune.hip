@@ -67,36 +67,36 @@ namespace {
   _Pragma("unroll") for (int s_ = 0; s_ < S; ++s_) matvec(pa, st##d[s_], z[s_]);
 #define LH_DECL(d) double st##d[S][4];
 
-// A wave-uniform row-major 4x4 P-matrix held in 32 SGPRs (rows 0-1 | rows 2-3).
-typedef double sgpr8d __attribute__((ext_vector_type(8)));
-struct SMat {
-  sgpr8d lo, hi;
-};
-
 // The walk's P-matrices were written to the scratch area by THIS workgroup's prologue (vector stores, drained
-// and followed by the workgroup barrier) and are wanted as SCALAR operands.  The compiler only selects scalar
-// loads for memory it can prove the kernel never writes, so the loads are spelled out: volatile asm is never
-// moved across the barrier (or across another volatile asm), the wait for the data sits in the same statement,
-// and the registers come back as plain values.  No pointer is declared read-only or unaliased to get here.
+// and followed by the workgroup barrier) and are wanted as SCALAR operands.  The compiler selects scalar loads
+// only for memory it may assume the kernel does not change, so the walk reads the scratch area through a
+// pointer to the constant address space -- and that pointer does not exist before the barrier: it is the
+// OUTPUT of a volatile asm statement placed after the barrier.  Every P-matrix load is data-dependent on that
+// statement, so none can be scheduled above the barrier, whatever the optimiser assumes about aliasing
+// (nothing is declared __restrict__ or read-only that is written here); from that point on the lines are
+// indeed constant for the rest of the kernel.  The compiler issues the loads and counts their completion
+// itself, which is what lets it start them well ahead of their use.
 // (The scalar cache cannot hold a stale copy: it is invalidated at kernel boundaries, and inside a launch a
 // scratch line is never read before the workgroup that reads it has written it.)
-__device__ __forceinline__ SMat load_pmat(const double* p /* wave-uniform, 64-byte aligned */) {
-  SMat m;
-  asm volatile(
-      "s_load_dwordx16 %0, %2, 0x0\n\t"
-      "s_load_dwordx16 %1, %2, 0x40\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&s"(m.lo), "=&s"(m.hi)
-      : "s"(p));
-  return m;
+typedef const double __attribute__((address_space(4))) * pmat_ptr;
+
+__device__ __forceinline__ pmat_ptr pmat_after_barrier(const double* p) {
+  // the address is the same in every lane; say so in a form the register allocator has to honour
+  // (the builtin returns a signed int: widen through uint32_t, or a low word with bit 31 set smears into the high one)
+  const uint64_t bits = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bits);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits >> 32));
+  uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
+  asm volatile("; lh: P-matrix scratch base %0 -- scalar loads of the walk depend on this statement" : "+s"(v) : : "memory");
+  return (pmat_ptr)v;
 }
 
-// x = P * a (scalar operands)
-__device__ __forceinline__ void matvec(const SMat& p, const double (&a)[4], double (&x)[4]) {
-  x[0] = fma(p.lo[3], a[3], fma(p.lo[2], a[2], fma(p.lo[1], a[1], p.lo[0] * a[0])));
-  x[1] = fma(p.lo[7], a[3], fma(p.lo[6], a[2], fma(p.lo[5], a[1], p.lo[4] * a[0])));
-  x[2] = fma(p.hi[3], a[3], fma(p.hi[2], a[2], fma(p.hi[1], a[1], p.hi[0] * a[0])));
-  x[3] = fma(p.hi[7], a[3], fma(p.hi[6], a[2], fma(p.hi[5], a[1], p.hi[4] * a[0])));
+// x = P * a for a wave-uniform row-major 4x4 P (scalar operands)
+__device__ __forceinline__ void matvec(pmat_ptr p, const double (&a)[4], double (&x)[4]) {
+  x[0] = fma(p[3], a[3], fma(p[2], a[2], fma(p[1], a[1], p[0] * a[0])));
+  x[1] = fma(p[7], a[3], fma(p[6], a[2], fma(p[5], a[1], p[4] * a[0])));
+  x[2] = fma(p[11], a[3], fma(p[10], a[2], fma(p[9], a[1], p[8] * a[0])));
+  x[3] = fma(p[15], a[3], fma(p[14], a[2], fma(p[13], a[1], p[12] * a[0])));
 }
 
 // Column `st` of a tip branch's P (= P * onehot(st)) from the LDS table tiptab[tip][4][4]; a tip whose
@@ -122,7 +122,7 @@ __device__ __forceinline__ void tip_column(const double* tiptab, int tip, int st
 template <int kDepth, int S, bool kN>
 __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_t* __restrict__ msa, int L,
                                            int n_ops, const int4* __restrict__ op_ptr,
-                                           const double* pm, const double* tiptab,
+                                           pmat_ptr pm, const double* tiptab,
                                            const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
   unsigned usite[S];  // MSA byte offsets are 32-bit: (tip row) * L + site
 #pragma unroll
@@ -181,7 +181,7 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
         tip_column<kN>(tiptab, op.z, sb[s], v[s]);
       }
     } else {
-      const SMat pb = load_pmat(pm + (size_t)k * 32);
+      const pmat_ptr pb = pm + (size_t)k * 32;
 #pragma unroll
       for (int s = 0; s < S; ++s) matvec(pb, a[s], v[s]);
       if (kind == OP_TIP_ACC) {
@@ -190,7 +190,7 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
           tip_column<kN>(tiptab, op.y, sa[s], u[s]);
         }
       } else {  // OP_POP_ACC
-        const SMat pa = load_pmat(pm + (size_t)k * 32 + 16);
+        const pmat_ptr pa = pm + (size_t)k * 32 + 16;
         double(&z)[S][4] = u;
         if (op.w == 0) {
           LH_POP_SLOT(0)
@@ -376,9 +376,8 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
   __threadfence_block();
   __syncthreads();
 
-  // P-matrices in schedule order: the walk reads them with explicit scalar loads (load_pmat), whose
-  // addresses depend on the op number only.
-  const double* pm = pmat_w + pm_off;
+  // P-matrices in schedule order (addresses depend on the op number only), readable from here on
+  const pmat_ptr pm = pmat_after_barrier(pmat_w + pm_off);
   const int lane = tid & 63;
   const int tile0 = blockIdx.x * tile;
   const int site_end = min(tile0 + tile, L);
