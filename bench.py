@@ -197,7 +197,7 @@ def parse_args():
                          "a box with fewer GPUs than ranks -- ranks then share devices (LOCAL_RANK modulo)")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = {"config2": DEFAULT_BATCH, "config3": 0, "config4": 2048, "small": 64}[args.preset]
+        args.batch = {"config2": DEFAULT_BATCH, "config3": 0, "config4": 6144, "small": 64}[args.preset]
     return args
 
 

@@ -319,7 +319,7 @@ int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_
   return 0;
 }
 
-size_t scratch_doubles(int T) { return (size_t)std::max(T - 2, 1) * 32 + (T > 106 ? (size_t)T * 16 : 0); }
+size_t scratch_doubles(int T) { return (size_t)std::max(T - 2, 1) * 32; }
 
 int ensure_workspace(lh_family* f, int n, int R, int T) {
   Workspace& w = f->ws;
@@ -334,8 +334,7 @@ int ensure_workspace(lh_family* f, int n, int R, int T) {
   const int cap = std::max(n, 1);
   LH_HIP(hipMalloc((void**)&w.rates, sizeof(double) * cap * R));
   LH_HIP(hipMalloc((void**)&w.eig, sizeof(double) * cap * 36));
-  // K1's scratch area per (sample, rate): the schedule's P-matrices and, for trees large enough that K1
-  // may keep the tip table there instead of in LDS, the tip table
+  // K1's scratch area per (sample, rate): the schedule's P-matrices
   LH_HIP(hipMalloc((void**)&w.pmat, sizeof(double) * cap * R * scratch_doubles(T)));
   LH_HIP(hipMalloc((void**)&w.site_lik, sizeof(double) * cap * R * 5 * std::max(L, (size_t)1)));
   LH_HIP(hipMalloc((void**)&w.site_scal, sizeof(int32_t) * cap * R * std::max(L, (size_t)1)));

@@ -117,13 +117,53 @@ __device__ __forceinline__ void tip_column(const double* tiptab, int tip, int st
   }
 }
 
+// Large trees: a table of all T tip matrices (128 B per tip) would take the LDS of a CU for one or two
+// workgroups.  The walk visits the tips in schedule order, so the table is built a SEGMENT of the schedule at a
+// time: kSegOps consecutive ops, two slots per op (slot 2 (k - k0) + c for child c of op k, used when that
+// child is a tip).  At a segment boundary -- the same op for every wave of the workgroup, the schedule is
+// wave-uniform -- the workgroup meets at a barrier, thread j computes the matrix of slot j of the next
+// segment, and a second barrier releases the walk.  12 KB of LDS whatever the tree size.
+constexpr int kSegOps = 48;
+
+struct SegCtx {
+  const double* e;       // the sample's eigen-decomposition (36 doubles)
+  const double* bl;      // its branch lengths
+  double rt;             // the rate of this workgroup
+  double* tab;           // LDS: [2 * kSegOps][4][4] slots
+  int rtid, nthr;        // this thread's number among the threads that fill the table, and their count
+};
+
+// Fill the slots of segment [k0, k0 + kSegOps): thread j takes slot j (P = I + U expm1(lambda t r) U^-1 of the
+// tip's branch, stored column by column as the walk gathers it).
+__device__ __forceinline__ void seg_fill(const SegCtx& c, const int4* __restrict__ op_ptr, int n_ops, int k0) {
+  for (int j = c.rtid; j < 2 * kSegOps; j += c.nthr) {
+    const int k = k0 + (j >> 1);
+    if (k >= n_ops) continue;
+    const int4 op = op_ptr[k];
+    const int kind = op.x & 15;
+    int tip = -1;
+    if (kind == OP_CHERRY) tip = (j & 1) ? op.z : op.y;
+    if (kind == OP_TIP_ACC && !(j & 1)) tip = op.y;
+    if (tip < 0) continue;
+    double P[4][4];
+    compute_pmatrix(c.e, c.bl[tip] * c.rt, P);
+    double* o = c.tab + j * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
+  }
+}
+
 // The schedule walk of one wave: S sites per lane (site0 + 64*s), all lanes active (sites past the end
 // of the tile are clamped to a valid one and not written back).
-template <int kDepth, int S, bool kN>
+// tiptab: the tip table ([T][4][4], or the segment slots when kSeg); naive_tab: the naive tip's entry.
+template <int kDepth, int S, bool kN, bool kSeg = false>
 __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_t* __restrict__ msa, int L,
                                            int n_ops, const int4* __restrict__ op_ptr,
-                                           pmat_ptr pm, const double* tiptab,
-                                           const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
+                                           pmat_ptr pm, const double* tiptab, const double* naive_tab,
+                                           const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S],
+                                           const SegCtx& seg) {
   unsigned usite[S];  // MSA byte offsets are 32-bit: (tip row) * L + site
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -155,9 +195,20 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
       if (kd == OP_CHERRY) sb[s] = msa[(unsigned)((op.z - 1) * L) + usite[s]];
     }
   }
+  int seg_k0 = 0;  // first op of the segment whose tip matrices are in the table (kSeg)
   for (int k = 0; k < n_ops; ++k) {
     const int4 op_next = op_ptr[k + 1 < n_ops ? k + 1 : k];
     const int kind = op.x & 15;
+    if constexpr (kSeg) {
+      if (k - seg_k0 == kSegOps) {  // every wave of the workgroup arrives here at the same op
+        __syncthreads();            // nobody reads the old segment any more
+        seg_k0 = k;
+        seg_fill(seg, op_ptr, n_ops, k);
+        __syncthreads();
+      }
+    }
+    // table rows of the op's tip children
+    const int row_y = kSeg ? 2 * (k - seg_k0) : op.y, row_z = kSeg ? 2 * (k - seg_k0) + 1 : op.z;
     if (op.x & OP_PUSH_FLAG) {
       const unsigned push_mask = __builtin_amdgcn_readfirstlane(1u << op.w);
       LH_PUSH_IF(0) LH_PUSH_IF(1) LH_PUSH_IF(2) LH_PUSH_IF(3)
@@ -177,8 +228,8 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
     if (kind == OP_CHERRY) {
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        tip_column<kN>(tiptab, op.y, sa[s], u[s]);
-        tip_column<kN>(tiptab, op.z, sb[s], v[s]);
+        tip_column<kN>(tiptab, row_y, sa[s], u[s]);
+        tip_column<kN>(tiptab, row_z, sb[s], v[s]);
       }
     } else {
       const pmat_ptr pb = pm + (size_t)k * 32;
@@ -187,7 +238,7 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
       if (kind == OP_TIP_ACC) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          tip_column<kN>(tiptab, op.y, sa[s], u[s]);
+          tip_column<kN>(tiptab, row_y, sa[s], u[s]);
         }
       } else {  // OP_POP_ACC
         const pmat_ptr pa = pm + (size_t)k * 32 + 16;
@@ -269,10 +320,10 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
       double tv[4];  // tip 0 = naive; its possible states are the five naive bases of the xMSA
       if (b < 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) tv[i] = tiptab[b * 4 + i];
+        for (int i = 0; i < 4; ++i) tv[i] = naive_tab[b * 4 + i];
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) tv[i] = ((tiptab[i] + tiptab[4 + i]) + tiptab[8 + i]) + tiptab[12 + i];
+        for (int i = 0; i < 4; ++i) tv[i] = ((naive_tab[i] + naive_tab[4 + i]) + naive_tab[8 + i]) + naive_tab[12 + i];
       }
       lik[s][b] = fma(w3, tv[3], fma(w2, tv[2], fma(w1, tv[1], w0 * tv[0])));
     }
@@ -296,7 +347,7 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
 // site_lik[n][1][5][L] then holds the rate mixture (equal weights, scalers aligned to the smallest, the
 // arithmetic K2a would do) and K2a runs with a single "rate".  A quarter of the output traffic, and K2a's
 // bandwidth-bound assembly shrinks to a quarter.  Used when R * wpr <= 8 waves and the R tip tables fit.
-template <int kDepth, bool kTwo, bool kN, bool kFused, bool kTipGlobal = false>
+template <int kDepth, bool kTwo, bool kN, bool kFused, bool kSeg = false>
 __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, const uint8_t* __restrict__ msa, int L,
                                            int T, int n_ops, const int32_t* __restrict__ ops,
                                            const double* __restrict__ brlen, const double* __restrict__ rates,
@@ -311,13 +362,13 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
   const int nthr = kFused ? wpr * 64 : (int)blockDim.x;       // threads working on this rate
   const int rtid = kFused ? tid - rate * nthr : tid;
   const int sample = blockIdx.z;
-  // scratch area of one (sample, rate): the schedule's P-matrices, followed -- for large trees only, whose
-  // tip table (128 B per tip) would leave room for just one or two workgroups in a CU's LDS -- by the tip
-  // table, which the walk then reads through the vector cache instead
-  const size_t pm_stride = (size_t)(T - 2) * 32 + (kTipGlobal ? (size_t)T * 16 : 0);
+  // scratch area of one (sample, rate): the schedule's P-matrices
+  const size_t pm_stride = (size_t)(T - 2) * 32;
   const size_t pm_off = ((size_t)sample * R + rate) * pm_stride;
-  double* tiptab = kTipGlobal ? pmat_w + pm_off + (size_t)(T - 2) * 32
-                              : reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);  // [T][4][4]
+  // LDS tip table [T][4][4] (per rate when fused); large trees (kSeg): the segment slots [2 kSegOps][4][4]
+  // followed by the naive tip's entry
+  double* tiptab = reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);
+  const double* naive_tab = kSeg ? tiptab + 2 * kSegOps * 16 : tiptab;
   const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
 
   // Prologue (formerly a kernel of its own): the P-matrices of this (sample, rate).
@@ -360,9 +411,10 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
     }
     if (do_tips) {
       const int stride = half ? nthr - half : nthr;
-      for (int j = half ? rtid - half : rtid; j < T; j += stride) {
+      // (kSeg: only the naive tip here; the other tips' matrices are made a segment at a time, below)
+      for (int j = half ? rtid - half : rtid; j < (kSeg ? 1 : T); j += stride) {
         compute_pmatrix(e, bl[j] * rt, P);
-        double* o = tiptab + j * 16;
+        double* o = kSeg ? tiptab + 2 * kSegOps * 16 : tiptab + j * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -370,6 +422,9 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
       }
     }
   }
+  SegCtx seg{eig + (size_t)sample * 36, brlen + (size_t)sample * (2 * (size_t)T - 2),
+             rates[(size_t)sample * R + rate], tiptab, rtid, nthr};
+  if constexpr (kSeg) seg_fill(seg, op_ptr, n_ops, 0);
   // every storing wave's stores have reached L2 (which is where the scalar cache fills from) before any
   // wave passes the barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -391,13 +446,14 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
   if (two_sites) {
     site0 = tile0 + wave * 128 + lane;
     n_own = 2;
-    if constexpr (kTwo) prune_wave<kDepth, 2, kN>(site0, site_end, msa, L, n_ops, op_ptr, pm, tiptab, p4, lik, scl);
+    if constexpr (kTwo)
+      prune_wave<kDepth, 2, kN, kSeg>(site0, site_end, msa, L, n_ops, op_ptr, pm, tiptab, naive_tab, p4, lik, scl, seg);
   } else {
     site0 = tile0 + n2 * 128 + (wave - n2) * 64 + lane;
     n_own = 1;
     double lik1[1][5];
     int scl1[1];
-    prune_wave<kDepth, 1, kN>(site0, site_end, msa, L, n_ops, op_ptr, pm, tiptab, p4, lik1, scl1);
+    prune_wave<kDepth, 1, kN, kSeg>(site0, site_end, msa, L, n_ops, op_ptr, pm, tiptab, naive_tab, p4, lik1, scl1, seg);
 #pragma unroll
     for (int b = 0; b < 5; ++b) lik[0][b] = lik1[0][b];
     scl[0] = scl1[0];
@@ -480,9 +536,14 @@ LH_PRUNE_KERNEL(prune_kernel_w5, 5)
 LH_PRUNE_KERNEL(prune_kernel_w4, 4)
 #undef LH_PRUNE_KERNEL
 
-// Large trees: tip table in the scratch area instead of LDS (see prune_body), five waves per SIMD.
+// Large trees: tip table built a schedule segment at a time (see SegCtx); register budgets for five and four
+// waves per SIMD.
 template <int kDepth, bool kN>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) prune_kernel_tg(LH_PRUNE_PARAMS) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) prune_kernel_seg(LH_PRUNE_PARAMS) {
+  prune_body<kDepth, true, kN, false, true>(LH_PRUNE_ARGS);
+}
+template <int kDepth, bool kN>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) prune_kernel_seg4(LH_PRUNE_PARAMS) {
   prune_body<kDepth, true, kN, false, true>(LH_PRUNE_ARGS);
 }
 
@@ -528,10 +589,12 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   // as the exchange area [R][5][pad] doubles + [R][pad] ints) within a third of a CU's LDS
   const size_t pad = (size_t)n2 * 128 + (size_t)n1 * 64;
   const size_t fused_lds = std::max((size_t)R * tip_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
-  const bool fused = allow_fused && two && R * wpr <= 8 && fused_lds <= 53 * 1024;
-  // large trees: with the tip table in LDS fewer than three waves per SIMD would be resident
-  const bool tip_global = two && !fused && (160 * 1024 / tip_bytes) * wpr / 4 < 3;
-  const size_t lds = fused ? fused_lds : tip_global ? 0 : tip_bytes;
+  static const bool seg_env = getenv("LH_K1_SEGMENTS") != nullptr;  // test hook: segments on small trees too
+  static const int seg_waves = getenv("LH_K1_SEG_WAVES") ? atoi(getenv("LH_K1_SEG_WAVES")) : 4;  // measured: 4 (128 VGPRs, few spills) beats 5 by 9 %
+  const bool fused = allow_fused && two && R * wpr <= 8 && fused_lds <= 53 * 1024 && !seg_env;
+  // large trees: with the whole tip table in LDS fewer than five waves per SIMD would be resident
+  const bool seg = two && !fused && ((160 * 1024 / tip_bytes) * wpr / 4 < 5 || seg_env);
+  const size_t lds = fused ? fused_lds : seg ? (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) : tip_bytes;
   const int wg_waves = fused ? R * wpr : wpr;
   dim3 grid(tiles, fused ? 1 : R, n), block(64 * wg_waves);
   const int n_ops = T - 2;
@@ -559,8 +622,10 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   {                                         \
     if (fused)                              \
       LH_LAUNCH_BUDGET(D, N, true)          \
-    else if (tip_global)                    \
-      LH_LAUNCH_K((prune_kernel_tg<D, N>))  \
+    else if (seg && seg_waves == 4)         \
+      LH_LAUNCH_K((prune_kernel_seg4<D, N>)) \
+    else if (seg)                           \
+      LH_LAUNCH_K((prune_kernel_seg<D, N>)) \
     else                                    \
       LH_LAUNCH_BUDGET(D, N, false)         \
   }

@@ -255,6 +255,17 @@ def test_large_tree_family(hip, tmp_path):
     compare(h, desc, ll, res, ref)
 
 
+def test_mid_tree_family(hip, tmp_path):
+    """120 leaves on the small germline set: 118 schedule ops (three segments when K1 runs its large-tree form)."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_leaves=120, n_samples=3, seed=12), out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    desc, ll, res, ref = run_family(hip, h, rows, 4)
+    compare(h, desc, ll, res, ref)
+
+
 def test_minimal_tree_and_rate_counts(hip, data_dir, tmp_path):
     """Edge shapes: the smallest tree the path accepts (naive + two sequences: one cherry op, no stack), a
     single evaluation per call, and R = 1, 2, 8 rate categories."""
@@ -289,6 +300,23 @@ def test_several_site_tiles_per_sample(tmp_path):
     env = dict(os.environ, LH_K1_TILE_CAP="192")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("env", [{"LH_K1_SEGMENTS": "1"}, {"LH_K1_SEG_WAVES": "5"},
+                                 {"LH_K1_SEGMENTS": "1", "LH_K1_TILE_CAP": "128"}])
+def test_segmented_tip_table(tmp_path, env):
+    """K1's large-tree form (tip matrices built a schedule segment at a time, lh_prune.hip SegCtx): the 500-leaf
+    family runs it by default (11 segments; also with the five-waves register budget and with several site tiles),
+    and LH_K1_SEGMENTS forces it onto the 120-leaf family of test_mid_tree_family as well."""
+    import subprocess
+    import sys
+    code = ("import pathlib, linearham_amd, tests.test_gpu_parity as t; lib = linearham_amd.load_library(); "
+            "t.test_large_tree_family(lib, pathlib.Path(%r)); "
+            "t.test_mid_tree_family(lib, pathlib.Path(%r))" % (str(tmp_path / "a"), str(tmp_path / "b")))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **env), capture_output=True,
+                       text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 

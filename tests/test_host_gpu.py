@@ -255,3 +255,53 @@ def test_full_size_family_properties(tmp_path):
     ref = fam.eval([trees[i] for i in idx], [rows_tsv[i]["er"] for i in idx], [rows_tsv[i]["pi"] for i in idx],
                    [rows_tsv[i]["alpha"] for i in idx], n_threads=3)
     np.testing.assert_allclose(ll[idx], ref, rtol=1e-10)
+
+
+def test_config4_full_size_family(tmp_path):
+    """BASELINE.json configs[4] at its stated size: 500 leaves x 600 sites with the FULL germline set (200 V /
+    30 D / 12 J alleles), through the C++ host and the C ABI.  Layout properties on a whole batch (identical
+    rows give identical bits wherever they sit; a second call repeats bit for bit), every distinct row against
+    the dense C oracle to 1e-10 -- and, on the tree samples where the reference's own 2^(256 d) equalisation
+    overflows (src/PhyloHMM.cpp:190-192), the same non-finite mask on both sides."""
+    import ctypes as C
+    import linearham_amd
+    from linearham_amd import host as hst
+    from oracle import oracle_c
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec(n_leaves=500, n_sites=600, n_samples=64), out)
+    hmm = hst.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    sizes = hmm.sizes()
+    assert sizes["n_tips"] == 501 and sizes["n_sites"] == 600
+    n = 704                                     # 11 copies of each row
+    flat = hmm.flatten_tsv(os.path.join(out, "trees.tsv"), n)
+    lib = linearham_amd.load_library()
+    T, depth, rows = flat["n_tips"], flat["max_depth"], flat["n_rows"]
+    assert rows == 64 and depth <= 16
+
+    def run():
+        ll = np.zeros(n)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        lib.check(lib.lib.lh_eval_batch(C.c_void_p(flat["family"]), n, T, depth, p(flat["ops"], C.c_int32),
+                                        p(flat["brlen"], C.c_double), p(flat["er"], C.c_double),
+                                        p(flat["pi"], C.c_double), p(flat["alpha"], C.c_double), 4,
+                                        p(ll, C.c_double), None))
+        return ll
+    ll = run()
+    for r in range(rows):
+        assert len(set(np.nan_to_num(ll[r::rows], nan=1.0, posinf=2.0, neginf=3.0).tolist())) == 1, r
+    assert np.array_equal(ll, run(), equal_nan=True)
+    # every distinct row against the dense reference algorithm (C oracle)
+    rows_tsv = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    o = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    labels = list(o.xmsa_labels)
+    trees = [hst.newick_arrays(rows_tsv[r]["tree"], labels) for r in range(rows)]
+    oracle_c.build()
+    fam = oracle_c.COracleFamily(o, 4)
+    ref = fam.eval(trees, [r["er"] for r in rows_tsv], [r["pi"] for r in rows_tsv], [r["alpha"] for r in rows_tsv],
+                   n_threads=min(16, len(os.sched_getaffinity(0))))
+    got = ll[:rows]
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin)               # the reference's overflow rows, and only those
+    assert fin.sum() >= rows - 8                                # ... are a small minority
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-10)

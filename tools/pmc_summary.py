@@ -40,10 +40,15 @@ def main():
     ap.add_argument("--filter", default="")
     ap.add_argument("--json")
     ap.add_argument("--note", default="")
+    ap.add_argument("--evals-per-launch", type=int, default=None,
+                    help="evaluations per launch group of the profiled command (bench.py matches it before it "
+                         "quotes these counters per launch)")
     args = ap.parse_args()
     res = collect(args.dirs, args.filter)
     if args.json:
         out = {"_note": args.note}
+        if args.evals_per_launch is not None:
+            out["_evals_per_launch"] = args.evals_per_launch
         out.update(res)
         with open(args.json, "w") as f:
             json.dump(out, f, indent=1)
