@@ -129,6 +129,19 @@ int lh_family_info(const lh_family* fam, int32_t* n_patterns, int32_t* n_unique_
  * turns the form off. */
 int lh_family_consensus_sets(const lh_family* fam);
 
+/* Opt-in extended-range mode (default off = the reference's arithmetic, overflows included).  The reference
+ * loses a tree sample in two places: exp(lnL - log pi) underflows to 0 when a column's likelihood is below
+ * 1e-308 (src/PhyloHMM.cpp:237), and the 2^(256 d) equalisation of a region's emission products to the LARGEST
+ * ScaleMatrix count overflows to inf when two alleles' counts differ by 4 or more (src/PhyloHMM.cpp:190-192;
+ * acknowledged at scripts/run_bootstrap_asr_ess.R:37-39).  With the mode on, emissions are carried as
+ * (value, 2^-256 count) pairs into the products and the junction rows, a region is equalised to its SMALLEST
+ * count (negligible alleles underflow to 0 instead of likely ones overflowing), and a forward row is rescaled
+ * by its largest entry instead of its smallest positive one.  Every such step is an exact power-of-two
+ * rescaling, so the log-likelihood equals the default mode's wherever that is finite (tests: 1e-10) and stays
+ * finite where the reference returns inf / NaN; the forward arrays and scaler counts of lh_eval_outputs are
+ * then in this mode's scaling (value x 2^(-256 count) is what agrees), which is the documented divergence. */
+int lh_family_set_extended_range(lh_family* fam, int enable);
+
 /* Tree in rooted-at-naive form: tips are nodes 0..T-1 (0 = `naive`, i = MSA row i-1), inner nodes
  * T..2T-3.  children[2*(v-T)+{0,1}] are the two children of inner node v when the tree is rooted at
  * `root`, the inner node adjacent to `naive`.  Writes the kernel's post-order schedule:

@@ -43,7 +43,7 @@ class _EvalOutputs(C.Structure):
 EXPORTS = ["lh_last_error", "lh_device_count", "lh_family_create", "lh_family_destroy",
            "lh_forward_size", "lh_scaler_size", "lh_family_info", "lh_family_consensus_sets", "lh_schedule_tree", "lh_eval_batch",
            "lh_eval_batch_device", "lh_forward_batch", "lh_asr_batch", "lh_asr_batch_device",
-           "lh_profile_enable", "lh_profile_read", "lh_asr_profile_read"]
+           "lh_profile_enable", "lh_profile_read", "lh_asr_profile_read", "lh_family_set_extended_range"]
 
 
 def library_path():
@@ -84,6 +84,7 @@ class HipLibrary:
                                             C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.lh_asr_profile_read.argtypes = [C.c_void_p, c_f64p, C.POINTER(C.c_int64)]
         lib.lh_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        lib.lh_family_set_extended_range.argtypes = [C.c_void_p, C.c_int]
         lib.lh_profile_read.argtypes = [C.c_void_p, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_int64)]
 
     def error(self):
@@ -284,6 +285,9 @@ class Family:
             er.ctypes.data_as(c_f64p), pi.ctypes.data_as(c_f64p), rates.ctypes.data_as(c_f64p), rates.shape[1],
             naive.ctypes.data_as(c_u8p), seed, first_sample, anc.ctypes.data_as(c_u8p), choice.ctypes.data_as(c_u8p)))
         return anc, choice
+
+    def set_extended_range(self, on=True):
+        self.hip.check(self.hip.lib.lh_family_set_extended_range(self.handle, int(on)))
 
     def profile_enable(self, on=True):
         self.hip.check(self.hip.lib.lh_profile_enable(self.handle, int(on)))

@@ -581,4 +581,9 @@ void StoreXmsaIndex(std::pair<int, int> id, std::map<std::pair<int, int>, int>& 
   xmsa_ind = res.first->second;
 }
 
+void PhyloHMM::SetExtendedRange(bool on) {
+  // takes effect with the next InitializePhyloEmission / RunPipeline
+  if (lh_family_set_extended_range(family(), on ? 1 : 0)) throw std::runtime_error(lh_last_error());
+}
+
 }  // namespace linearham

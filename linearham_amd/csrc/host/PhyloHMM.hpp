@@ -116,6 +116,9 @@ class PhyloHMM : public HMM {
     CreateFamily();
     return family_;
   }
+  /// Opt-in extended-range arithmetic of the device path (lh_family_set_extended_range): finite log-likelihoods
+  /// where the reference's equalisation overflows or its exp underflows; off by default.
+  void SetExtendedRange(bool on);
   int n_xmsa() const { return xmsa_.cols(); }
 };
 

@@ -215,6 +215,9 @@ int lhh_phylo_init_parameters_str(void* h, const char* newick, const double* er,
 int lhh_phylo_init_emission(void* h) {
   return Guard([&] { dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h)).InitializePhyloEmission(); });
 }
+int lhh_phylo_set_extended_range(void* h, int on) {
+  return Guard([&] { dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h)).SetExtendedRange(on != 0); });
+}
 int lhh_loglikelihood(void* h, double* out) {
   return Guard([&] { *out = static_cast<HMM*>(h)->LogLikelihood(); });
 }

@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
     if (argc < 2 || std::string(argv[1]) == "-h" || std::string(argv[1]) == "--help") {
       std::cout << "A Phylo-HMM implementation for B cell receptor sequence analysis.\n"
                    "USAGE: linearham {--compute-logl|--sample|--pipeline|--asr} --yaml-path <string> --cluster-ind <int> "
-                   "--hmm-param-dir <string> [--seed <int>] [--num-rates <int>] ...\n";
+                   "--hmm-param-dir <string> [--seed <int>] [--num-rates <int>] [--extended-range <0|1>] ...\n";
       return argc < 2 ? EXIT_FAILURE : EXIT_SUCCESS;
     }
     const std::string subcmd = argv[1];
@@ -66,6 +66,8 @@ int main(int argc, char** argv) {
     const int num_rates = std::stoi(a.opt("num-rates", "1"));
     linearham::PhyloHMMPtr phylo_hmm_ptr =
         std::make_shared<linearham::PhyloHMM>(yaml_path, cluster_ind, hmm_param_dir, seed);
+    // not in the reference: finite log-likelihoods where its scaling over/underflows (include/linearham_amd.h)
+    if (std::stoi(a.opt("extended-range", "0")) != 0) phylo_hmm_ptr->SetExtendedRange(true);
     if (subcmd == "--pipeline") {
       phylo_hmm_ptr->RunPipeline(a.one("input-path"), a.one("output-path"), num_rates);
       return EXIT_SUCCESS;

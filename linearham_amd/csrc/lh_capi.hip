@@ -36,7 +36,7 @@ struct Workspace {
 struct ForwardWs {  // K2a -> K2b hand-off, sized by the largest batch seen
   int n_cap = 0;
   double *gem = nullptr, *jem = nullptr;
-  int32_t* gcnt = nullptr;
+  int32_t *gcnt = nullptr, *jrs = nullptr;
 };
 
 struct AsrWs {  // K3's CLV area and the device copies of lh_asr_batch's host arrays (grow-only)
@@ -85,6 +85,7 @@ struct lh_family {
   Staging st;
   HostPipe pipe;
   bool profile = false;
+  bool extended = false;  // lh_family_set_extended_range
   std::vector<EventSet> events;
   double ms[3] = {0, 0, 0};
   int64_t launches = 0;
@@ -280,7 +281,7 @@ int upload_vec(lh_family* f, const std::vector<T>& v, const T** out) {
 // `remap` translates xMSA column indices into positions of the compact junction-column list; -1 (the
 // state does not emit at this site) and padding become the zero sentinel at position n_jcols.
 int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_t>& remap, int n_jcols,
-                    lh::DevJunction* d) {
+                    const int32_t* xmsa_site, const std::vector<int32_t>& pat_of_site, lh::DevJunction* d) {
   const size_t W = j.n_rows, nL = j.n_left, nR = j.n_right;
   const size_t pL = (nL + 63) / 64 * 64, pR = (nR + 63) / 64 * 64;
   d->n_rows = j.n_rows;
@@ -316,6 +317,11 @@ int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_
   if (upload_vec(f, pad_genes<double>(j.exit_nlo, 1, nR, pR, 4, 0.0), &d->exit_nlo)) return 1;
   if (upload_vec(f, pad_genes<double>(j.exit_trans, 1, nR, pR, 1, 0.0), &d->exit_trans)) return 1;
   if (upload_vec(f, pad_genes<double>(j.exit_gp_li, 1, nR, pR, 1, 0.0), &d->exit_gp_li)) return 1;
+  // pattern of each row's alignment site, through the NTI emission column of the row (always present)
+  std::vector<int32_t> row_pat(W, f->host.n_prune);
+  if (xmsa_site)
+    for (size_t i = 0; i < W; ++i) row_pat[i] = pat_of_site[xmsa_site[j.nti_xmsa[i * nR * 4]]];
+  if (upload_vec(f, row_pat, &d->row_pat)) return 1;
   return 0;
 }
 
@@ -371,19 +377,20 @@ int run_forward(lh_family* f, int n, int R, const double* site_lik, const int32_
   if (n > w.n_cap) {
     // growing the hand-off buffers: earlier launches on other streams may still be using them
     LH_HIP(hipDeviceSynchronize());
-    void** bufs[] = {(void**)&w.gem, (void**)&w.jem, (void**)&w.gcnt};
+    void** bufs[] = {(void**)&w.gem, (void**)&w.jem, (void**)&w.gcnt, (void**)&w.jrs};
     for (void** b : bufs) {
       if (*b) LH_HIP(hipFree(*b));
       *b = nullptr;
     }
     w.n_cap = 0;
+    LH_HIP(hipMalloc((void**)&w.jrs, sizeof(int32_t) * (size_t)n * std::max(f->host.vd.n_rows + f->host.dj.n_rows, 1)));
     LH_HIP(hipMalloc((void**)&w.gem, sizeof(double) * (size_t)n * std::max<int64_t>(f->host.gem_size, 1)));
     LH_HIP(hipMalloc((void**)&w.jem, sizeof(double) * (size_t)n * std::max(f->host.n_jcols, 1)));
     LH_HIP(hipMalloc((void**)&w.gcnt, sizeof(int32_t) * (size_t)n * 3));
     w.n_cap = n;
   }
-  lh::launch_forward(f->host, n, R, site_lik, site_scal, pi, em_in, em_out, w.gem, w.gcnt, w.jem, loglik_dev, fwd,
-                     sco, stream);
+  lh::launch_forward(f->host, n, R, site_lik, site_scal, pi, em_in, em_out, w.gem, w.gcnt, w.jem, w.jrs, loglik_dev,
+                     fwd, sco, f->extended, stream);
   LH_HIP(hipGetLastError());
   return 0;
 }
@@ -423,6 +430,7 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
   int rc = 0;
   const size_t C = desc->n_xmsa;
   std::vector<int32_t> ucol(C);  // caller's column -> u-column
+  std::vector<int32_t> pat_of_site_all;  // alignment site -> K1 pattern (families with an alignment)
   if (desc->n_seqs > 0) {
     if (!desc->msa || !desc->xmsa_site || !desc->xmsa_naive_base) rc = fail("lh_family_create: null array in descriptor");
     const size_t N = desc->n_seqs, L = desc->n_sites;
@@ -488,6 +496,7 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
         if (col_of_ucol[ucol[c]] < 0) col_of_ucol[ucol[c]] = (int32_t)c;
       }
       h.n_ucol = (int32_t)u_pat.size();
+      pat_of_site_all = pat_of_site;
       rc = rc || upload(f, pmsa.data(), pmsa.size(), &h.msa);
       rc = rc || upload(f, pat_of_site.data(), pat_of_site.size(), &h.site_pat);
       rc = rc || upload(f, u_pat.data(), u_pat.size(), &h.u_pat);
@@ -538,11 +547,11 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
     h.n_jcols = (int32_t)jcols.size();
     rc = upload(f, jcols.data(), jcols.size(), &h.jcols);
   }
-  rc = rc || upload_junction(f, desc->vd, remap, h.n_jcols, &h.vd);
+  rc = rc || upload_junction(f, desc->vd, remap, h.n_jcols, seg_site, pat_of_site_all, &h.vd);
   if (!rc && desc->vd.n_left != (int)nV) rc = fail("lh_family_create: vd.n_left != number of V genes");
   if (h.has_d) {
     rc = rc || upload_segments(f, desc->dgerm, desc->n_xmsa, ucol, h.n_ucol, seg_site, &h.dgerm);
-    rc = rc || upload_junction(f, desc->dj, remap, h.n_jcols, &h.dj);
+    rc = rc || upload_junction(f, desc->dj, remap, h.n_jcols, seg_site, pat_of_site_all, &h.dj);
     if (!rc && (desc->vd.n_right != desc->dgerm.n_genes || desc->dj.n_left != desc->dgerm.n_genes ||
                 desc->dj.n_right != (int)nJ))
       rc = fail("lh_family_create: junction gene counts do not match the germline regions");
@@ -590,7 +599,7 @@ void lh_family_destroy(lh_family* f) {
   if (!f) return;
   for (void* p : f->allocs) (void)hipFree(p);
   Workspace& w = f->ws;
-  void* bufs[] = {w.rates, w.eig, w.pmat, w.site_lik, w.site_scal, f->fws.gem, f->fws.jem, f->fws.gcnt};
+  void* bufs[] = {w.rates, w.eig, w.pmat, w.site_lik, w.site_scal, f->fws.gem, f->fws.jem, f->fws.gcnt, f->fws.jrs};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* p : f->st.ptr)
@@ -739,6 +748,12 @@ int lh_schedule_tree(int32_t T, const int32_t* children, int32_t root, int32_t* 
   if (n_out != I || depth != 0) return fail("lh_schedule_tree: internal scheduling error");
   if (maxd > 16) return fail("lh_schedule_tree: tree needs more than 16 stack slots");
   if (max_depth) *max_depth = maxd;
+  return 0;
+}
+
+int lh_family_set_extended_range(lh_family* f, int enable) {
+  if (!f) return fail("null family");
+  f->extended = enable != 0;
   return 0;
 }
 

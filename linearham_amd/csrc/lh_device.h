@@ -53,6 +53,8 @@ struct DevJunction {
   const int32_t *nti_xmsa;      // [n_rows][right_pad][4]
   const double *exit_nlo;       // [right_pad][4]
   const double *exit_trans, *exit_gp_li;  // [right_pad]
+  const int32_t* row_pat;       // [n_rows] K1 pattern of the row's alignment site (>= n_prune: the all-N pattern
+                                // or a family without an alignment); used by the extended-range mode only
 };
 
 // Two reductions happen once per family, on the host (lh_family_create):
@@ -144,9 +146,12 @@ size_t asr_slots(int L, int R);  // slots per sample in K3's CLV area: clv[n][T-
 // em_in[n][C].  K2a leaves the germline/padding emission products in gem[n][gem_size], their scaler
 // counts in gcnt[n][3] and the junction columns' emissions in jem[n][n_jcols]; K2b runs the scaled
 // forward sweep over them -> loglik[n] (+ optional forward rows and scaler counts).
+// extended: the opt-in extended-range mode (include/linearham_amd.h, lh_family_set_extended_range); jrs[n][rows
+// of both junctions] is then the K2a -> K2b hand-off of the junction rows' emission scaler counts.
 void launch_forward(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
                     const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt, double* jem,
-                    double* loglik, double* forward_out, int32_t* scaler_out, hipStream_t stream);
+                    int32_t* jrs, double* loglik, double* forward_out, int32_t* scaler_out, bool extended,
+                    hipStream_t stream);
 size_t forward_lds_bytes(const DevFamily& fam);
 
 }  // namespace lh

@@ -50,6 +50,10 @@ __device__ static inline int block_max_int(int v, int* red, int phase) {
   return max(max(r[0], r[1]), max(r[2], r[3]));
 }
 
+__device__ static inline int block_min_int(int v, int* red, int phase) {
+  return -block_max_int(-v, red, phase);
+}
+
 __device__ static inline double pow_scale(int d) {  // std::pow(SCALE_FACTOR, d), src/PhyloHMM.cpp:191
   return d <= 0 ? 1.0 : d == 1 ? 0x1p256 : d == 2 ? 0x1p512 : d == 3 ? 0x1p768 : __builtin_inf();
 }
@@ -135,6 +139,60 @@ __device__ static int fill_segments(const DevSegments& seg, const double* em, in
     if (g < n) out[g] = v[q] * pow_scale(mx - c[q]);
   }
   return mx;
+}
+
+// Extended-range mode (lh_family_set_extended_range): every factor is a pair (em[x], ems[x]) = value and
+// 2^-256 count of the column's emission; the running product carries the counts along, and the region is
+// equalised to its SMALLEST count -- alleles more than 2^-1024 below the best one underflow to 0 -- instead of
+// to the largest as the reference does (where the likely alleles overflow to inf, src/PhyloHMM.cpp:190-192).
+template <int kG, bool kByteOff>
+__device__ static int fill_segments_ext(const DevSegments& seg, const double* em, const int* ems, int tid,
+                                        double* __restrict__ out, int* redi, int phase) {
+  double v[kG];
+  int c[kG];
+  const int n = seg.n_genes;
+#pragma unroll
+  for (int q = 0; q < kG; ++q) {
+    v[q] = 1.0;
+    c[q] = 0;
+    const int g = tid + kFwdThreads * q;
+    if (g >= n) continue;
+    const uint4* chunk = seg.inds_c + g;
+    double x = 1.0;
+    int k = 0;
+    for (int j = 0; j < seg.n_chunks; ++j) {
+      const uint4 w = chunk[(size_t)j * n];
+      const unsigned packed[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned idx = ((packed[u >> 1] >> (16 * (u & 1))) & 0xffffu) >> (kByteOff ? 3 : 0);
+        x *= em[idx];
+        k += ems[idx];
+        while (x > 0.0 && x < kScaleThreshold) {
+          x *= kScaleFactor;
+          ++k;
+        }
+      }
+    }
+    v[q] = x;
+    c[q] = k;
+  }
+  int local_min = 0x3fffffff;
+#pragma unroll
+  for (int q = 0; q < kG; ++q)
+    if (tid + kFwdThreads * q < n && v[q] > 0.0) local_min = min(local_min, c[q]);
+  int mn = block_min_int(local_min, redi, phase);
+  if (mn == 0x3fffffff) mn = 0;  // every product is zero (or the set is empty)
+#pragma unroll
+  for (int q = 0; q < kG; ++q) {
+    const int g = tid + kFwdThreads * q;
+    if (g < n) {
+      double x = v[q];
+      for (int d = c[q] - mn; d > 0 && x != 0.0; --d) x *= kScaleThreshold;
+      out[g] = x;
+    }
+  }
+  return mn;
 }
 
 // capacity of the consensus form's LDS arrays: the largest set's sites + 2 (the prefix past the last site and
@@ -297,12 +355,12 @@ __device__ static int fill_consensus(const DevSegments& seg, const double* em, i
   return mx;
 }
 
-template <int kG, bool kFromSiteLik, bool kByteOff>
+template <int kG, bool kFromSiteLik, bool kByteOff, bool kExt = false>
 __global__ void __launch_bounds__(kFwdThreads)
     emission_kernel(const DevFamily fam, int R, const double* __restrict__ site_lik,
                     const int32_t* __restrict__ site_scal, const double* __restrict__ pi,
                     const double* __restrict__ em_in, double* __restrict__ em_out, double* __restrict__ gem_all,
-                    int32_t* __restrict__ gcnt_all, double* __restrict__ jem_all) {
+                    int32_t* __restrict__ gcnt_all, double* __restrict__ jem_all, int32_t* __restrict__ jrs_all) {
   extern __shared__ double em[];  // [C + 1] emissions (em[C] = 1.0 sentinel) | reduction scratch
   const size_t s = blockIdx.x;
   const int tid = threadIdx.x;
@@ -313,6 +371,7 @@ __global__ void __launch_bounds__(kFwdThreads)
   double* cons_inv = reinterpret_cast<double*>(redi + 2 * kFwdWaves + 2);  // [cap]
   double* cons_pv = cons_inv + cons_cap;                                    // [cap + 4]
   int* cons_pk = reinterpret_cast<int*>(cons_pv + cons_cap + 4);            // [cap + 4]
+  int* ems = cons_pk + (cons_cap ? cons_cap + 4 : 0);                       // [C + 1] (kExt only): 2^-256 counts
   if (tid == 0) *em_bad = 0;
   __syncthreads();
   bool my_bad = false;
@@ -345,16 +404,28 @@ __global__ void __launch_bounds__(kFwdThreads)
       // per column): site_lik / pi_b scaled down by 2^(256*smin), which also underflows to 0 like exp().
       double e = acc;
       if (b != 4) e /= pi[s * 4 + b];
-      for (int q = 0; q < smin && e != 0.0; ++q) e *= kScaleThreshold;
+      if constexpr (kExt) {
+        ems[u] = smin;  // the emission is e * 2^(-256 smin); the count travels beside the value
+      } else {
+        for (int q = 0; q < smin && e != 0.0; ++q) e *= kScaleThreshold;
+      }
       em[u] = e;
       my_bad |= !(e >= 0x1p-1000 && e <= 1.0 + 1e-9);
+    }
+    if constexpr (kExt) {  // the all-N pattern's columns (skipped above) carry no count
+      for (int u = tid; u < C; u += kFwdThreads)
+        if (fam.u_pat[u] >= NP) ems[u] = 0;
     }
   } else {
     for (int u = tid; u < C; u += kFwdThreads) {
       const double e = em_in[s * fam.n_xmsa + fam.col_of_ucol[u]];
       em[u] = e;
+      if constexpr (kExt) ems[u] = 0;
       my_bad |= !(e >= 0x1p-1000 && e <= 1.0 + 1e-9);
     }
+  }
+  if constexpr (kExt) {
+    if (tid == 0) ems[C] = 0;
   }
   // The consensus form of the germline products needs every emission in (0, 1] (see fill_consensus) and its
   // reciprocal finite; a sample with a zero or nearly subnormal emission (underflow), a NaN or an emission above 1
@@ -364,7 +435,12 @@ __global__ void __launch_bounds__(kFwdThreads)
   __syncthreads();
   if (em_out) {  // the caller's view: one value per xMSA column
     const int CX = fam.n_xmsa;
-    for (int c = tid; c < CX; c += kFwdThreads) em_out[s * CX + c] = em[fam.ucol_of_col[c]];
+    for (int c = tid; c < CX; c += kFwdThreads) {
+      double e = em[fam.ucol_of_col[c]];
+      if constexpr (kExt)  // PhyloHMM::xmsa_emission_ is the plain value (it may underflow; the path below does not use it)
+        for (int q = ems[fam.ucol_of_col[c]]; q > 0 && e != 0.0; --q) e *= kScaleThreshold;
+      em_out[s * CX + c] = e;
+    }
   }
 
   // emissions of the columns the junction rows touch, compacted for K2b
@@ -372,12 +448,28 @@ __global__ void __launch_bounds__(kFwdThreads)
     double* jem = jem_all + s * fam.n_jcols;
     for (int j = tid; j < fam.n_jcols; j += kFwdThreads) jem[j] = em[fam.jcols[j]];
   }
+  if constexpr (kExt) {
+    // ... and the 2^-256 count of each junction row: all columns of a row belong to one alignment site, whose
+    // count (the smallest over the rate categories, as above) depends on the site's pattern only
+    const int W1 = fam.vd.n_rows, W2 = fam.has_d ? fam.dj.n_rows : 0, NP = fam.n_prune;
+    int32_t* jrs = jrs_all + s * (size_t)(W1 + W2);
+    for (int r = tid; r < W1 + W2; r += kFwdThreads) {
+      const int pat = r < W1 ? fam.vd.row_pat[r] : fam.dj.row_pat[r - W1];
+      int smin = 0;
+      if (kFromSiteLik && pat < NP) {
+        smin = 0x7fffffff;
+        for (int q = 0; q < R; ++q) smin = min(smin, site_scal[(s * R + q) * NP + pat]);
+      }
+      jrs[r] = smin;
+    }
+  }
 
   // [vpadding nV | vgerm nV | dgerm nD | jgerm nJ | jpadding nJ]
   const int nV = fam.vgerm.n_genes, nD = fam.dgerm.n_genes, nJ = fam.jgerm.n_genes;
   double* gem = gem_all + s * fam.gem_size;
   const bool direct = *em_bad != 0;  // (written before the barrier that followed the emission assembly)
   auto fill = [&](const DevSegments& seg, double* out, int phase) {
+    if constexpr (kExt) return fill_segments_ext<kG, kByteOff>(seg, em, ems, tid, out, redi, phase);
     if (seg.cons_sites > 0 && !direct)
       return fill_consensus<kG, kByteOff>(seg, em, tid, out, redi, phase, cons_inv, cons_pv, cons_pk, cons_cap);
     return fill_segments<kG, kByteOff>(seg, em, tid, out, redi, phase);
@@ -455,6 +547,33 @@ __device__ static inline unsigned wave_min_key(unsigned v) {
   return min(min(a, b), min(c, d));
 }
 
+template <int kCtrl>
+__device__ static inline unsigned dpp_max_u32(unsigned v) {
+  return max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, 0xf, 0xf, true));
+}
+
+__device__ static inline unsigned wave_max_u32(unsigned v) {
+  v = dpp_max_u32<kDppQuadSwap1>(v);
+  v = dpp_max_u32<kDppQuadSwap2>(v);
+  v = dpp_max_u32<kDppHalfMirror>(v);
+  v = dpp_max_u32<kDppMirror>(v);
+  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, d));
+}
+
+// The entry that decides a vector's rescaling: its smallest positive one (ScaleMatrix, the reference) or, in the
+// extended-range mode, its largest -- the vector is then brought back above 2^-256 at its top, entries far
+// below it may underflow, and no entry can overflow.  Keys as scale_key (min) / plain high words (max).
+template <bool kExt>
+__device__ static inline unsigned key_start() {
+  return kExt ? 0u : 0xffffffffu;
+}
+template <bool kExt>
+__device__ static inline unsigned key_add(unsigned key, double v) {
+  return kExt ? max(key, (unsigned)__double2hiint(v)) : min(key, scale_key(v));
+}
+
 // ScaleMatrix on a wave-uniform basis: the reference multiplies the whole vector by 2^256 until its
 // smallest positive entry reaches 2^-256, i.e. k = #{j in 1..4 : minpos < 2^(-256 j)} times (a double
 // is never below 2^-1074, so k <= 4).  k follows from the exponent field with scalar instructions, and
@@ -480,6 +599,11 @@ __device__ static inline RowScale row_scale(unsigned min_key) {  // min_key: wav
   s.k = k3 + (s.extra ? 1 : 0);
   s.factor = __hiloint2double((1023 + 256 * k3) << 20, 0);
   return s;
+}
+
+template <bool kExt>
+__device__ static inline RowScale wave_row_scale(unsigned key) {
+  return row_scale(kExt ? wave_max_u32(key) - 1u : wave_min_key(key));
 }
 
 // One junction row's table entries for the genes a lane owns (family constants, independent of the
@@ -526,12 +650,14 @@ __device__ static inline void load_row(const DevJunction& J, int i, unsigned lan
   }
 }
 
-template <int GL, int GR>
+// kExt (extended-range mode): row i's emissions carry the 2^-256 count jrs[i], added to the running count, and
+// rows are rescaled by their largest entry (see key_start).
+template <int GL, int GR, bool kExt>
 __device__ static int junction_wave(const DevJunction& J, const double* jem, const double* ntt_lds, int lane,
                                     const double (&f_in)[GL], int count_in, const double* __restrict__ germ_em,
                                     const double* __restrict__ pad_trans, const double* __restrict__ pad_em,
                                     double (&g_out)[GR], double* __restrict__ fwd_out,
-                                    int32_t* __restrict__ scal_out) {
+                                    int32_t* __restrict__ scal_out, const int32_t* __restrict__ jrs) {
   const int W = J.n_rows, nL = J.n_left, nR = J.n_right;
   int count = count_in;
   double fL[GL], fN[GR][4], fR[GR];  // the previous row, ScaleMatrix already applied
@@ -562,13 +688,13 @@ __device__ static int junction_wave(const DevJunction& J, const double* jem, con
   // Row i: compute every live state from row i-1, one reduction for (rank-one sum, smallest binade),
   // then -- only on the rows where ScaleMatrix fires -- rescale the row in place.
   auto step = [&](int i, const RowTables<GL, GR>& t) __attribute__((always_inline)) {
-    unsigned key = 0xffffffffu;
+    unsigned key = key_start<kExt>();
     double part = 0.0;
 #pragma unroll
     for (int q = 0; q < GL; ++q) {
       const double v = (fL[q] * t.ltr[q]) * jem[t.lidx[q]];
       fL[q] = v;
-      key = min(key, scale_key(v));
+      key = key_add<kExt>(key, v);
       part += v * t.llo[q];  // contribution to the next row's rank-one term
     }
 #pragma unroll
@@ -584,17 +710,18 @@ __device__ static int junction_wave(const DevJunction& J, const double* jem, con
         s += A * nli[q][b];
         const double v = s * jem[nxs[b]];
         fN[q][b] = v;
-        key = min(key, scale_key(v));
+        key = key_add<kExt>(key, v);
       }
       double s = ((n0 * t.nlo[q][0] + n1 * t.nlo[q][1]) + n2 * t.nlo[q][2]) + n3 * t.nlo[q][3];
       s += fR[q] * t.rtr[q];
       s += A * t.rli[q];
       const double v = s * jem[t.ridx[q]];
       fR[q] = v;
-      key = min(key, scale_key(v));
+      key = key_add<kExt>(key, v);
     }
     A = wave_sum(part);
-    const RowScale sc = row_scale(wave_min_key(key));
+    const RowScale sc = wave_row_scale<kExt>(key);
+    if constexpr (kExt) count += jrs[i];
     if (sc.k != 0) {  // wave-uniform, a few rows per junction
       A = sc.apply(A);
 #pragma unroll
@@ -638,7 +765,7 @@ __device__ static int junction_wave(const DevJunction& J, const double* jem, con
   }
 
   // hand-off into the right germline region (A already holds the last row's rank-one sum)
-  unsigned key = 0xffffffffu;
+  unsigned key = key_start<kExt>();
 #pragma unroll
   for (int q = 0; q < GR; ++q) {
     const unsigned r = lane + 64u * q;
@@ -653,21 +780,22 @@ __device__ static int junction_wave(const DevJunction& J, const double* jem, con
       if (pad_trans) v *= pad_trans[r];
       if (pad_em) v *= pad_em[r];
     }
-    key = min(key, scale_key(v));
+    key = key_add<kExt>(key, v);
     g_out[q] = v;
   }
-  const RowScale last = row_scale(wave_min_key(key));
+  const RowScale last = wave_row_scale<kExt>(key);
 #pragma unroll
   for (int q = 0; q < GR; ++q) g_out[q] = last.apply(g_out[q]);
   return count + last.k;
 }
 
 // GA: register slots for the V genes (ceil(nV / 64)); GB: slots for the D and J genes.
-template <int GA, int GB>
+template <int GA, int GB, bool kExt = false>
 __global__ void __launch_bounds__(64 * kJunctionWaves)
     junction_kernel(const DevFamily fam, int n, const double* __restrict__ gem_all,
                     const int32_t* __restrict__ gcnt_all, const double* __restrict__ jem_all,
-                    double* __restrict__ loglik, double* __restrict__ fwd_all, int32_t* __restrict__ scal_all) {
+                    const int32_t* __restrict__ jrs_all, double* __restrict__ loglik, double* __restrict__ fwd_all,
+                    int32_t* __restrict__ scal_all) {
   // [NTI->NTI blocks of the vd right genes | same for dj | kJunctionWaves slices of n_jcols + 1 doubles]
   extern __shared__ double jlds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -698,7 +826,7 @@ __global__ void __launch_bounds__(64 * kJunctionWaves)
 
   // initial forward over the V germline region (src/HMM.cpp:291-319)
   double gV[GA];
-  unsigned key = 0xffffffffu;
+  unsigned key = key_start<kExt>();
 #pragma unroll
   for (int q = 0; q < GA; ++q) {
     const int t = lane + 64 * q;
@@ -710,12 +838,13 @@ __global__ void __launch_bounds__(64 * kJunctionWaves)
       v *= fam.vgerm_trans_prod[t];
       v *= gem[nV + t];
     }
-    key = min(key, scale_key(v));
+    key = key_add<kExt>(key, v);
     gV[q] = v;
   }
   int vcount = cv;
+  const int32_t* jrs = kExt ? jrs_all + (size_t)s * (fam.vd.n_rows + (fam.has_d ? fam.dj.n_rows : 0)) : nullptr;
   {
-    const RowScale sc = row_scale(wave_min_key(key));
+    const RowScale sc = wave_row_scale<kExt>(key);
 #pragma unroll
     for (int q = 0; q < GA; ++q) gV[q] = sc.apply(gV[q]);
     vcount += sc.k;
@@ -738,8 +867,8 @@ __global__ void __launch_bounds__(64 * kJunctionWaves)
     const double* dgerm_em = gem + 2 * (size_t)nV;
     const double* jgerm_em = dgerm_em + nD;
     const double* jpad_em = jgerm_em + nJ;
-    const int dcount = cd + junction_wave<GA, GB>(fam.vd, jem, ntt_vd, lane, gV, vcount, dgerm_em, nullptr, nullptr,
-                                                  gD, fwd, sco);
+    const int dcount = cd + junction_wave<GA, GB, kExt>(fam.vd, jem, ntt_vd, lane, gV, vcount, dgerm_em, nullptr,
+                                                        nullptr, gD, fwd, sco, jrs);
     if (fwd) {
       fwd += (size_t)fam.vd.n_rows * (fam.vd.n_left + 5 * (size_t)fam.vd.n_right);
 #pragma unroll
@@ -752,15 +881,16 @@ __global__ void __launch_bounds__(64 * kJunctionWaves)
       if (lane == 0) sco[0] = dcount;
       sco += 1;
     }
-    jcount = cj + junction_wave<GB, GB>(fam.dj, jem, ntt_dj, lane, gD, dcount, jgerm_em, fam.jpadding_transition,
-                                        jpad_em, gJ, fwd, sco);
+    jcount = cj + junction_wave<GB, GB, kExt>(fam.dj, jem, ntt_dj, lane, gD, dcount, jgerm_em,
+                                              fam.jpadding_transition, jpad_em, gJ, fwd, sco,
+                                              kExt ? jrs + fam.vd.n_rows : nullptr);
     if (fwd) fwd += (size_t)fam.dj.n_rows * (fam.dj.n_left + 5 * (size_t)fam.dj.n_right);
     if (sco) sco += fam.dj.n_rows;
   } else {
     const double* jgerm_em = gem + 2 * (size_t)nV;
     const double* jpad_em = jgerm_em + nJ;
-    jcount = cj + junction_wave<GA, GB>(fam.vd, jem, ntt_vd, lane, gV, vcount, jgerm_em, fam.jpadding_transition,
-                                        jpad_em, gJ, fwd, sco);
+    jcount = cj + junction_wave<GA, GB, kExt>(fam.vd, jem, ntt_vd, lane, gV, vcount, jgerm_em,
+                                              fam.jpadding_transition, jpad_em, gJ, fwd, sco, jrs);
     if (fwd) fwd += (size_t)fam.vd.n_rows * (fam.vd.n_left + 5 * (size_t)fam.vd.n_right);
     if (sco) sco += fam.vd.n_rows;
   }
@@ -785,79 +915,104 @@ static size_t junction_lds_bytes(const DevFamily& fam) {
          sizeof(double);
 }
 
-static size_t emission_lds_bytes(const DevFamily& fam) {
+static size_t emission_lds_bytes(const DevFamily& fam, bool ext) {
   const size_t cap = (size_t)cons_capacity(fam);
   return (((size_t)fam.n_ucol + 2) & ~(size_t)1) * sizeof(double) + (2 * kFwdWaves + 2) * sizeof(int) +
-         (cap ? (2 * cap + 4) * sizeof(double) + (cap + 4) * sizeof(int) : 0);
+         (cap ? (2 * cap + 4) * sizeof(double) + (cap + 4) * sizeof(int) : 0) +
+         (ext ? ((size_t)fam.n_ucol + 2) * sizeof(int) : 0);
 }
 
 size_t forward_lds_bytes(const DevFamily& fam) {
-  const size_t a = emission_lds_bytes(fam), b = junction_lds_bytes(fam);
+  const size_t a = emission_lds_bytes(fam, true), b = junction_lds_bytes(fam);
   return a > b ? a : b;
 }
 
-template <int kG, bool kSite, bool kByteOff>
+template <int kG, bool kSite, bool kByteOff, bool kExt>
 static void launch_emission_k(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
                               const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt,
-                              double* jem, hipStream_t stream) {
-  const size_t lds = emission_lds_bytes(fam);
+                              double* jem, int32_t* jrs, hipStream_t stream) {
+  const size_t lds = emission_lds_bytes(fam, kExt);
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emission_kernel<kG, kSite, kByteOff>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emission_kernel<kG, kSite, kByteOff, kExt>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((emission_kernel<kG, kSite, kByteOff>), dim3(n), dim3(kFwdThreads), lds, stream, fam, R,
-                     site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem);
+  hipLaunchKernelGGL((emission_kernel<kG, kSite, kByteOff, kExt>), dim3(n), dim3(kFwdThreads), lds, stream, fam, R,
+                     site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, jrs);
 }
 
 template <int kG>
 static void launch_emission_g(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
                               const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt,
-                              double* jem, hipStream_t stream) {
-#define LH_ARGS fam, n, R, site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, stream
-  if (site_lik) {
+                              double* jem, int32_t* jrs, bool ext, hipStream_t stream) {
+#define LH_ARGS fam, n, R, site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, jrs, stream
+  if (ext) {  // opt-in mode: one index form is enough
+    if (site_lik) {
+      if (fam.idx_byte_offsets)
+        launch_emission_k<kG, true, true, true>(LH_ARGS);
+      else
+        launch_emission_k<kG, true, false, true>(LH_ARGS);
+    } else {
+      if (fam.idx_byte_offsets)
+        launch_emission_k<kG, false, true, true>(LH_ARGS);
+      else
+        launch_emission_k<kG, false, false, true>(LH_ARGS);
+    }
+  } else if (site_lik) {
     if (fam.idx_byte_offsets)
-      launch_emission_k<kG, true, true>(LH_ARGS);
+      launch_emission_k<kG, true, true, false>(LH_ARGS);
     else
-      launch_emission_k<kG, true, false>(LH_ARGS);
+      launch_emission_k<kG, true, false, false>(LH_ARGS);
   } else {
     if (fam.idx_byte_offsets)
-      launch_emission_k<kG, false, true>(LH_ARGS);
+      launch_emission_k<kG, false, true, false>(LH_ARGS);
     else
-      launch_emission_k<kG, false, false>(LH_ARGS);
+      launch_emission_k<kG, false, false, false>(LH_ARGS);
   }
 #undef LH_ARGS
 }
 
 template <int GA, int GB>
 static void launch_junction_g(const DevFamily& fam, int n, const double* gem, const int32_t* gcnt, const double* jem,
-                              double* loglik, double* forward_out, int32_t* scaler_out, hipStream_t stream) {
+                              const int32_t* jrs, double* loglik, double* forward_out, int32_t* scaler_out, bool ext,
+                              hipStream_t stream) {
   const size_t lds = junction_lds_bytes(fam);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_kernel<GA, GB>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((junction_kernel<GA, GB>), dim3((n + kJunctionWaves - 1) / kJunctionWaves),
-                     dim3(64 * kJunctionWaves), lds, stream, fam, n, gem, gcnt, jem, loglik, forward_out, scaler_out);
+  const dim3 grid((n + kJunctionWaves - 1) / kJunctionWaves), block(64 * kJunctionWaves);
+  if (ext) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_kernel<GA, GB, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((junction_kernel<GA, GB, true>), grid, block, lds, stream, fam, n, gem, gcnt, jem, jrs, loglik,
+                       forward_out, scaler_out);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_kernel<GA, GB, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((junction_kernel<GA, GB, false>), grid, block, lds, stream, fam, n, gem, gcnt, jem, jrs, loglik,
+                       forward_out, scaler_out);
+  }
 }
 
 template <int GA>
 static void launch_junction_a(int gb, const DevFamily& fam, int n, const double* gem, const int32_t* gcnt,
-                              const double* jem, double* loglik, double* forward_out, int32_t* scaler_out,
-                              hipStream_t stream) {
+                              const double* jem, const int32_t* jrs, double* loglik, double* forward_out,
+                              int32_t* scaler_out, bool ext, hipStream_t stream) {
   if (gb <= 1)
-    launch_junction_g<GA, 1>(fam, n, gem, gcnt, jem, loglik, forward_out, scaler_out, stream);
+    launch_junction_g<GA, 1>(fam, n, gem, gcnt, jem, jrs, loglik, forward_out, scaler_out, ext, stream);
   else if (gb <= 2)
-    launch_junction_g<GA, 2>(fam, n, gem, gcnt, jem, loglik, forward_out, scaler_out, stream);
+    launch_junction_g<GA, 2>(fam, n, gem, gcnt, jem, jrs, loglik, forward_out, scaler_out, ext, stream);
   else
-    launch_junction_g<GA, 4>(fam, n, gem, gcnt, jem, loglik, forward_out, scaler_out, stream);
+    launch_junction_g<GA, 4>(fam, n, gem, gcnt, jem, jrs, loglik, forward_out, scaler_out, ext, stream);
 }
 
 // site_lik != null: emissions are assembled from K1's output (em_out optional);
 // site_lik == null: emissions are taken from em_in (SimpleHMM / lh_forward_batch).
-// gem [n][gem_size], gcnt [n][3], jem [n][n_jcols]: per-sample hand-off buffers between K2a and K2b.
+// gem [n][gem_size], gcnt [n][3], jem [n][n_jcols]: per-sample hand-off buffers between K2a and K2b
+// (+ jrs [n][junction rows] in the extended-range mode).
 void launch_forward(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
                     const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt, double* jem,
-                    double* loglik, double* forward_out, int32_t* scaler_out, hipStream_t stream) {
+                    int32_t* jrs, double* loglik, double* forward_out, int32_t* scaler_out, bool ext,
+                    hipStream_t stream) {
   const int slots = (fam.max_genes + kFwdThreads - 1) / kFwdThreads;
-#define LH_ARGS fam, n, R, site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, stream
+#define LH_ARGS fam, n, R, site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, jrs, ext, stream
   if (slots <= 1)
     launch_emission_g<1>(LH_ARGS);
   else if (slots <= 2)
@@ -867,7 +1022,7 @@ void launch_forward(const DevFamily& fam, int n, int R, const double* site_lik, 
 #undef LH_ARGS
   const int ga = (fam.vgerm.n_genes + 63) / 64;
   const int gb = (std::max(fam.dgerm.n_genes, fam.jgerm.n_genes) + 63) / 64;
-#define LH_ARGS gb, fam, n, gem, gcnt, jem, loglik, forward_out, scaler_out, stream
+#define LH_ARGS gb, fam, n, gem, gcnt, jem, jrs, loglik, forward_out, scaler_out, ext, stream
   if (ga <= 1)
     launch_junction_a<1>(LH_ARGS);
   else if (ga <= 2)

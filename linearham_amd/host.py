@@ -117,6 +117,9 @@ class PhyloHMM(_HMM):
     def initialize_phylo_emission(self):
         _check(self.lib.lhh_phylo_init_emission(self.h))
 
+    def set_extended_range(self, on=True):
+        _check(self.lib.lhh_phylo_set_extended_range(self.h, int(on)))
+
     def run_pipeline(self, input_path, output_path, num_rates):
         _check(self.lib.lhh_run_pipeline(self.h, input_path.encode(), output_path.encode(), num_rates))
 

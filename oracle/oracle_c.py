@@ -110,8 +110,10 @@ class COracleFamily:
         j.xmsa = self._i32(xm)
         return j
 
-    def eval(self, trees, er, pi, alphas, n_threads=1, want_em=False):
-        """trees: list of (children [(T-2)*2], root, brlen [2T-2]) in the C-ABI form."""
+    def eval(self, trees, er, pi, alphas, n_threads=1, want_em=False, extended=False):
+        """trees: list of (children [(T-2)*2], root, brlen [2T-2]) in the C-ABI form.
+        extended: the product's opt-in extended-range mode restated on the dense algorithm (not reference
+        behaviour; see oracle_kernels.c)."""
         n, T = len(trees), self.f.T
         children = np.stack([np.asarray(t[0], dtype=np.int32) for t in trees])
         roots = np.array([t[1] for t in trees], dtype=np.int32)
@@ -123,6 +125,13 @@ class COracleFamily:
         er, pi = np.ascontiguousarray(er, dtype=np.float64), np.ascontiguousarray(pi, dtype=np.float64)
         ll = np.zeros(n)
         em = np.zeros((n, self.f.C)) if want_em else None
+        if extended:
+            self.lib.oc_eval_batch_ext(C.byref(self.f), n, children.ctypes.data_as(c_i32p),
+                                       roots.ctypes.data_as(c_i32p), order.ctypes.data_as(c_i32p),
+                                       brlen.ctypes.data_as(c_f64p), er.ctypes.data_as(c_f64p),
+                                       pi.ctypes.data_as(c_f64p), rates.ctypes.data_as(c_f64p),
+                                       ll.ctypes.data_as(c_f64p), n_threads)
+            return ll
         self.lib.oc_eval_batch(C.byref(self.f), n, children.ctypes.data_as(c_i32p), roots.ctypes.data_as(c_i32p),
                                order.ctypes.data_as(c_i32p), brlen.ctypes.data_as(c_f64p),
                                er.ctypes.data_as(c_f64p), pi.ctypes.data_as(c_f64p), rates.ctypes.data_as(c_f64p),

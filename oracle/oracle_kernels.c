@@ -16,6 +16,12 @@
  * Parity status: pinned through tests/test_oracle_c.py (agrees with the numpy oracle, which is pinned
  * to the reference's Catch-test literals, to <= 1e-12 relative on the toy and synthetic families).
  * Discrete-Gamma rates are computed by the caller (scipy) and passed in.
+ *
+ * ext != 0 (oc_eval_batch_ext): the product's opt-in extended-range mode (include/linearham_amd.h,
+ * lh_family_set_extended_range) restated on the same dense algorithm -- NOT reference behaviour: emissions
+ * are (value, 2^-256 count) pairs, a region's products are equalised to the smallest count, vectors are
+ * rescaled by their largest entry.  Parity of that mode is therefore "unpinned" by construction; it is
+ * checked against this file where the reference is finite (same log-likelihood) and for finiteness elsewhere.
  */
 #include <math.h>
 #include <stdint.h>
@@ -97,20 +103,41 @@ static void jacobi4(double A[4][4], double W[4][4]) {
   }
 }
 
-static int fill_segments(const oc_segments* s, const double* em, double* out) {
-  /* FillGermlinePaddingEmission, src/PhyloHMM.cpp:158-193 */
-  int mx = 0;
+static int scale_vec_max(double* v, int n) { /* extended-range mode: by the largest entry */
+  int k = 0;
+  for (;;) {
+    double mx = 0;
+    for (int i = 0; i < n; ++i)
+      if (v[i] > mx) mx = v[i];
+    if (!(mx > 0.0 && mx < SCALE_THRESHOLD)) return k;
+    for (int i = 0; i < n; ++i) v[i] *= SCALE_FACTOR;
+    ++k;
+  }
+}
+
+static int fill_segments(const oc_segments* s, const double* em, const int* emc, double* out) {
+  /* FillGermlinePaddingEmission, src/PhyloHMM.cpp:158-193; emc != NULL: extended-range mode */
+  int mx = 0, mn = 1 << 30;
   int* cnt = (int*)malloc(sizeof(int) * (s->n_genes > 0 ? s->n_genes : 1));
   for (int g = 0; g < s->n_genes; ++g) {
     double v = 1.0;
     int c = 0;
     for (int j = s->offsets[g]; j < s->offsets[g + 1]; ++j) {
       v *= em[s->xmsa_inds[j]];
+      if (emc) c += emc[s->xmsa_inds[j]];
       c += scale_vec(&v, 1);
     }
     out[g] = v;
     cnt[g] = c;
     if (c > mx) mx = c;
+    if (v > 0.0 && c < mn) mn = c;
+  }
+  if (emc) {
+    if (mn == 1 << 30) mn = 0;
+    for (int g = 0; g < s->n_genes; ++g)
+      for (int d = cnt[g] - mn; d > 0 && out[g] != 0.0; --d) out[g] *= SCALE_THRESHOLD;
+    free(cnt);
+    return mn;
   }
   for (int g = 0; g < s->n_genes; ++g) out[g] *= pow(SCALE_FACTOR, mx - cnt[g]);
   free(cnt);
@@ -118,7 +145,7 @@ static int fill_segments(const oc_segments* s, const double* em, double* out) {
 }
 
 /* ComputeJunctionForwardProbabilities + ComputeGermlineForwardProbabilities for one junction */
-static int junction(const oc_junction* J, const double* em, const double* g_in, int count_in,
+static int junction(const oc_junction* J, const double* em, const int* emc, const double* g_in, int count_in,
                     const double* germ_em, const double* pad_trans, const double* pad_em, double* g_out,
                     double* buf /* 3*S */) {
   const int S = J->S, W = J->W;
@@ -130,6 +157,20 @@ static int junction(const oc_junction* J, const double* em, const double* g_in, 
     for (int s = 0; s < S; ++s) { /* FillJunctionEmission row */
       const int idx = J->xmsa[(size_t)i * S + s];
       E[s] = idx >= 0 ? em[idx] : 0.0;
+    }
+    if (emc) { /* extended range: bring the row's emissions to their smallest count, which joins the row's */
+      int mn = 1 << 30;
+      for (int s = 0; s < S; ++s) {
+        const int idx = J->xmsa[(size_t)i * S + s];
+        if (idx >= 0 && em[idx] > 0.0 && emc[idx] < mn) mn = emc[idx];
+      }
+      if (mn == 1 << 30) mn = 0;
+      for (int s = 0; s < S; ++s) {
+        const int idx = J->xmsa[(size_t)i * S + s];
+        if (idx >= 0)
+          for (int d = emc[idx] - mn; d > 0 && E[s] != 0.0; --d) E[s] *= SCALE_THRESHOLD;
+      }
+      count += mn;
     }
     if (i == 0) {
       for (int s = 0; s < S; ++s) {
@@ -146,7 +187,7 @@ static int junction(const oc_junction* J, const double* em, const double* g_in, 
       }
     }
     for (int s = 0; s < S; ++s) cur[s] *= E[s];
-    count += scale_vec(cur, S);
+    count += emc ? scale_vec_max(cur, S) : scale_vec(cur, S);
     double* t = prev; prev = cur; cur = t;
   }
   for (int g = 0; g < J->n_to; ++g) {
@@ -158,7 +199,7 @@ static int junction(const oc_junction* J, const double* em, const double* g_in, 
     if (pad_em) acc *= pad_em[g];
     g_out[g] = acc;
   }
-  return count + scale_vec(g_out, J->n_to);
+  return count + (emc ? scale_vec_max(g_out, J->n_to) : scale_vec(g_out, J->n_to));
 }
 
 /* One evaluation.  children/root/brlen in the C ABI's rooted-at-naive form (any rooting gives the
@@ -166,7 +207,7 @@ static int junction(const oc_junction* J, const double* em, const double* g_in, 
  * in post-order.  Returns log-likelihood; writes em[C] if non-NULL. */
 static double eval_one(const oc_family* F, const int32_t* children, int root, const int32_t* order,
                        const double* brlen, const double* er, const double* pi, const double* rates,
-                       double* em_out) {
+                       double* em_out, int ext) {
   const int T = F->T, C = F->C, R = F->R, nodes = 2 * T - 2, I = T - 2;
   /* GTR eigendecomposition */
   double S[4][4] = {{0}}, A[4][4], W[4][4], sq[4], lam[4], U[4][4], Ui[4][4];
@@ -244,6 +285,7 @@ static double eval_one(const oc_family* F, const int32_t* children, int root, co
   }
   /* root edge (root -- naive tip 0), naive correction, exp */
   double* em = (double*)malloc(sizeof(double) * C);
+  int* emc = ext ? (int*)calloc(C, sizeof(int)) : NULL;
   {
     const double* rc = clv + (size_t)(root - T) * R * 4 * C;
     for (int c = 0; c < C; ++c) {
@@ -257,6 +299,11 @@ static double eval_one(const oc_family* F, const int32_t* children, int root, co
           acc += pi[i] * rc[((size_t)r * 4 + i) * C + c] * tp;
         }
         site += acc / R;
+      }
+      if (ext) { /* value and 2^-256 count side by side, no exp */
+        em[c] = st != 4 ? site / pi[st] : site;
+        emc[c] = scal[(size_t)(root - T) * C + c];
+        continue;
       }
       double lnl = log(site) - scal[(size_t)(root - T) * C + c] * LOG_SCALE_FACTOR;
       if (st != 4) lnl -= log(pi[st]);
@@ -274,8 +321,8 @@ static double eval_one(const oc_family* F, const int32_t* children, int root, co
   double *e2 = e1 + mg, *gA = e1 + 2 * mg, *gB = e1 + 3 * mg;
   double* buf = (double*)malloc(sizeof(double) * 3 * (size_t)Smax);
   const int nV = F->vgerm.n_genes;
-  int vcount = fill_segments(&F->vpadding, em, e2);
-  vcount += fill_segments(&F->vgerm, em, e1);
+  int vcount = fill_segments(&F->vpadding, em, emc, e2);
+  vcount += fill_segments(&F->vgerm, em, emc, e1);
   for (int g = 0; g < nV; ++g) { /* ComputeInitialForwardProbabilities, src/HMM.cpp:291-319 */
     double v = F->vgerm_gene_prob[g];
     v *= F->vpadding_transition[g];
@@ -284,26 +331,26 @@ static double eval_one(const oc_family* F, const int32_t* children, int root, co
     v *= e1[g];
     gA[g] = v;
   }
-  vcount += scale_vec(gA, nV);
+  vcount += ext ? scale_vec_max(gA, nV) : scale_vec(gA, nV);
   int jcount;
   const double* gJ;
   if (F->has_d) {
-    int dcount = fill_segments(&F->dgerm, em, e1);
-    dcount += junction(&F->vd, em, gA, vcount, e1, NULL, NULL, gB, buf);
-    jcount = fill_segments(&F->jgerm, em, e1);
-    jcount += fill_segments(&F->jpadding, em, e2);
-    jcount += junction(&F->dj, em, gB, dcount, e1, F->jpadding_transition, e2, gA, buf);
+    int dcount = fill_segments(&F->dgerm, em, emc, e1);
+    dcount += junction(&F->vd, em, emc, gA, vcount, e1, NULL, NULL, gB, buf);
+    jcount = fill_segments(&F->jgerm, em, emc, e1);
+    jcount += fill_segments(&F->jpadding, em, emc, e2);
+    jcount += junction(&F->dj, em, emc, gB, dcount, e1, F->jpadding_transition, e2, gA, buf);
     gJ = gA;
   } else {
-    jcount = fill_segments(&F->jgerm, em, e1);
-    jcount += fill_segments(&F->jpadding, em, e2);
-    jcount += junction(&F->vd, em, gA, vcount, e1, F->jpadding_transition, e2, gB, buf);
+    jcount = fill_segments(&F->jgerm, em, emc, e1);
+    jcount += fill_segments(&F->jpadding, em, emc, e2);
+    jcount += junction(&F->vd, em, emc, gA, vcount, e1, F->jpadding_transition, e2, gB, buf);
     gJ = gB;
   }
   double tot = 0;
   for (int g = 0; g < F->jgerm.n_genes; ++g) tot += gJ[g];
   const double ll = log(tot) - jcount * LOG_SCALE_FACTOR;
-  free(em); free(e1); free(buf);
+  free(em); free(emc); free(e1); free(buf);
   return ll;
 }
 
@@ -317,6 +364,19 @@ int oc_eval_batch(const oc_family* F, int n, const int32_t* children, const int3
   for (int s = 0; s < n; ++s)
     loglik[s] = eval_one(F, children + (size_t)s * 2 * (T - 2), roots[s], order + (size_t)s * (T - 2),
                          brlen + (size_t)s * (2 * T - 2), er + (size_t)s * 6, pi + (size_t)s * 4,
-                         rates + (size_t)s * F->R, em_out ? em_out + (size_t)s * F->C : NULL);
+                         rates + (size_t)s * F->R, em_out ? em_out + (size_t)s * F->C : NULL, 0);
+  return 0;
+}
+
+/* The same in the product's extended-range mode (see the header comment). */
+int oc_eval_batch_ext(const oc_family* F, int n, const int32_t* children, const int32_t* roots,
+                      const int32_t* order, const double* brlen, const double* er, const double* pi,
+                      const double* rates, double* loglik, int n_threads) {
+  const int T = F->T;
+#pragma omp parallel for schedule(dynamic) num_threads(n_threads > 0 ? n_threads : 1)
+  for (int s = 0; s < n; ++s)
+    loglik[s] = eval_one(F, children + (size_t)s * 2 * (T - 2), roots[s], order + (size_t)s * (T - 2),
+                         brlen + (size_t)s * (2 * T - 2), er + (size_t)s * 6, pi + (size_t)s * 4,
+                         rates + (size_t)s * F->R, NULL, 1);
   return 0;
 }

@@ -75,11 +75,13 @@ def expand_forward(h, fam_desc, fwd, sco):
     return out
 
 
-def run_family(hip, h, samples, num_rates):
+def run_family(hip, h, samples, num_rates, extended=False):
     """samples: list of dict(tree=newick, er, pi, alpha). Returns (gpu results, oracle results)."""
     import linearham_amd
     desc = db.build_family_desc(h)
     fam = linearham_amd.Family(desc, hip)
+    if extended:
+        fam.set_extended_range(True)
     T = h.msa.shape[0] + 1
     ops, brl, depth = [], [], 0
     for s in samples:
@@ -214,6 +216,31 @@ def test_synthetic_family(hip, tmp_path, preset):
     compare(h, desc, ll, res, ref)
     if preset == "medium":
         assert any(r["jgerm_scaler_count"] > 0 for r in ref)
+
+
+@pytest.mark.parametrize("preset", ["medium", "igk", "many_alleles"])
+def test_extended_range_equals_default_where_finite(hip, tmp_path, preset):
+    """The opt-in extended-range mode (lh_family_set_extended_range) on families the reference evaluates without
+    over/underflow: same log-likelihood (1e-10) and emissions; its forward arrays are scaled differently
+    (documented), so value x 2^(-256 count) is what is compared there: the final J germline vector."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    spec = {"medium": sf.Spec.small(n_leaves=40, n_samples=3, seed=11),
+            "igk": sf.Spec.small(locus="igk", n_samples=3, seed=5),
+            "many_alleles": sf.Spec.small(n_v=300, n_d=70, n_j=5, n_samples=2, seed=21)}[preset]
+    sf.generate(spec, out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    desc, ll, res, ref = run_family(hip, h, rows, 4, extended=True)
+    for i, r in enumerate(ref):
+        assert abs(ll[i] - r["loglik"]) <= 1e-10 * abs(r["loglik"]), (i, ll[i], r["loglik"])
+        np.testing.assert_allclose(res["xmsa_emission"][i], r["xmsa_emission"], rtol=1e-8)
+        ex = expand_forward(h, desc, res["forward"][i], res["scaler_counts"][i])
+        got = np.log(ex["jgerm_forward"].sum()) - ex["jgerm_scaler_count"] * np.log(2.0 ** 256)
+        assert abs(got - r["loglik"]) <= 1e-10 * abs(r["loglik"])
+        big = r["jgerm_forward"] > r["jgerm_forward"].max() * 1e-100
+        d = (ex["jgerm_scaler_count"] - r["jgerm_scaler_count"]) * 256
+        np.testing.assert_allclose(ex["jgerm_forward"][big], np.ldexp(r["jgerm_forward"][big], d), rtol=1e-8)
 
 
 @pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108])

@@ -305,3 +305,64 @@ def test_config4_full_size_family(tmp_path):
     assert np.array_equal(np.isfinite(got), fin)               # the reference's overflow rows, and only those
     assert fin.sum() >= rows - 8                                # ... are a small minority
     np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-10)
+
+
+def test_extended_range_mode(tmp_path):
+    """Opt-in extended-range arithmetic (lh_family_set_extended_range; not reference behaviour): on the full
+    configs[4] family it must (a) equal the default mode's log-likelihood to 1e-10 wherever that is finite,
+    (b) be finite on the tree samples where the reference's 2^(256 d) equalisation overflows, (c) agree there
+    with the same mode restated on the dense algorithm (oracle_kernels.c, ext), and (d) leave a sampling
+    distribution: forward rows differ from the default's only by a positive factor per row."""
+    import ctypes as C
+    import linearham_amd
+    from linearham_amd import host as hst
+    from linearham_amd.capi import _EvalOutputs
+    from oracle import oracle_c
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec(n_leaves=500, n_sites=600, n_samples=64), out)
+    hmm = hst.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    flat = hmm.flatten_tsv(os.path.join(out, "trees.tsv"), 64)
+    lib = linearham_amd.load_library()
+    fam = C.c_void_p(flat["family"])
+    T, depth, n = flat["n_tips"], flat["max_depth"], 64
+    fs = lib.lib.lh_forward_size(fam)
+
+    def run(want_fwd=False):
+        ll = np.zeros(n)
+        fwd = np.zeros((n, fs)) if want_fwd else None
+        outs = _EvalOutputs()
+        if want_fwd:
+            outs.forward = fwd.ctypes.data_as(C.POINTER(C.c_double))
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        lib.check(lib.lib.lh_eval_batch(fam, n, T, depth, p(flat["ops"], C.c_int32), p(flat["brlen"], C.c_double),
+                                        p(flat["er"], C.c_double), p(flat["pi"], C.c_double),
+                                        p(flat["alpha"], C.c_double), 4, p(ll, C.c_double), C.byref(outs)))
+        return ll, fwd
+    ll_def, fwd_def = run(True)
+    hmm.set_extended_range(True)
+    ll_ext, fwd_ext = run(True)
+    hmm.set_extended_range(False)
+    ll_back, _ = run()
+    assert np.array_equal(ll_back, ll_def, equal_nan=True)          # the switch is clean
+    fin = np.isfinite(ll_def)
+    assert 0 < (~fin).sum() <= 8                                    # the family does contain overflow rows
+    assert np.all(np.isfinite(ll_ext))
+    np.testing.assert_allclose(ll_ext[fin], ll_def[fin], rtol=1e-10)
+    # the overflow rows against the dense restatement of the mode
+    rows_tsv = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    o = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    labels = list(o.xmsa_labels)
+    bad = [int(i) for i in np.where(~fin)[0]] + [0, 1]
+    trees = [hst.newick_arrays(rows_tsv[r]["tree"], labels) for r in bad]
+    oracle_c.build()
+    ofam = oracle_c.COracleFamily(o, 4)
+    ref = ofam.eval(trees, [rows_tsv[r]["er"] for r in bad], [rows_tsv[r]["pi"] for r in bad],
+                    [rows_tsv[r]["alpha"] for r in bad], n_threads=4, extended=True)
+    np.testing.assert_allclose(ll_ext[bad], ref, rtol=1e-10)
+    # forward rows of a finite sample: same direction in both modes (V germline vector: the first nV entries)
+    nV = 200
+    a, b = fwd_def[0, :nV], fwd_ext[0, :nV]
+    keep = a > a.max() * 1e-200
+    ratio = b[keep] / a[keep]
+    np.testing.assert_allclose(ratio, ratio[0], rtol=1e-12)
