@@ -241,6 +241,92 @@ struct HMM::SamplingLists {
   ColumnLists vd_germ, vd_junction, dj_germ, dj_junction;
 };
 
+void HMM::EnsureSamplingLists() {
+  if (sampling_lists_) return;
+  sampling_lists_.reset(new SamplingLists());
+  sampling_lists_->vd_germ = ColumnLists::Build(vd_junction_dgerm_transition_);
+  sampling_lists_->vd_junction = ColumnLists::Build(vd_junction_transition_);
+  if (locus_ == "igh") {
+    sampling_lists_->dj_germ = ColumnLists::Build(dj_junction_jgerm_transition_);
+    sampling_lists_->dj_junction = ColumnLists::Build(dj_junction_transition_);
+  }
+}
+
+int HMM::RawDrawsPerSample() const {
+  const bool igh = locus_ == "igh";
+  int draws = 0;
+  draws += jgerm_.state_strs.size() >= 2;
+  draws += vgerm_.state_strs.size() >= 2;
+  // a junction row draws over all S junction states (S >= 2 whenever a junction exists: four NTI states per right gene)
+  draws += flexbounds_.at(igh ? "d_l" : "j_l").second - flexbounds_.at("v_r").first;
+  if (igh) {
+    draws += dgerm_.state_strs.size() >= 2;
+    draws += flexbounds_.at("j_l").second - flexbounds_.at("d_r").first;
+  }
+  return 2 * draws;  // generate_canonical<double, 53> on a 32-bit engine
+}
+
+// The same sequence of operations as SampleNaiveSequence below, on caller-owned state.
+void HMM::SampleRow(RowSampler& s, const double* fwd, std::mt19937& rng) const {
+  const SamplingLists& sl = *sampling_lists_;
+  const bool igh = locus_ == "igh";
+  const int nV = (int)vgerm_.state_strs.size(), nJ = (int)jgerm_.state_strs.size();
+  s.vgerm_forward.assign(fwd, fwd + nV);
+  fwd += nV;
+  const int W1 = flexbounds_.at(igh ? "d_l" : "j_l").second - flexbounds_.at("v_r").first;
+  fwd = UnpackJunction(fwd, vd_junction_, vgerm_, igh ? dgerm_ : jgerm_, flexbounds_.at("v_r").first, W1,
+                       s.vd_junction_forward, s.vd_scatter);
+  if (igh) {
+    const int nD = (int)dgerm_.state_strs.size();
+    s.dgerm_forward.assign(fwd, fwd + nD);
+    fwd += nD;
+    const int W2 = flexbounds_.at("j_l").second - flexbounds_.at("d_r").first;
+    fwd = UnpackJunction(fwd, dj_junction_, dgerm_, jgerm_, flexbounds_.at("d_r").first, W2, s.dj_junction_forward,
+                         s.dj_scatter);
+  }
+  s.jgerm_forward.assign(fwd, fwd + nJ);
+
+  s.naive_seq.assign(msa_.cols(), 'N');
+  {  // SampleInitialState
+    s.distr.param(std::discrete_distribution<int>::param_type(s.jgerm_forward.data(),
+                                                              s.jgerm_forward.data() + s.jgerm_forward.size()));
+    s.jgerm_state_ind = s.distr(rng);
+    s.jgerm_state_str = jgerm_.state_strs[s.jgerm_state_ind];
+    s.jgerm_left_del = jgerm_.left_del[s.jgerm_state_ind];
+    s.jgerm_right_del = jgerm_.right_del[s.jgerm_state_ind];
+    const auto& rg = jgerm_.ggene_ranges.at(s.jgerm_state_str);
+    for (int i = rg.first; i < rg.second; i++) s.naive_seq[jgerm_.site_inds[i]] = alphabet_[jgerm_.naive_bases[i]];
+  }
+  if (igh) {
+    SampleJunctionStates(s.jgerm_state_ind, dj_junction_jgerm_transition_, dj_junction_, dj_junction_transition_,
+                         s.dj_junction_forward, GermlineType::D, GermlineType::J, flexbounds_.at("d_r"), alphabet_, rng,
+                         s.distr, s.naive_seq, s.jgerm_left_del, s.dj_junction_state_strs, s.dj_junction_state_inds,
+                         s.dj_junction_insertion, s.dgerm_right_del, &sl.dj_germ, &sl.dj_junction);
+    SampleGermlineState(s.dj_junction_state_inds, dgerm_dj_junction_transition_, dgerm_, s.dgerm_forward, alphabet_,
+                        rng, s.distr, s.naive_seq, s.dgerm_state_str, s.dgerm_state_ind, s.dgerm_left_del,
+                        s.dgerm_right_del);
+    SampleJunctionStates(s.dgerm_state_ind, vd_junction_dgerm_transition_, vd_junction_, vd_junction_transition_,
+                         s.vd_junction_forward, GermlineType::V, GermlineType::D, flexbounds_.at("v_r"), alphabet_, rng,
+                         s.distr, s.naive_seq, s.dgerm_left_del, s.vd_junction_state_strs, s.vd_junction_state_inds,
+                         s.vd_junction_insertion, s.vgerm_right_del, &sl.vd_germ, &sl.vd_junction);
+  } else {
+    SampleJunctionStates(s.jgerm_state_ind, vd_junction_dgerm_transition_, vd_junction_, vd_junction_transition_,
+                         s.vd_junction_forward, GermlineType::V, GermlineType::J, flexbounds_.at("v_r"), alphabet_, rng,
+                         s.distr, s.naive_seq, s.jgerm_left_del, s.vd_junction_state_strs, s.vd_junction_state_inds,
+                         s.vd_junction_insertion, s.vgerm_right_del, &sl.vd_germ, &sl.vd_junction);
+  }
+  SampleGermlineState(s.vd_junction_state_inds, vgerm_vd_junction_transition_, vgerm_, s.vgerm_forward, alphabet_, rng,
+                      s.distr, s.naive_seq, s.vgerm_state_str, s.vgerm_state_ind, s.vgerm_left_del, s.vgerm_right_del);
+  const std::string& q = s.naive_seq;
+  std::size_t a = 0, b = q.size();
+  while (a < q.size() && q[a] == 'N') ++a;
+  while (b > a && q[b - 1] == 'N') --b;
+  bool ok = b > a;
+  for (std::size_t i = a; i < b && ok; ++i) ok = alphabet_.find(q[i]) != std::string::npos && q[i] != 'N';
+  s.vgerm_left_insertion = ok ? q.substr(0, a) : "";
+  s.jgerm_right_insertion = ok ? q.substr(b) : "";
+}
+
 // src/HMM.cpp:358-431.  Sampling stays on the host: it consumes ONE std::mt19937 stream in file
 // order (src/HMM.cpp:56), with libstdc++'s discrete_distribution, exactly like the reference.
 std::string HMM::SampleNaiveSequence() {
@@ -249,15 +335,7 @@ std::string HMM::SampleNaiveSequence() {
     cache_forward_ = false;
   }
   naive_seq_samp_.assign(msa_.cols(), 'N');
-  if (!sampling_lists_) {
-    sampling_lists_.reset(new SamplingLists());
-    sampling_lists_->vd_germ = ColumnLists::Build(vd_junction_dgerm_transition_);
-    sampling_lists_->vd_junction = ColumnLists::Build(vd_junction_transition_);
-    if (locus_ == "igh") {
-      sampling_lists_->dj_germ = ColumnLists::Build(dj_junction_jgerm_transition_);
-      sampling_lists_->dj_junction = ColumnLists::Build(dj_junction_transition_);
-    }
-  }
+  EnsureSamplingLists();
   const SamplingLists& sl = *sampling_lists_;
   SampleInitialState();
   if (locus_ == "igh") {

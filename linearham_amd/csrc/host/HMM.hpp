@@ -102,6 +102,35 @@ class HMM {
   void InitializeStateSpace();
   void InitializeTransition();
 
+  void EnsureSamplingLists();
+
+ public:
+  /// Everything one naive-sequence sample touches, outside the HMM object: RunPipeline's worker threads each own
+  /// one and sample different rows of the table at the same time (the HMM itself is only read).
+  struct RowSampler {
+    VectorXd vgerm_forward, dgerm_forward, jgerm_forward;
+    MatrixXd vd_junction_forward, dj_junction_forward;
+    std::vector<int> vd_scatter, dj_scatter;
+    std::discrete_distribution<int> distr;
+    std::string naive_seq;
+    std::string vgerm_state_str, dgerm_state_str, jgerm_state_str;
+    int vgerm_state_ind = 0, vgerm_left_del = 0, vgerm_right_del = 0;
+    int dgerm_state_ind = 0, dgerm_left_del = 0, dgerm_right_del = 0;
+    int jgerm_state_ind = 0, jgerm_left_del = 0, jgerm_right_del = 0;
+    std::vector<std::string> vd_junction_state_strs, dj_junction_state_strs;
+    std::vector<int> vd_junction_state_inds, dj_junction_state_inds;
+    std::string vgerm_left_insertion, vd_junction_insertion, dj_junction_insertion, jgerm_right_insertion;
+  };
+  /// HMM::SampleNaiveSequence (src/HMM.cpp:358-431) on the compact forward arrays `fwd` of one evaluation
+  /// (lh_eval_outputs.forward), drawing from `rng`; const, safe to call from several threads with distinct
+  /// samplers.  EnsureSamplingLists() must have run.
+  void SampleRow(RowSampler& s, const double* fwd, std::mt19937& rng) const;
+  /// std::mt19937 outputs one SampleNaiveSequence consumes: every draw of a discrete_distribution over two or
+  /// more weights takes one generate_canonical<double, 53> = two outputs, and the number of draws per sample is
+  /// fixed by the family (one per germline region with more than one allele, one per junction site).
+  int RawDrawsPerSample() const;
+
+ protected:
   /// Runs the device forward pass if needed (pure virtual: the derived class knows how the
   /// emissions are produced) and unpacks the compact forward arrays into the dense members.
   virtual void RunForwardAlgorithm() = 0;

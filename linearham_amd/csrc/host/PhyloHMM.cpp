@@ -1,7 +1,11 @@
 #include "PhyloHMM.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <sstream>
 #include <thread>
@@ -259,27 +263,98 @@ void PhyloHMM::WriteOutputHeaders(std::ofstream& outfile) const {
   outfile << "JGene\tJ5pDel\tJ3pDel\tJFwkInsertion\n";
 }
 
+namespace {
+
+// operator<<(std::ostream&, double) with the stream's defaults = printf("%g")
+void AppendG(std::string& o, double v) {
+  char b[40];
+  const int n = std::snprintf(b, sizeof b, "%g", v);
+  o.append(b, (std::size_t)n);
+}
+void AppendInt(std::string& o, long long v) {
+  char b[24];
+  const int n = std::snprintf(b, sizeof b, "%lld", v);
+  o.append(b, (std::size_t)n);
+}
+
+}  // namespace
+
+// One line of the output table (src/PhyloHMM.cpp:288-327), from explicit pieces so that RunPipeline's worker
+// threads can format rows side by side.
+void PhyloHMM::FormatOutputLine(std::string& o, int iteration, double rb_loglikelihood, double prior, double alpha,
+                                const double* er, const double* pi, const std::string& tree, const double* sr,
+                                int num_rates, double lh_loglikelihood, const RowSampler& s) const {
+  AppendInt(o, iteration);
+  o.push_back('\t');
+  AppendG(o, rb_loglikelihood);
+  o.push_back('\t');
+  AppendG(o, prior);
+  o.push_back('\t');
+  AppendG(o, alpha);
+  o.push_back('\t');
+  for (int k = 0; k < 6; ++k) AppendG(o, er[k]), o.push_back('\t');
+  for (int k = 0; k < 4; ++k) AppendG(o, pi[k]), o.push_back('\t');
+  o += tree;
+  o.push_back('\t');
+  for (int k = 0; k < num_rates; ++k) AppendG(o, sr[k]), o.push_back('\t');
+  AppendG(o, lh_loglikelihood);
+  o.push_back('\t');
+  AppendG(o, lh_loglikelihood - rb_loglikelihood);
+  o.push_back('\t');
+  o += s.naive_seq;
+  o.push_back('\t');
+  o += s.vgerm_state_str;
+  o.push_back('\t');
+  AppendInt(o, s.vgerm_left_del);
+  o.push_back('\t');
+  AppendInt(o, s.vgerm_right_del);
+  o.push_back('\t');
+  o += s.vgerm_left_insertion;
+  o.push_back('\t');
+  o += s.vd_junction_insertion;
+  o.push_back('\t');
+  if (locus_ == "igh") {
+    o += s.dgerm_state_str;
+    o.push_back('\t');
+    AppendInt(o, s.dgerm_left_del);
+    o.push_back('\t');
+    AppendInt(o, s.dgerm_right_del);
+    o.push_back('\t');
+    o += s.dj_junction_insertion;
+    o.push_back('\t');
+  }
+  o += s.jgerm_state_str;
+  o.push_back('\t');
+  AppendInt(o, s.jgerm_left_del);
+  o.push_back('\t');
+  AppendInt(o, s.jgerm_right_del);
+  o.push_back('\t');
+  o += s.jgerm_right_insertion;
+  o.push_back('\n');
+}
+
 // src/PhyloHMM.cpp:288-327
 void PhyloHMM::WriteOutputLine(std::ofstream& outfile) const {
-  outfile << iteration_ << "\t" << rb_loglikelihood_ << "\t" << prior_ << "\t" << alpha_ << "\t";
-  for (auto er : er_) outfile << er << "\t";
-  for (auto pi : pi_) outfile << pi << "\t";
-  if (pending_newick_)
-    outfile << *pending_newick_ << "\t";  // exported by FlattenBatch's workers
-  else
-    outfile << ExportNewick(tree_, xmsa_labels_) << "\t";
-  for (auto sr : sr_) outfile << sr << "\t";
-  outfile << lh_loglikelihood_ << "\t" << logweight_ << "\t" << naive_sequence_ << "\t";
-  outfile << vgerm_state_str_samp_ << "\t" << vgerm_left_del_samp_ << "\t" << vgerm_right_del_samp_ << "\t"
-          << vgerm_left_insertion_samp_ << "\t";
-  if (locus_ == "igh") {
-    outfile << vd_junction_insertion_samp_ << "\t" << dgerm_state_str_samp_ << "\t" << dgerm_left_del_samp_ << "\t"
-            << dgerm_right_del_samp_ << "\t" << dj_junction_insertion_samp_ << "\t";
-  } else {
-    outfile << vd_junction_insertion_samp_ << "\t";
-  }
-  outfile << jgerm_state_str_samp_ << "\t" << jgerm_left_del_samp_ << "\t" << jgerm_right_del_samp_ << "\t"
-          << jgerm_right_insertion_samp_ << "\n";
+  RowSampler s;  // a view of the members the line is made of
+  s.naive_seq = naive_sequence_;
+  s.vgerm_state_str = vgerm_state_str_samp_;
+  s.vgerm_left_del = vgerm_left_del_samp_;
+  s.vgerm_right_del = vgerm_right_del_samp_;
+  s.vgerm_left_insertion = vgerm_left_insertion_samp_;
+  s.vd_junction_insertion = vd_junction_insertion_samp_;
+  s.dgerm_state_str = dgerm_state_str_samp_;
+  s.dgerm_left_del = dgerm_left_del_samp_;
+  s.dgerm_right_del = dgerm_right_del_samp_;
+  s.dj_junction_insertion = dj_junction_insertion_samp_;
+  s.jgerm_state_str = jgerm_state_str_samp_;
+  s.jgerm_left_del = jgerm_left_del_samp_;
+  s.jgerm_right_del = jgerm_right_del_samp_;
+  s.jgerm_right_insertion = jgerm_right_insertion_samp_;
+  std::string line;
+  FormatOutputLine(line, iteration_, rb_loglikelihood_, prior_, alpha_, er_.data(), pi_.data(),
+                   pending_newick_ ? *pending_newick_ : ExportNewick(tree_, xmsa_labels_), sr_.data(), (int)sr_.size(),
+                   lh_loglikelihood_, s);
+  outfile << line;
 }
 
 namespace {
@@ -312,81 +387,341 @@ std::vector<std::string> SplitTsv(const std::string& line) {
 
 }  // namespace
 
-// src/PhyloHMM.cpp:393-446.  The reference evaluates row by row; here the whole table is evaluated
-// on the GPU in batches, then naive sequences are sampled on the host strictly in file order (one
-// std::mt19937 stream, src/HMM.cpp:56) and the rows are written.
-void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& output_path, int num_rates) {
-  std::ifstream in(input_path);
-  if (!in) throw std::runtime_error("Can't open RevBayes output file " + input_path);
-  std::string line;
-  if (!std::getline(in, line)) throw std::runtime_error("Empty RevBayes output file " + input_path);
-  const std::vector<std::string> header = SplitTsv(line);
-  const char* names[15] = {"Iteration", "Likelihood", "Prior", "alpha", "er[1]", "er[2]", "er[3]", "er[4]",
-                           "er[5]",     "er[6]",      "pi[1]", "pi[2]", "pi[3]", "pi[4]", "tree"};
-  int col[15];
-  for (int k = 0; k < 15; ++k) {
-    const auto it = std::find(header.begin(), header.end(), names[k]);
-    if (it == header.end()) throw std::runtime_error(std::string("Missing column \"") + names[k] + "\" in " + input_path);
-    col[k] = (int)(it - header.begin());
-  }
-  struct Row {
-    int iteration;
-    double lik, prior;
-    TreeSample ts;
-  };
-  std::vector<Row> rows;
-  while (std::getline(in, line)) {
-    if (line.empty()) continue;
-    const std::vector<std::string> f = SplitTsv(line);
-    Row r;
-    auto get = [&](int k) -> const std::string& {
-      if (col[k] >= (int)f.size()) throw std::runtime_error("Too few columns in " + input_path);
-      return f[col[k]];
-    };
-    r.iteration = std::stoi(get(0));
-    r.lik = std::stod(get(1));
-    r.prior = std::stod(get(2));
-    r.ts.alpha = std::stod(get(3));
-    for (int k = 0; k < 6; ++k) r.ts.er.push_back(std::stod(get(4 + k)));
-    for (int k = 0; k < 4; ++k) r.ts.pi.push_back(std::stod(get(10 + k)));
-    r.ts.newick = get(14);
-    rows.push_back(std::move(r));
+// A RevBayes table held in memory: the rows are located once (no per-field strings) and handed to worker
+// threads; a field is converted where it is needed.
+struct PhyloHMM::TsvTable {
+  std::string buf;                                        // the file, NUL-terminated
+  std::vector<std::pair<std::size_t, std::size_t>> rows;  // data lines: offset and length (empty lines skipped)
+  std::vector<std::string> header;
+  int col[15];                                            // columns of RunPipeline's fifteen fields
+
+  static TsvTable Read(const std::string& path, const char* what) {
+    TsvTable t;
+    std::FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error(std::string("Can't open ") + what + " " + path);
+    std::fseek(f, 0, SEEK_END);
+    const long size = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    t.buf.resize(size > 0 ? (std::size_t)size : 0);
+    if (size > 0 && std::fread(&t.buf[0], 1, (std::size_t)size, f) != (std::size_t)size) {
+      std::fclose(f);
+      throw std::runtime_error("Can't read " + path);
+    }
+    std::fclose(f);
+    const char* p = t.buf.c_str();
+    const std::size_t n = t.buf.size();
+    std::size_t pos = 0;
+    bool first = true;
+    while (pos < n) {
+      const char* nl = static_cast<const char*>(std::memchr(p + pos, '\n', n - pos));
+      const std::size_t end = nl ? (std::size_t)(nl - p) : n;
+      std::size_t len = end - pos;
+      if (len && p[pos + len - 1] == '\r') --len;
+      if (first) {
+        t.header = SplitTsv(std::string(p + pos, len));
+        first = false;
+      } else if (len) {
+        t.rows.push_back({pos, len});
+      }
+      pos = end + 1;
+    }
+    if (first) throw std::runtime_error(std::string("Empty ") + what + " " + path);
+    return t;
   }
 
+  void Locate(const char* const* names, int n, int* out, const std::string& path) const {
+    for (int k = 0; k < n; ++k) {
+      const auto it = std::find(header.begin(), header.end(), names[k]);
+      if (it == header.end()) throw std::runtime_error(std::string("Missing column \"") + names[k] + "\" in " + path);
+      out[k] = (int)(it - header.begin());
+    }
+  }
+
+  // Field boundaries of row r (begin offsets of every field and the end of the row); a quoted field keeps its
+  // quotes here and loses them in Field().  `quoted` tells whether the row holds a double quote at all.
+  void Split(std::size_t r, std::vector<std::size_t>& starts, bool* quoted) const {
+    const char* p = buf.c_str() + rows[r].first;
+    const std::size_t len = rows[r].second;
+    starts.clear();
+    starts.push_back(0);
+    *quoted = std::memchr(p, '"', len) != nullptr;
+    if (!*quoted) {
+      std::size_t pos = 0;
+      while (const char* tab = static_cast<const char*>(std::memchr(p + pos, '\t', len - pos))) {
+        pos = (std::size_t)(tab - p) + 1;
+        starts.push_back(pos);
+      }
+    } else {
+      bool in = false;
+      for (std::size_t i = 0; i < len; ++i) {
+        if (p[i] == '"')
+          in = !in;
+        else if (p[i] == '\t' && !in)
+          starts.push_back(i + 1);
+      }
+    }
+    starts.push_back(len + 1);
+  }
+};
+
+namespace {
+
+struct FieldView {
+  const char* p;
+  std::size_t n;
+};
+
+}  // namespace
+
+// The part of FlattenBatch that also reads its rows from the table: rows [r0, r1) are parsed (numbers, tree),
+// rooted at naive's neighbour and scheduled by `n_threads` workers straight into the device arrays.
+struct PhyloHMM::TableBatch {
+  DeviceBatch dev;
+  std::vector<int> iteration;
+  std::vector<double> lik, prior;
+  std::vector<std::string> exported;  // per row: the output table's tree column (with_export)
+};
+
+PhyloHMM::TableBatch PhyloHMM::FlattenTable(const TsvTable& t, std::size_t r0, std::size_t r1, bool with_export,
+                                            bool with_scalars, const std::string& path) const {
+  const auto t_begin = std::chrono::steady_clock::now();
+  TableBatch tb;
+  DeviceBatch& b = tb.dev;
+  const int T = (int)xmsa_labels_.size();
+  const std::size_t m = r1 - r0;
+  b.n = (int)m;
+  b.n_tips = T;
+  b.ops.resize(m * (std::size_t)(T - 2) * 4);
+  b.brlen.resize(m * (std::size_t)(2 * T - 2));
+  b.er.resize(m * 6);
+  b.pi.resize(m * 4);
+  b.alpha.resize(m);
+  if (with_export) tb.exported.resize(m);
+  if (with_scalars) {
+    tb.iteration.resize(m);
+    tb.lik.resize(m);
+    tb.prior.resize(m);
+  }
+  const LabelIndex labels(xmsa_labels_);
+  auto work = [&](std::size_t lo, std::size_t hi, int* max_depth) {
+    NewickScratch scratch;
+    std::vector<std::size_t> starts;
+    std::vector<int32_t> children(2 * (std::size_t)(T - 2));
+    std::string unq;
+    for (std::size_t i = lo; i < hi; ++i) {
+      bool quoted = false;
+      t.Split(r0 + i, starts, &quoted);
+      const char* row = t.buf.c_str() + t.rows[r0 + i].first;
+      auto field = [&](int k) {
+        const int c = t.col[k];
+        if (c + 1 >= (int)starts.size()) throw std::runtime_error("Too few columns in " + path);
+        FieldView f{row + starts[c], starts[c + 1] - 1 - starts[c]};
+        if (quoted && f.n >= 2 && f.p[0] == '"' && f.p[f.n - 1] == '"') f = FieldView{f.p + 1, f.n - 2};
+        return f;
+      };
+      auto number = [&](int k) {
+        const FieldView f = field(k);
+        const char* end = nullptr;
+        const double v = ParseDouble(f.p, &end);
+        if (end == f.p || end > f.p + f.n) throw std::runtime_error("Bad number in column \"" + t.header[t.col[k]] + "\" of " + path);
+        return v;
+      };
+      if (with_scalars) {
+        tb.iteration[i] = (int)number(0);
+        tb.lik[i] = number(1);
+        tb.prior[i] = number(2);
+      }
+      b.alpha[i] = number(3);
+      for (int k = 0; k < 6; ++k) b.er[i * 6 + k] = number(4 + k);
+      for (int k = 0; k < 4; ++k) b.pi[i * 4 + k] = number(10 + k);
+      FieldView tree = field(14);
+      if (quoted && std::memchr(tree.p, '"', tree.n)) {  // doubled quotes inside a quoted field (never seen; kept right)
+        unq.clear();
+        for (std::size_t q = 0; q < tree.n; ++q) {
+          unq.push_back(tree.p[q]);
+          if (tree.p[q] == '"' && q + 1 < tree.n && tree.p[q + 1] == '"') ++q;
+        }
+        tree = FieldView{unq.c_str(), unq.size()};
+      }
+      int32_t root = -1, depth = 0;
+      ParseNewickInto(tree.p, tree.n, labels, EPS, scratch, children.data(), &root,
+                      b.brlen.data() + i * (std::size_t)(2 * T - 2), with_export ? &tb.exported[i] : nullptr);
+      CheckHip(lh_schedule_tree(T, children.data(), root, b.ops.data() + i * (std::size_t)(T - 2) * 4, &depth),
+               "lh_schedule_tree");
+      *max_depth = std::max(*max_depth, (int)depth);
+    }
+  };
+  const int hw = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+  const int n_threads = (int)std::max<std::size_t>(1, std::min<std::size_t>(hw, m / 32));
+  std::vector<std::thread> pool;
+  std::vector<int> depths(n_threads, 0);
+  std::vector<std::exception_ptr> errors(n_threads);
+  for (int w = 0; w < n_threads; ++w) {
+    const std::size_t lo = m * w / n_threads, hi = m * (w + 1) / n_threads;
+    auto body = [&, w, lo, hi] {
+      try {
+        work(lo, hi, &depths[w]);
+      } catch (...) {
+        errors[w] = std::current_exception();
+      }
+    };
+    if (n_threads == 1)
+      body();
+    else
+      pool.emplace_back(body);
+  }
+  for (std::thread& th : pool) th.join();
+  for (const std::exception_ptr& e : errors)
+    if (e) std::rethrow_exception(e);  // the first failing row range, in file order
+  for (int d : depths) b.max_depth = std::max(b.max_depth, d);
+  if (std::getenv("LH_PIPELINE_TIMING"))
+    std::fprintf(stderr, "[FlattenTable] %zu rows on %d threads: %.3f s\n", m, n_threads,
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  return tb;
+}
+
+PhyloHMM::DeviceBatch PhyloHMM::FlattenTsv(const std::string& path, int* n_rows) const {
+  const auto t0 = std::chrono::steady_clock::now();
+  TsvTable t = TsvTable::Read(path, "RevBayes output file");
+  if (std::getenv("LH_PIPELINE_TIMING"))
+    std::fprintf(stderr, "[FlattenTsv] read + line index %.3f s\n",
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  const char* names[15] = {"alpha", "alpha", "alpha", "alpha", "er[1]", "er[2]", "er[3]", "er[4]",
+                           "er[5]", "er[6]",  "pi[1]", "pi[2]", "pi[3]", "pi[4]", "tree"};
+  t.Locate(names, 15, t.col, path);
+  if (t.rows.empty()) throw std::runtime_error("no rows in table");
+  *n_rows = (int)t.rows.size();
+  return FlattenTable(t, 0, t.rows.size(), false, false, path).dev;
+}
+
+// src/PhyloHMM.cpp:393-446.  The reference evaluates, samples and writes row by row on one core.  Here the table
+// is read once, and per batch of rows: worker threads parse and schedule the trees, the GPU evaluates the batch,
+// and worker threads draw the naive sequences and format the output lines, which are written in file order.
+// Sampling consumes ONE std::mt19937 stream in file order (src/HMM.cpp:56); a sample takes a fixed number of
+// engine outputs (HMM::RawDrawsPerSample), so the worker that starts at row r copies the engine and skips
+// r samples' worth of outputs: every row sees exactly the numbers it would see in the serial loop (checked on
+// the first row of every run, and by the seed-0 goldens).  The last row goes through the object's own members,
+// which are then in the state the reference's loop leaves behind.
+void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& output_path, int num_rates) {
+  const bool timing = std::getenv("LH_PIPELINE_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double>(b - a).count();
+  };
+  const auto t_start = now();
+  TsvTable table = TsvTable::Read(input_path, "RevBayes output file");
+  const char* names[15] = {"Iteration", "Likelihood", "Prior", "alpha", "er[1]", "er[2]", "er[3]", "er[4]",
+                           "er[5]",     "er[6]",      "pi[1]", "pi[2]", "pi[3]", "pi[4]", "tree"};
+  table.Locate(names, 15, table.col, input_path);
+  const std::size_t N = table.rows.size();
+  const auto t_read = now();
+
   CreateFamily();
+  EnsureSamplingLists();
   std::ofstream outfile(output_path);
   if (!outfile) throw std::runtime_error("Can't open output file " + output_path);
   er_.assign(6, 0.0);
   pi_.assign(4, 0.0);
   sr_.assign(num_rates, 0.0);
   num_rates_ = num_rates;
-  const std::size_t kBatch = 1024;
   const std::size_t FS = lh_forward_size(family_), SS = lh_scaler_size(family_);
-  int line_ind = 0;
-  for (std::size_t off = 0; off < rows.size(); off += kBatch) {
-    const std::size_t m = std::min(kBatch, rows.size() - off);
-    std::vector<TreeSample> samples;
-    for (std::size_t i = 0; i < m; ++i) samples.push_back(rows[off + i].ts);
-    std::vector<TreeArrays> trees;
-    std::vector<std::string> exported;
-    const DeviceBatch b = FlattenBatch(samples, &trees, &exported);
-    std::vector<double> ll(m), rates(m * num_rates), fwd(m * FS);
-    std::vector<int32_t> sco(m * SS);
+  const int T = (int)xmsa_labels_.size();
+  const int raw_per_sample = RawDrawsPerSample();
+  const std::size_t kBatch = 4096;
+  double t_flat = 0, t_eval = 0, t_samp = 0, t_write = 0;
+  std::vector<double> ll, rates, fwd;
+  std::vector<int32_t> sco;
+  bool header_written = false;
+  for (std::size_t off = 0; off < N; off += kBatch) {
+    const std::size_t m = std::min(kBatch, N - off);
+    const auto t0 = now();
+    TableBatch tb = FlattenTable(table, off, off + m, true, true, input_path);
+    const DeviceBatch& b = tb.dev;
+    const auto t1 = now();
+    ll.resize(m);
+    rates.resize(m * num_rates);
+    fwd.resize(m * FS);
+    sco.resize(m * SS);
     lh_eval_outputs outs{rates.data(), nullptr, fwd.data(), sco.data()};
     CheckHip(lh_eval_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(),
                            b.pi.data(), b.alpha.data(), num_rates, ll.data(), &outs),
              "lh_eval_batch");
-    for (std::size_t i = 0; i < m; ++i) {
-      const Row& r = rows[off + i];
-      iteration_ = r.iteration;
-      rb_loglikelihood_ = r.lik;
-      prior_ = r.prior;
-      alpha_ = r.ts.alpha;
-      er_ = r.ts.er;
-      pi_ = r.ts.pi;
-      tree_ = std::move(trees[i]);
+    const auto t2 = now();
+    // rows of this batch except the table's very last one: sampled and formatted by the workers
+    const std::size_t m_par = (off + m == N) ? m - 1 : m;
+    const int hw = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    const int n_threads = (int)std::max<std::size_t>(1, std::min<std::size_t>(hw, m_par / 8));
+    std::vector<std::string> chunks(n_threads);
+    std::vector<std::exception_ptr> errors(n_threads);
+    auto sample_rows = [&](int w, std::size_t lo, std::size_t hi) {
+      try {
+        RowSampler s;
+        std::mt19937 rng = rng_;
+        rng.discard((unsigned long long)(off + lo) * (unsigned long long)raw_per_sample);
+        std::string& o = chunks[w];
+        o.reserve((hi - lo) * (tb.exported.empty() ? 512 : tb.exported[lo].size() + 1024));
+        for (std::size_t i = lo; i < hi; ++i) {
+          if (off + i == 0) {  // the bookkeeping above rests on this count: check it where it is cheap
+            std::mt19937 expect = rng;
+            SampleRow(s, fwd.data() + i * FS, rng);
+            expect.discard((unsigned long long)raw_per_sample);
+            if (!(expect == rng)) throw std::runtime_error("RunPipeline: a sample consumed an unexpected number of random numbers");
+          } else {
+            SampleRow(s, fwd.data() + i * FS, rng);
+          }
+          FormatOutputLine(o, tb.iteration[i], tb.lik[i], tb.prior[i], b.alpha[i], b.er.data() + i * 6,
+                           b.pi.data() + i * 4, tb.exported[i], rates.data() + i * num_rates, num_rates, ll[i], s);
+        }
+      } catch (...) {
+        errors[w] = std::current_exception();
+      }
+    };
+    {
+      std::vector<std::thread> pool;
+      for (int w = 0; w < n_threads; ++w) {
+        const std::size_t lo = m_par * w / n_threads, hi = m_par * (w + 1) / n_threads;
+        if (n_threads == 1)
+          sample_rows(w, lo, hi);
+        else
+          pool.emplace_back(sample_rows, w, lo, hi);
+      }
+      for (std::thread& th : pool) th.join();
+      for (const std::exception_ptr& e : errors)
+        if (e) std::rethrow_exception(e);
+    }
+    const auto t3 = now();
+    if (!header_written) {
+      WriteOutputHeaders(outfile);
+      header_written = true;
+    }
+    for (const std::string& c : chunks) outfile.write(c.data(), (std::streamsize)c.size());
+    if (m_par < m) {
+      // the last row of the table, through the members (as every row goes in the reference)
+      const std::size_t i = m - 1;
+      rng_.discard((unsigned long long)(N - 1) * (unsigned long long)raw_per_sample);
+      iteration_ = tb.iteration[i];
+      rb_loglikelihood_ = tb.lik[i];
+      prior_ = tb.prior[i];
+      alpha_ = b.alpha[i];
+      er_.assign(b.er.begin() + i * 6, b.er.begin() + (i + 1) * 6);
+      pi_.assign(b.pi.begin() + i * 4, b.pi.begin() + (i + 1) * 4);
+      tree_.n_tips = T;
+      tree_.children.resize(2 * (std::size_t)(T - 2));
+      tree_.brlen.assign(b.brlen.begin() + i * (2 * (std::size_t)T - 2), b.brlen.begin() + (i + 1) * (2 * (std::size_t)T - 2));
+      {  // the tree's arrays again (the batch keeps schedules, not child lists)
+        const LabelIndex labels(xmsa_labels_);
+        NewickScratch scratch;
+        const std::pair<std::size_t, std::size_t> row = table.rows[off + i];
+        std::vector<std::size_t> starts;
+        bool quoted = false;
+        table.Split(off + i, starts, &quoted);
+        const int c = table.col[14];
+        std::string text(table.buf.c_str() + row.first + starts[c], starts[c + 1] - 1 - starts[c]);
+        if (quoted) text = SplitTsv(std::string(table.buf.c_str() + row.first, row.second)).at(c);
+        tree_ = ParseNewick(text, xmsa_labels_, EPS, true);
+      }
       have_tree_ = true;
-      pending_newick_ = &exported[i];
+      pending_newick_ = &tb.exported[i];
       sr_.assign(rates.begin() + i * num_rates, rates.begin() + (i + 1) * num_rates);
       pending_forward_.assign(fwd.begin() + i * FS, fwd.begin() + (i + 1) * FS);
       pending_scalers_.assign(sco.begin() + i * SS, sco.begin() + (i + 1) * SS);
@@ -395,13 +730,21 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       lh_loglikelihood_ = LogLikelihood();
       logweight_ = lh_loglikelihood_ - rb_loglikelihood_;
       naive_sequence_ = SampleNaiveSequence();
-      if (line_ind == 0) WriteOutputHeaders(outfile);
       WriteOutputLine(outfile);
       pending_newick_ = nullptr;
-      line_ind += 1;
     }
+    const auto t4 = now();
+    t_flat += secs(t0, t1);
+    t_eval += secs(t1, t2);
+    t_samp += secs(t2, t3);
+    t_write += secs(t3, t4);
   }
   outfile.close();
+  if (timing)
+    std::fprintf(stderr,
+                 "[RunPipeline] %zu rows: read %.3f s, family %.3f s, parse+schedule %.3f s, device (incl. copies) %.3f s, "
+                 "sample+format %.3f s, write %.3f s\n",
+                 N, secs(t_start, t_read), 0.0, t_flat, t_eval, t_samp, t_write);
 }
 
 // scripts/run_bootstrap_asr_ess.R:86-101: the tree rooted on the naive branch (the added root node sits at

@@ -46,6 +46,11 @@ class PhyloHMM : public HMM {
   void RunForwardAlgorithm() override;
   void WriteOutputHeaders(std::ofstream& outfile) const;
   void WriteOutputLine(std::ofstream& outfile) const;
+  void FormatOutputLine(std::string& line, int iteration, double rb_loglikelihood, double prior, double alpha,
+                        const double* er, const double* pi, const std::string& tree, const double* sr, int num_rates,
+                        double lh_loglikelihood, const RowSampler& sample) const;
+  struct TsvTable;
+  struct TableBatch;
 
  public:
   PhyloHMM(const std::string& yaml_path, int cluster_ind, const std::string& hmm_param_dir, int seed);
@@ -112,6 +117,8 @@ class PhyloHMM : public HMM {
   /// same worker threads (RunPipeline needs both per row and would otherwise redo them one by one).
   DeviceBatch FlattenBatch(const std::vector<TreeSample>& samples, std::vector<TreeArrays>* trees = nullptr,
                            std::vector<std::string>* exported = nullptr) const;
+  /// The whole RevBayes table `path` as device inputs (rows parsed and scheduled by worker threads).
+  DeviceBatch FlattenTsv(const std::string& path, int* n_rows) const;
   lh_family* family() {
     CreateFamily();
     return family_;
@@ -120,6 +127,10 @@ class PhyloHMM : public HMM {
   /// where the reference's equalisation overflows or its exp underflows; off by default.
   void SetExtendedRange(bool on);
   int n_xmsa() const { return xmsa_.cols(); }
+
+ private:
+  TableBatch FlattenTable(const TsvTable& table, std::size_t r0, std::size_t r1, bool with_export, bool with_scalars,
+                          const std::string& path) const;
 };
 
 typedef std::shared_ptr<PhyloHMM> PhyloHMMPtr;

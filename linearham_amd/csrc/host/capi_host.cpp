@@ -1,6 +1,7 @@
 // Test/bench-facing C entry points of liblinearham_host.so: construct the C++ host classes and dump
 // their accessors as JSON so that the pytest suite can compare them with the reference's goldens
 // (test/test.cpp) -- the role the Catch binary plays upstream.
+#include <cmath>
 #include <cstring>
 #include <iomanip>
 #include <sstream>
@@ -264,42 +265,13 @@ int lhh_phylo_flatten_tsv(void* h, const char* tsv_path, int n, int32_t* ops, do
                           int need_family, void** family) {
   return Guard([&] {
     PhyloHMM& p = dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h));
-    std::ifstream in(tsv_path);
-    if (!in) throw std::runtime_error(std::string("Can't open ") + tsv_path);
-    std::string line;
-    std::getline(in, line);
-    std::vector<std::string> header;
-    {
-      std::stringstream ss(line);
-      std::string f;
-      while (std::getline(ss, f, '\t')) header.push_back(f);
-    }
-    auto colidx = [&](const std::string& name) {
-      for (std::size_t i = 0; i < header.size(); ++i)
-        if (header[i] == name) return (int)i;
-      throw std::runtime_error("Missing column " + name);
-    };
-    const int c_alpha = colidx("alpha"), c_tree = colidx("tree");
-    int c_er[6], c_pi[4];
-    for (int k = 0; k < 6; ++k) c_er[k] = colidx("er[" + std::to_string(k + 1) + "]");
-    for (int k = 0; k < 4; ++k) c_pi[k] = colidx("pi[" + std::to_string(k + 1) + "]");
-    std::vector<PhyloHMM::TreeSample> rows;
-    while (std::getline(in, line)) {
-      if (line.empty()) continue;
-      std::vector<std::string> f;
-      std::stringstream ss(line);
-      std::string x;
-      while (std::getline(ss, x, '\t')) f.push_back(x);
-      PhyloHMM::TreeSample ts;
-      ts.alpha = std::stod(f.at(c_alpha));
-      for (int k = 0; k < 6; ++k) ts.er.push_back(std::stod(f.at(c_er[k])));
-      for (int k = 0; k < 4; ++k) ts.pi.push_back(std::stod(f.at(c_pi[k])));
-      ts.newick = f.at(c_tree);
-      rows.push_back(ts);
-    }
-    if (rows.empty()) throw std::runtime_error("no rows in table");
-    *n_rows_in_file = (int)rows.size();
-    const PhyloHMM::DeviceBatch b = p.FlattenBatch(rows);
+    int n_file = 0;
+    const PhyloHMM::DeviceBatch b = p.FlattenTsv(tsv_path, &n_file);
+    *n_rows_in_file = n_file;
+    struct {
+      std::size_t n;
+      std::size_t size() const { return n; }
+    } rows{(std::size_t)n_file};
     *n_tips = b.n_tips;
     *max_depth = b.max_depth;
     *family = need_family ? p.family() : nullptr;
@@ -362,6 +334,51 @@ int lhh_selftest_sparse_draw(int seed, int trials) {
     const int sparse = DrawDiscreteSparse(b, idx.data(), nz.data(), (int)idx.size(), size);
     if (dense != sparse || a != b) ++bad;
   }
+  return bad;
+}
+
+// Self-test of ParseDouble / AppendFixed6 (newick.hpp) against strtod / printf("%f"): random values in the forms
+// a RevBayes table and libpll's exporter produce, plus exact ties of the sixth decimal.  Returns the mismatches.
+int lhh_selftest_numbers(int seed, int trials) {
+  std::mt19937_64 rng((uint64_t)seed);
+  int bad = 0;
+  char buf[96];
+  auto check_parse = [&](const char* s) {
+    const char* e1 = nullptr;
+    char* e2 = nullptr;
+    const double a = ParseDouble(s, &e1), b = std::strtod(s, &e2);
+    if (std::memcmp(&a, &b, sizeof a) != 0 || e1 != e2) ++bad;
+  };
+  auto check_fixed = [&](double v) {
+    std::string o;
+    AppendFixed6(o, v);
+    std::snprintf(buf, sizeof buf, "%f", v);
+    if (o != buf) ++bad;
+  };
+  const char* fixed_cases[] = {"0", "0.0", "1e-06", "1E-6", "0.0078125", ".5", "5.", "12345678901234567890", "1e400",
+                               "0.1e-320", "123.456e+10", "7e", "1e+", "0.30000000000000004", "9007199254740993",
+                               "4.9e-324", "x", "", "-0.25", "+3.5e2:"};
+  for (const char* c : fixed_cases) check_parse(c);
+  for (int i = 0; i < trials; ++i) {
+    const double u = (double)(rng() >> 11) * 0x1p-53;
+    const int e = (int)(rng() % 14) - 9;
+    const double v = u * std::pow(10.0, e);
+    const char* fmts[] = {"%.6g", "%.8g", "%.10g", "%.17g", "%f", "%.12f", "%e"};
+    std::snprintf(buf, sizeof buf, fmts[rng() % 7], v);
+    check_parse(buf);
+    check_fixed(v);
+    // exact halves of the sixth decimal that are binary fractions: (2m + 1) * 15625 / 2^(7 + j)
+    const double tie = (double)(2 * (rng() % 4096) + 1) * 15625.0 * std::ldexp(1.0, -7 - (int)(rng() % 6)) / 15625.0 /
+                       15625.0 * 15625.0;
+    check_fixed(tie);
+    check_fixed((double)(rng() % 2000001) * 0.0078125);
+    check_fixed((double)(rng() % 1000) + 0.5e-6 * (double)(rng() % 3));
+  }
+  check_fixed(0.0078125);
+  check_fixed(0.0);
+  check_fixed(1e-7);
+  check_fixed(4e9);
+  check_fixed(123456789.9999995);
   return bad;
 }
 

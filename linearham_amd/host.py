@@ -140,10 +140,7 @@ class PhyloHMM(_HMM):
         n_tips, depth, n_rows = C.c_int(), C.c_int(), C.c_int()
         fam = C.c_void_p()
         flag = C.c_int(1 if need_family else 0)
-        _check(self.lib.lhh_phylo_flatten_tsv(self.h, tsv_path.encode(), 0, None, None, None, None, None,
-                                              C.byref(n_tips), C.byref(depth), C.byref(n_rows), flag,
-                                              C.byref(fam)))
-        T = n_tips.value
+        T = self.sizes()["n_tips"]
         ops = np.zeros((n, T - 2, 4), dtype=np.int32)
         brlen = np.zeros((n, 2 * T - 2))
         er, pi, alpha = np.zeros((n, 6)), np.zeros((n, 4)), np.zeros(n)
@@ -154,5 +151,6 @@ class PhyloHMM(_HMM):
                                               p(brlen, C.c_double), p(er, C.c_double), p(pi, C.c_double),
                                               p(alpha, C.c_double), C.byref(n_tips), C.byref(depth),
                                               C.byref(n_rows), flag, C.byref(fam)))
+        assert n_tips.value == T
         return dict(ops=ops, brlen=brlen, er=er, pi=pi, alpha=alpha, n_tips=T, max_depth=depth.value,
                     n_rows=n_rows.value, family=fam.value)

@@ -76,13 +76,15 @@ def test_phylo_hmm(goldens, data_dir, case, params, R):
             assert s[k] == want[k], k
 
 
-@pytest.mark.parametrize("locus", ["igh", "igk"])
-def test_run_pipeline_matches_oracle(tmp_path, locus):
+@pytest.mark.parametrize("locus,n_rows", [("igh", 9), ("igk", 9), ("igh", 150)])
+def test_run_pipeline_matches_oracle(tmp_path, locus, n_rows):
     """PhyloHMM::RunPipeline (src/PhyloHMM.cpp:393-446) on a synthetic RevBayes table: batched GPU
-    evaluation + in-order host sampling must reproduce the row-by-row oracle, including the RNG stream."""
+    evaluation + host sampling must reproduce the row-by-row oracle, including the RNG stream -- also when the
+    rows are sampled by several worker threads, each on a copy of the engine advanced to its first row (150
+    rows: every core of the box samples a share)."""
     from tools import synth_family as sf
     out = str(tmp_path / "fam")
-    sf.generate(sf.Spec.small(n_samples=9, locus=locus), out)
+    sf.generate(sf.Spec.small(n_samples=n_rows, locus=locus), out)
     yaml_path, pdir, tsv = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params"), os.path.join(out, "trees.tsv")
     h = host.PhyloHMM(yaml_path, 0, pdir, 3)
     res = os.path.join(out, "lh.tsv")
@@ -181,10 +183,7 @@ def test_run_asr_matches_oracle(tmp_path, locus):
 def test_cli_compute_logl(data_dir):
     """`linearham --compute-logl` prints the log-likelihood with 6 significant digits
     (src/linearham.cpp:341-348)."""
-    exe = os.path.join(os.path.dirname(host.host_library_path()), "linearham")
-    if not os.path.exists(exe):   # a built artefact (not in history): g++ is enough to make it
-        from linearham_amd import build as lb
-        lb.build_host(verbose=False)
+    exe = _exe()
     cmd = [exe, "--compute-logl", "--yaml-path", os.path.join(data_dir, "phylo_hmm_input.yaml"), "--cluster-ind", "0",
            "--hmm-param-dir", os.path.join(data_dir, "hmm_params"), "--newick-path",
            os.path.join(data_dir, "newton.tree"), "--num-rates", "4"]
@@ -196,6 +195,62 @@ def test_cli_compute_logl(data_dir):
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip() == "-75.8136"
     bad = subprocess.run([exe, "--nonsense", "--yaml-path", "x"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "ERROR:" in bad.stderr
+
+
+def _exe():
+    exe = os.path.join(os.path.dirname(host.host_library_path()), "linearham")
+    if not os.path.exists(exe):   # a built artefact (not in history): g++ is enough to make it
+        from linearham_amd import build as lb
+        lb.build_host(verbose=False)
+    return exe
+
+
+def test_cli_sample(goldens, data_dir):
+    """`linearham --sample` (src/linearham.cpp:353-356): N naive sequences, one per line; the first with seed 0 is
+    the reference's golden draw (test/test.cpp:888-910), the whole list what the library's own calls give."""
+    want = goldens["PhyloHMM:phylo_hmm_input"]["vars"]
+    yaml_path, pdir = os.path.join(data_dir, "phylo_hmm_input.yaml"), os.path.join(data_dir, "hmm_params")
+    tree = os.path.join(data_dir, "newton.tree")
+    cmd = [_exe(), "--sample", "--yaml-path", yaml_path, "--cluster-ind", "0", "--hmm-param-dir", pdir, "--newick-path",
+           tree, "--num-rates", "4", "--seed", "0", "--N", "5"]
+    for x in ER:
+        cmd += ["--er", str(x)]
+    for x in PI:
+        cmd += ["--pi", str(x)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = out.stdout.split()
+    assert len(got) == 5 and got[0] == want["naive_seq_samp"]
+    h = host.PhyloHMM(yaml_path, 0, pdir, 0)
+    h.initialize_phylo_parameters(tree, ER, PI, 1.0, 4)
+    h.initialize_phylo_emission()
+    assert got == [h.sample_naive_sequence() for _ in range(5)]
+
+
+def test_cli_pipeline(tmp_path):
+    """`linearham --pipeline` (src/linearham.cpp:390-422) writes, byte for byte, the table the library call writes
+    (which test_run_pipeline_matches_oracle pins to the oracle), and the extended-range switch leaves a table the
+    reference evaluates without overflow unchanged."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_samples=40, seed=17), out)
+    yaml_path, pdir, tsv = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params"), os.path.join(out, "trees.tsv")
+    lib_out, cli_out, ext_out = (os.path.join(out, n) for n in ("lib.tsv", "cli.tsv", "ext.tsv"))
+    host.PhyloHMM(yaml_path, 0, pdir, 5).run_pipeline(tsv, lib_out, 4)
+    common = ["--yaml-path", yaml_path, "--cluster-ind", "0", "--hmm-param-dir", pdir, "--input-path", tsv,
+              "--num-rates", "4", "--seed", "5"]
+    r = subprocess.run([_exe(), "--pipeline"] + common + ["--output-path", cli_out], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert open(cli_out).read() == open(lib_out).read()
+    assert len(open(cli_out).read().splitlines()) == 41
+    r = subprocess.run([_exe(), "--pipeline"] + common + ["--output-path", ext_out, "--extended-range", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert open(ext_out).read() == open(lib_out).read()
+    bad = subprocess.run([_exe(), "--pipeline"] + common[:-4] + ["--input-path", tsv + ".missing", "--output-path",
+                                                                  cli_out], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "ERROR:" in bad.stderr
 
 
