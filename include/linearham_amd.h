@@ -106,6 +106,14 @@ typedef struct {
 const char* lh_last_error(void);
 int lh_device_count(void);
 
+/* Optional helpers for a host that wants its start-up and its copies off the critical path (no reference
+ * counterpart): lh_warmup() initialises the HIP runtime and the current device's context (callable from a side
+ * thread while the caller parses its inputs); lh_host_alloc / lh_host_free hand out page-locked host memory,
+ * which the host-pointer entry points copy to and from at full PCIe rate (any host pointer is accepted). */
+int lh_warmup(void);
+void* lh_host_alloc(size_t bytes);
+void lh_host_free(void* p);
+
 int lh_family_create(const lh_family_desc* desc, lh_family** out);
 void lh_family_destroy(lh_family* fam);
 

@@ -44,6 +44,7 @@ lh_junction JunctionTables::c() const {
 
 // src/HMM.cpp:27-63
 HMM::HMM(const std::string& yaml_path, int cluster_ind, const std::string& hmm_param_dir, int seed) {
+  StageTimer timer;
   yaml_lite::Node root = yaml_lite::LoadFile(yaml_path);
   try {
     locus_ = root["germline-info"]["locus"].as_string();
@@ -61,7 +62,9 @@ HMM::HMM(const std::string& yaml_path, int cluster_ind, const std::string& hmm_p
     throw std::runtime_error("Can't read one of \"flexbounds\", \"relpos\" from  " + yaml_path +
                              " . Check that \"linearham-info\" was written to the yaml file and is not null.");
   }
+  timer.Mark("cluster yaml");
   ggenes_ = CreateGermlineGeneMap(hmm_param_dir);
+  timer.Mark("germline parameter files");
   Require(!ggenes_.empty(), "no germline parameter files found in " + hmm_param_dir);
   alphabet_ = ggenes_.begin()->second.germ_ptr->alphabet() + "N";
   Require(locus_ == "igh" || locus_ == "igk" || locus_ == "igl", "locus must be igh, igk or igl");
@@ -70,7 +73,9 @@ HMM::HMM(const std::string& yaml_path, int cluster_ind, const std::string& hmm_p
   InitializeMsa();
   rng_.seed(seed);
   InitializeStateSpace();
+  timer.Mark("state space");
   InitializeTransition();
+  timer.Mark("transition matrices");
 }
 
 HMM::~HMM() {

@@ -6,7 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <exception>
+#include <functional>
+#include <mutex>
 #include <sstream>
 #include <thread>
 
@@ -125,7 +128,9 @@ void PhyloHMM::CreateFamily() {
   d.jpadding_transition = jpadding_transition_.data();
   d.vd = vd.c();
   if (igh) d.dj = dj.c();
+  StageTimer timer;
   CheckHip(lh_family_create(&d, &family_), "lh_family_create");
+  timer.Mark("lh_family_create (+ HIP init)");
 }
 
 // src/PhyloHMM.cpp:350-361
@@ -616,8 +621,11 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
   const std::size_t N = table.rows.size();
   const auto t_read = now();
 
+  StageTimer stage;
   CreateFamily();
+  stage.Mark("CreateFamily");
   EnsureSamplingLists();
+  stage.Mark("sampling column lists");
   std::ofstream outfile(output_path);
   if (!outfile) throw std::runtime_error("Can't open output file " + output_path);
   er_.assign(6, 0.0);
@@ -627,26 +635,111 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
   const std::size_t FS = lh_forward_size(family_), SS = lh_scaler_size(family_);
   const int T = (int)xmsa_labels_.size();
   const int raw_per_sample = RawDrawsPerSample();
-  const std::size_t kBatch = 4096;
-  double t_flat = 0, t_eval = 0, t_samp = 0, t_write = 0;
-  std::vector<double> ll, rates, fwd;
-  std::vector<int32_t> sco;
+  // Two stages, two batches in flight: a producer thread parses / schedules batch k + 1 and has the GPU
+  // evaluate it into one of two page-locked result slots while this thread's workers sample and format batch k.
+  const std::size_t kBatch = std::min<std::size_t>(2048, std::max<std::size_t>(N, 1));
+  struct Slot {
+    TableBatch tb;
+    double *ll = nullptr, *rates = nullptr, *fwd = nullptr;
+    int32_t* sco = nullptr;
+    std::size_t off = 0, m = 0;
+    int state = 0;  // 0 free, 1 filled
+  };
+  Slot slots[2];
+  std::mutex mu;
+  std::condition_variable cv;
+  std::exception_ptr producer_error;
+  bool cancel = false;  // the consumer gave up (error): the producer must not wait for a slot
+  double t_flat = 0, t_eval = 0, t_samp = 0, t_write = 0, t_wait = 0;
+  auto alloc_slot = [&](Slot& s) {
+    s.ll = static_cast<double*>(lh_host_alloc(sizeof(double) * kBatch));
+    s.rates = static_cast<double*>(lh_host_alloc(sizeof(double) * kBatch * num_rates));
+    s.fwd = static_cast<double*>(lh_host_alloc(sizeof(double) * kBatch * FS));
+    s.sco = static_cast<int32_t*>(lh_host_alloc(sizeof(int32_t) * kBatch * SS));
+    if (!s.ll || !s.rates || !s.fwd || !s.sco) throw std::runtime_error(lh_last_error());
+  };
+  auto free_slots = [&] {
+    for (Slot& s : slots) {
+      lh_host_free(s.ll);
+      lh_host_free(s.rates);
+      lh_host_free(s.fwd);
+      lh_host_free(s.sco);
+    }
+  };
+  std::thread producer([&] {
+    try {
+      int k = 0;
+      for (std::size_t off = 0; off < N; off += kBatch, k ^= 1) {
+        Slot& s = slots[k];
+        const std::size_t m = std::min(kBatch, N - off);
+        const auto t0 = now();
+        TableBatch tb = FlattenTable(table, off, off + m, true, true, input_path);
+        const auto t1 = now();
+        {
+          std::unique_lock<std::mutex> lock(mu);
+          cv.wait(lock, [&] { return s.state == 0 || cancel; });
+          if (cancel) return;
+        }
+        if (!s.ll) alloc_slot(s);
+        s.tb = std::move(tb);
+        s.off = off;
+        s.m = m;
+        const DeviceBatch& b = s.tb.dev;
+        lh_eval_outputs outs{s.rates, nullptr, s.fwd, s.sco};
+        const auto t2 = now();
+        CheckHip(lh_eval_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(),
+                               b.pi.data(), b.alpha.data(), num_rates, s.ll, &outs),
+                 "lh_eval_batch");
+        const auto t3 = now();
+        t_flat += secs(t0, t1);
+        t_eval += secs(t2, t3);
+        {
+          std::lock_guard<std::mutex> lock(mu);
+          s.state = 1;
+        }
+        cv.notify_all();
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lock(mu);
+      producer_error = std::current_exception();
+      cv.notify_all();
+    }
+  });
+  struct Joiner {  // the producer is stopped, joined and the slots are freed on every way out
+    std::thread& t;
+    std::function<void()> before, after;
+    ~Joiner() {
+      before();
+      if (t.joinable()) t.join();
+      after();
+    }
+  } joiner{producer,
+           [&] {
+             {
+               std::lock_guard<std::mutex> lock(mu);
+               cancel = true;
+             }
+             cv.notify_all();
+           },
+           free_slots};
+
   bool header_written = false;
-  for (std::size_t off = 0; off < N; off += kBatch) {
-    const std::size_t m = std::min(kBatch, N - off);
-    const auto t0 = now();
-    TableBatch tb = FlattenTable(table, off, off + m, true, true, input_path);
+  int k = 0;
+  for (std::size_t off = 0; off < N; off += kBatch, k ^= 1) {
+    Slot& slot = slots[k];
+    const auto tw = now();
+    {
+      std::unique_lock<std::mutex> lock(mu);
+      cv.wait(lock, [&] { return slot.state == 1 || producer_error; });
+      if (producer_error) std::rethrow_exception(producer_error);
+    }
+    const std::size_t m = slot.m;
+    const TableBatch& tb = slot.tb;
     const DeviceBatch& b = tb.dev;
-    const auto t1 = now();
-    ll.resize(m);
-    rates.resize(m * num_rates);
-    fwd.resize(m * FS);
-    sco.resize(m * SS);
-    lh_eval_outputs outs{rates.data(), nullptr, fwd.data(), sco.data()};
-    CheckHip(lh_eval_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(),
-                           b.pi.data(), b.alpha.data(), num_rates, ll.data(), &outs),
-             "lh_eval_batch");
+    const double *ll = slot.ll, *rates = slot.rates, *fwd = slot.fwd;
+    const int32_t* sco = slot.sco;
     const auto t2 = now();
+    t_wait += secs(tw, t2);
     // rows of this batch except the table's very last one: sampled and formatted by the workers
     const std::size_t m_par = (off + m == N) ? m - 1 : m;
     const int hw = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
@@ -663,14 +756,14 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
         for (std::size_t i = lo; i < hi; ++i) {
           if (off + i == 0) {  // the bookkeeping above rests on this count: check it where it is cheap
             std::mt19937 expect = rng;
-            SampleRow(s, fwd.data() + i * FS, rng);
+            SampleRow(s, fwd + i * FS, rng);
             expect.discard((unsigned long long)raw_per_sample);
             if (!(expect == rng)) throw std::runtime_error("RunPipeline: a sample consumed an unexpected number of random numbers");
           } else {
-            SampleRow(s, fwd.data() + i * FS, rng);
+            SampleRow(s, fwd + i * FS, rng);
           }
           FormatOutputLine(o, tb.iteration[i], tb.lik[i], tb.prior[i], b.alpha[i], b.er.data() + i * 6,
-                           b.pi.data() + i * 4, tb.exported[i], rates.data() + i * num_rates, num_rates, ll[i], s);
+                           b.pi.data() + i * 4, tb.exported[i], rates + i * num_rates, num_rates, ll[i], s);
         }
       } catch (...) {
         errors[w] = std::current_exception();
@@ -705,12 +798,7 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       alpha_ = b.alpha[i];
       er_.assign(b.er.begin() + i * 6, b.er.begin() + (i + 1) * 6);
       pi_.assign(b.pi.begin() + i * 4, b.pi.begin() + (i + 1) * 4);
-      tree_.n_tips = T;
-      tree_.children.resize(2 * (std::size_t)(T - 2));
-      tree_.brlen.assign(b.brlen.begin() + i * (2 * (std::size_t)T - 2), b.brlen.begin() + (i + 1) * (2 * (std::size_t)T - 2));
       {  // the tree's arrays again (the batch keeps schedules, not child lists)
-        const LabelIndex labels(xmsa_labels_);
-        NewickScratch scratch;
         const std::pair<std::size_t, std::size_t> row = table.rows[off + i];
         std::vector<std::size_t> starts;
         bool quoted = false;
@@ -722,9 +810,9 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       }
       have_tree_ = true;
       pending_newick_ = &tb.exported[i];
-      sr_.assign(rates.begin() + i * num_rates, rates.begin() + (i + 1) * num_rates);
-      pending_forward_.assign(fwd.begin() + i * FS, fwd.begin() + (i + 1) * FS);
-      pending_scalers_.assign(sco.begin() + i * SS, sco.begin() + (i + 1) * SS);
+      sr_.assign(rates + i * num_rates, rates + (i + 1) * num_rates);
+      pending_forward_.assign(fwd + i * FS, fwd + (i + 1) * FS);
+      pending_scalers_.assign(sco + i * SS, sco + (i + 1) * SS);
       pending_loglik_ = ll[i];
       cache_forward_ = true;
       lh_loglikelihood_ = LogLikelihood();
@@ -734,17 +822,21 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       pending_newick_ = nullptr;
     }
     const auto t4 = now();
-    t_flat += secs(t0, t1);
-    t_eval += secs(t1, t2);
     t_samp += secs(t2, t3);
     t_write += secs(t3, t4);
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      slot.state = 0;
+    }
+    cv.notify_all();
   }
+  (void)T;
   outfile.close();
   if (timing)
     std::fprintf(stderr,
-                 "[RunPipeline] %zu rows: read %.3f s, family %.3f s, parse+schedule %.3f s, device (incl. copies) %.3f s, "
-                 "sample+format %.3f s, write %.3f s\n",
-                 N, secs(t_start, t_read), 0.0, t_flat, t_eval, t_samp, t_write);
+                 "[RunPipeline] %zu rows: read %.3f s; producer: parse+schedule %.3f s, device (incl. copies) %.3f s; "
+                 "consumer: waiting %.3f s, sample+format %.3f s, write %.3f s; total %.3f s\n",
+                 N, secs(t_start, t_read), t_flat, t_eval, t_wait, t_samp, t_write, secs(t_start, now()));
 }
 
 // scripts/run_bootstrap_asr_ess.R:86-101: the tree rooted on the naive branch (the added root node sits at

@@ -1,5 +1,8 @@
 #include "VDJGermline.hpp"
 
+#include <exception>
+#include <thread>
+
 #include <dirent.h>
 
 #include <algorithm>
@@ -199,8 +202,14 @@ std::unordered_map<std::string, GermlineGene> CreateGermlineGeneMap(std::string 
   while ((e = readdir(dir)) != nullptr) files.push_back(e->d_name);
   closedir(dir);
   std::sort(files.begin(), files.end());
-  std::unordered_map<std::string, GermlineGene> ggenes;
-  std::string alphabet;
+  // which files are per-allele parameter files (src/VDJGermline.cpp:56,81)
+  struct Item {
+    std::string file, gname;
+    char seg;
+    GermlineGene ggene;
+    std::exception_ptr error;
+  };
+  std::vector<Item> items;
   for (const std::string& fn : files) {
     if (fn.size() < 10 || fn.compare(0, 2, "IG") != 0 || fn.compare(fn.size() - 5, 5, ".yaml") != 0) continue;
     const char locus = fn[2], seg = fn[3];
@@ -209,22 +218,46 @@ std::unordered_map<std::string, GermlineGene> CreateGermlineGeneMap(std::string 
     const std::string stem = fn.substr(0, fn.size() - 5);
     if (stem.find("_star_", 4) == std::string::npos) continue;
     if (seg == 'D' && (locus == 'K' || locus == 'L')) continue;
-    const std::string gname = FixGeneName(stem);
-    const yaml_lite::Node root = yaml_lite::LoadFile(hmm_param_dir + fn);
-    GermlineGene ggene;
-    if (seg == 'V') {
-      ggene.type = GermlineType::V;
-      ggene.germ_ptr.reset(new VGermline(root));
-    } else if (seg == 'D') {
-      ggene.type = GermlineType::D;
-      ggene.germ_ptr.reset(new DGermline(root));
-    } else {
-      ggene.type = GermlineType::J;
-      ggene.germ_ptr.reset(new JGermline(root));
+    items.push_back(Item{hmm_param_dir + fn, FixGeneName(stem), seg, GermlineGene(), nullptr});
+  }
+  // a full germline set is a few hundred files, each parsed independently: spread over the cores
+  auto load = [&](std::size_t lo, std::size_t hi) {
+    for (std::size_t i = lo; i < hi; ++i) {
+      Item& it = items[i];
+      try {
+        const yaml_lite::Node root = yaml_lite::LoadFile(it.file);
+        if (it.seg == 'V') {
+          it.ggene.type = GermlineType::V;
+          it.ggene.germ_ptr.reset(new VGermline(root));
+        } else if (it.seg == 'D') {
+          it.ggene.type = GermlineType::D;
+          it.ggene.germ_ptr.reset(new DGermline(root));
+        } else {
+          it.ggene.type = GermlineType::J;
+          it.ggene.germ_ptr.reset(new JGermline(root));
+        }
+      } catch (...) {
+        it.error = std::current_exception();
+      }
     }
-    if (alphabet.empty()) alphabet = ggene.germ_ptr->alphabet();
-    Require(alphabet == ggene.germ_ptr->alphabet(), "all germline alphabets must be identical");
-    ggenes.emplace(gname, ggene);
+  };
+  const std::size_t n_threads =
+      std::max<std::size_t>(1, std::min<std::size_t>(std::min(std::thread::hardware_concurrency(), 16u), items.size() / 8));
+  if (n_threads == 1) {
+    load(0, items.size());
+  } else {
+    std::vector<std::thread> pool;
+    for (std::size_t t = 0; t < n_threads; ++t)
+      pool.emplace_back(load, items.size() * t / n_threads, items.size() * (t + 1) / n_threads);
+    for (std::thread& th : pool) th.join();
+  }
+  std::unordered_map<std::string, GermlineGene> ggenes;
+  std::string alphabet;
+  for (Item& it : items) {  // file order, as the serial loop reported its first error
+    if (it.error) std::rethrow_exception(it.error);
+    if (alphabet.empty()) alphabet = it.ggene.germ_ptr->alphabet();
+    Require(alphabet == it.ggene.germ_ptr->alphabet(), "all germline alphabets must be identical");
+    ggenes.emplace(it.gname, it.ggene);
   }
   return ggenes;
 }

@@ -6,6 +6,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "PhyloHMM.hpp"
@@ -64,8 +65,17 @@ int main(int argc, char** argv) {
     const std::string hmm_param_dir = a.one("hmm-param-dir");
     const int seed = std::stoi(a.opt("seed", "0"));
     const int num_rates = std::stoi(a.opt("num-rates", "1"));
+    // the HIP runtime and the device context come up on a side thread while the parameter files are read
+    std::thread warmup([] { (void)lh_warmup(); });
+    struct Join {
+      std::thread& t;
+      ~Join() {
+        if (t.joinable()) t.join();
+      }
+    } join_warmup{warmup};
     linearham::PhyloHMMPtr phylo_hmm_ptr =
         std::make_shared<linearham::PhyloHMM>(yaml_path, cluster_ind, hmm_param_dir, seed);
+    warmup.join();
     // not in the reference: finite log-likelihoods where its scaling over/underflows (include/linearham_amd.h)
     if (std::stoi(a.opt("extended-range", "0")) != 0) phylo_hmm_ptr->SetExtendedRange(true);
     if (subcmd == "--pipeline") {

@@ -1,5 +1,9 @@
 #include "utils.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <numeric>
 
@@ -91,6 +95,17 @@ std::string FixGeneName(std::string name) {
     while ((p = name.find(rep.first)) != std::string::npos) name.replace(p, rep.first.size(), rep.second);
   }
   return name;
+}
+
+double StageTimer::Now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+StageTimer::StageTimer() : on(std::getenv("LH_PIPELINE_TIMING") != nullptr), t0(Now()) {}
+void StageTimer::Mark(const char* what) {
+  if (!on) return;
+  const double t = Now();
+  std::fprintf(stderr, "[host] %-28s %.3f s\n", what, t - t0);
+  t0 = t;
 }
 
 }  // namespace linearham

@@ -69,6 +69,15 @@ inline void Require(bool cond, const std::string& what) {
   if (!cond) throw std::runtime_error("linearham: requirement failed: " + what);
 }
 
+/// Wall-clock marks printed to stderr when LH_PIPELINE_TIMING is set (where the host side of a run spends its time).
+struct StageTimer {
+  bool on;
+  double t0;
+  static double Now();
+  StageTimer();
+  void Mark(const char* what);
+};
+
 }  // namespace linearham
 
 #endif  // LINEARHAM_UTILS_

@@ -407,6 +407,25 @@ int lh_device_count(void) {
   return n;
 }
 
+int lh_warmup(void) {
+  if (lh_device_count() < 1) return fail("lh_warmup: no HIP device available");
+  LH_HIP(hipFree(nullptr));  // creates the primary context of the current device
+  return 0;
+}
+
+void* lh_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    fail("lh_host_alloc: hipHostMalloc failed");
+    return nullptr;
+  }
+  return p;
+}
+
+void lh_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int lh_family_create(const lh_family_desc* desc, lh_family** out) {
   if (!desc || !out) return fail("lh_family_create: null argument");
   *out = nullptr;
