@@ -35,8 +35,8 @@ struct Workspace {
 
 struct ForwardWs {  // K2a -> K2b hand-off, sized by the largest batch seen
   int n_cap = 0;
-  double *gem = nullptr, *jem = nullptr;
-  int32_t *gcnt = nullptr, *jrs = nullptr;
+  double *gem = nullptr, *jem = nullptr, *dxf = nullptr;
+  int32_t *gcnt = nullptr, *jrs = nullptr, *dxc = nullptr;
 };
 
 struct AsrWs {  // K3's CLV area and the device copies of lh_asr_batch's host arrays (grow-only)
@@ -377,20 +377,22 @@ int run_forward(lh_family* f, int n, int R, const double* site_lik, const int32_
   if (n > w.n_cap) {
     // growing the hand-off buffers: earlier launches on other streams may still be using them
     LH_HIP(hipDeviceSynchronize());
-    void** bufs[] = {(void**)&w.gem, (void**)&w.jem, (void**)&w.gcnt, (void**)&w.jrs};
+    void** bufs[] = {(void**)&w.gem, (void**)&w.jem, (void**)&w.gcnt, (void**)&w.jrs, (void**)&w.dxf, (void**)&w.dxc};
     for (void** b : bufs) {
       if (*b) LH_HIP(hipFree(*b));
       *b = nullptr;
     }
     w.n_cap = 0;
     LH_HIP(hipMalloc((void**)&w.jrs, sizeof(int32_t) * (size_t)n * std::max(f->host.vd.n_rows + f->host.dj.n_rows, 1)));
+    LH_HIP(hipMalloc((void**)&w.dxf, sizeof(double) * (size_t)n * 32));
+    LH_HIP(hipMalloc((void**)&w.dxc, sizeof(int32_t) * (size_t)n));
     LH_HIP(hipMalloc((void**)&w.gem, sizeof(double) * (size_t)n * std::max<int64_t>(f->host.gem_size, 1)));
     LH_HIP(hipMalloc((void**)&w.jem, sizeof(double) * (size_t)n * std::max(f->host.n_jcols, 1)));
     LH_HIP(hipMalloc((void**)&w.gcnt, sizeof(int32_t) * (size_t)n * 3));
     w.n_cap = n;
   }
-  lh::launch_forward(f->host, n, R, site_lik, site_scal, pi, em_in, em_out, w.gem, w.gcnt, w.jem, w.jrs, loglik_dev,
-                     fwd, sco, f->extended, stream);
+  lh::launch_forward(f->host, n, R, site_lik, site_scal, pi, em_in, em_out, w.gem, w.gcnt, w.jem, w.jrs, w.dxf, w.dxc,
+                     loglik_dev, fwd, sco, f->extended, stream);
   LH_HIP(hipGetLastError());
   return 0;
 }
@@ -618,7 +620,8 @@ void lh_family_destroy(lh_family* f) {
   if (!f) return;
   for (void* p : f->allocs) (void)hipFree(p);
   Workspace& w = f->ws;
-  void* bufs[] = {w.rates, w.eig, w.pmat, w.site_lik, w.site_scal, f->fws.gem, f->fws.jem, f->fws.gcnt, f->fws.jrs};
+  void* bufs[] = {w.rates, w.eig,      w.pmat,     w.site_lik,  w.site_scal, f->fws.gem,
+                  f->fws.jem, f->fws.gcnt, f->fws.jrs, f->fws.dxf, f->fws.dxc};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* p : f->st.ptr)

@@ -90,6 +90,15 @@ struct DevFamily {
   int64_t scaler_size;    // ints per sample in the scaler-count output
 };
 
+// 1/v to ~1 ulp from the hardware estimate and two Newton steps (normal-range v; a quarter of the IEEE division
+// sequence).
+__device__ static inline double fast_rcp(double v) {
+  double r = __builtin_amdgcn_rcp(v);
+  r = fma(fma(-v, r, 1.0), r, r);
+  r = fma(fma(-v, r, 1.0), r, r);
+  return r;
+}
+
 // P = I + U expm1(lambda * t*r) Uinv, clamped at 0 (K1's prologue).
 // e: lambda[4] | U[4][4] | Uinv[4][4]
 __device__ static inline void compute_pmatrix(const double* __restrict__ e, double tr, double P[4][4]) {
@@ -146,12 +155,13 @@ size_t asr_slots(int L, int R);  // slots per sample in K3's CLV area: clv[n][T-
 // em_in[n][C].  K2a leaves the germline/padding emission products in gem[n][gem_size], their scaler
 // counts in gcnt[n][3] and the junction columns' emissions in jem[n][n_jcols]; K2b runs the scaled
 // forward sweep over them -> loglik[n] (+ optional forward rows and scaler counts).
+// dxf[n][32], dxc[n]: scratch between the two K2b kernels of the pair form (lh_forward.hip).
 // extended: the opt-in extended-range mode (include/linearham_amd.h, lh_family_set_extended_range); jrs[n][rows
 // of both junctions] is then the K2a -> K2b hand-off of the junction rows' emission scaler counts.
 void launch_forward(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
                     const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt, double* jem,
-                    int32_t* jrs, double* loglik, double* forward_out, int32_t* scaler_out, bool extended,
-                    hipStream_t stream);
+                    int32_t* jrs, double* dxf, int32_t* dxc, double* loglik, double* forward_out, int32_t* scaler_out,
+                    bool extended, hipStream_t stream);
 size_t forward_lds_bytes(const DevFamily& fam);
 
 }  // namespace lh

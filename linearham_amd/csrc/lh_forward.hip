@@ -30,6 +30,8 @@
 //       (gene g in lane g % 64, register slot g / 64) stays in VGPRs, and a CU holds 16 samples instead
 //       of 4, which is what hides the per-row table-load latency.  The row's 2^256 scaling is applied
 //       lazily, as an exact power-of-two factor, when the row is consumed and when it is written out.
+#include <cstdlib>
+
 #include "lh_device.h"
 
 namespace lh {
@@ -251,12 +253,12 @@ __device__ static int fill_consensus(const DevSegments& seg, const double* em, i
   const int j0 = 2 * tid;
   if (j0 < ns) {
     const double e = em_at(seg.cons_col[j0]);
-    cons_inv[j0] = 1.0 / e;
+    cons_inv[j0] = fast_rcp(e);
     x0 = sp_from(e);
   }
   if (j0 + 1 < ns) {
     const double e = em_at(seg.cons_col[j0 + 1]);
-    cons_inv[j0 + 1] = 1.0 / e;
+    cons_inv[j0 + 1] = fast_rcp(e);
     x1 = sp_from(e);
   }
   if (tid == 0) cons_inv[ns] = 1.0;  // the diff lists' padding position
@@ -302,7 +304,7 @@ __device__ static int fill_consensus(const DevSegments& seg, const double* em, i
     if (g < n) {
       const unsigned rng = seg.cons_rng[g];
       const int a = rng & 0xffffu, b = rng >> 16;
-      double r = cons_pv[b] / cons_pv[a];  // in (2^-256, 2^256)
+      double r = cons_pv[b] * fast_rcp(cons_pv[a]);  // in (2^-256, 2^256)
       int k = cons_pk[b] - cons_pk[a];     // value = r * 2^(-256 k)
       const uint32_t* dp = seg.cons_dif + g;
       for (int d = 0; d < seg.cons_diffs; d += 8) {  // eight departures at a time: their loads overlap
@@ -365,7 +367,8 @@ __global__ void __launch_bounds__(kFwdThreads)
   const size_t s = blockIdx.x;
   const int tid = threadIdx.x;
   const int C = fam.n_ucol;  // u-columns (lh_device.h); the caller's columns only appear in em_in / em_out
-  int* redi = reinterpret_cast<int*>(em + ((C + 2) & ~1));  // 2 * kFwdWaves ints, then one flag word
+  double* inv_pi = em + ((C + 2) & ~1);                      // [6]: 1 / pi_b of this sample, 1 for b = N
+  int* redi = reinterpret_cast<int*>(inv_pi + 6);            // 2 * kFwdWaves ints, then one flag word
   int* em_bad = redi + 2 * kFwdWaves;                        // some emission outside (0, 1]
   const int cons_cap = cons_capacity(fam);                                  // 0: no set in consensus form
   double* cons_inv = reinterpret_cast<double*>(redi + 2 * kFwdWaves + 2);  // [cap]
@@ -373,6 +376,7 @@ __global__ void __launch_bounds__(kFwdThreads)
   int* cons_pk = reinterpret_cast<int*>(cons_pv + cons_cap + 4);            // [cap + 4]
   int* ems = cons_pk + (cons_cap ? cons_cap + 4 : 0);                       // [C + 1] (kExt only): 2^-256 counts
   if (tid == 0) *em_bad = 0;
+  if (kFromSiteLik && tid < 5) inv_pi[tid] = tid < 4 ? 1.0 / pi[s * 4 + tid] : 1.0;
   __syncthreads();
   bool my_bad = false;
 
@@ -381,6 +385,8 @@ __global__ void __launch_bounds__(kFwdThreads)
     // smallest one) and apply the naive correction, once per distinct (naive base, pattern) pair.
     const int NP = fam.n_prune;
     const double w = 1.0 / R;
+    // (the naive correction divides a column's likelihood by pi of its naive base: one reciprocal per base and
+    // sample, above, instead of a division per column)
     for (int u = tid; u < C; u += kFwdThreads) {
       const int pat = fam.u_pat[u];
       const int b = fam.u_base[u];
@@ -402,8 +408,7 @@ __global__ void __launch_bounds__(kFwdThreads)
       // The reference forms exp(log(site_lik) - smin*log(2^256) - log(pi_b)) (src/PhyloHMM.cpp:226-237);
       // the same quantity is computed here without the log/exp round trip (two FP64 transcendentals
       // per column): site_lik / pi_b scaled down by 2^(256*smin), which also underflows to 0 like exp().
-      double e = acc;
-      if (b != 4) e /= pi[s * 4 + b];
+      double e = acc * inv_pi[b];
       if constexpr (kExt) {
         ems[u] = smin;  // the emission is e * 2^(-256 smin); the count travels beside the value
       } else {
@@ -789,6 +794,301 @@ __device__ static int junction_wave(const DevJunction& J, const double* jem, con
   return count + last.k;
 }
 
+// ---- two samples per wave (D-J junction of small D / J sets) ------------------------------------------------
+// A D-J junction row keeps one lane per D gene and one per J gene busy: with at most 32 of each, 42 of 64 lanes
+// of a wave-per-sample sweep idle on configs[2] (30 D, 12 J).  The pair form gives lanes 0-31 to one sample and
+// lanes 32-63 to another; gene g of either sample sits in lane g of its half.  Reductions are taken per half
+// (the DPP steps fold rows of 16 lanes; two v_readlane per half finish the job), everything that was
+// wave-uniform per sample -- the rank-one sum, the ScaleMatrix count -- becomes a per-lane value that is equal
+// across a half.
+
+struct HalfPair {
+  double a, b;  // totals of lanes 0-31 / 32-63
+};
+
+__device__ static inline HalfPair half_sums(double v) {
+  v += dpp_move<kDppQuadSwap1>(v);
+  v += dpp_move<kDppQuadSwap2>(v);
+  v += dpp_move<kDppHalfMirror>(v);
+  v += dpp_move<kDppMirror>(v);
+  return HalfPair{read_lane(v, 0) + read_lane(v, 16), read_lane(v, 32) + read_lane(v, 48)};
+}
+
+struct HalfKeys {
+  unsigned a, b;
+};
+
+template <bool kExt>
+__device__ static inline HalfKeys half_keys(unsigned v) {  // min of scale keys, or max of high words (kExt)
+  if (kExt) {
+    v = dpp_max_u32<kDppQuadSwap1>(v);
+    v = dpp_max_u32<kDppQuadSwap2>(v);
+    v = dpp_max_u32<kDppHalfMirror>(v);
+    v = dpp_max_u32<kDppMirror>(v);
+  } else {
+    v = dpp_min_u32<kDppQuadSwap1>(v);
+    v = dpp_min_u32<kDppQuadSwap2>(v);
+    v = dpp_min_u32<kDppHalfMirror>(v);
+    v = dpp_min_u32<kDppMirror>(v);
+  }
+  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+  return kExt ? HalfKeys{max(a, b) - 1u, max(c, d) - 1u} : HalfKeys{min(a, b), min(c, d)};
+}
+
+// The D-J junction sweep and the hand-off into the J germline region for the two samples of a wave
+// (junction_wave<1, 1> twice over).  `hi` = this lane belongs to the second sample; every pointer is the lane's
+// own sample's.  Returns the lane's sample's J scaler count; g_out = forward probability of J gene (lane & 31).
+template <bool kExt>
+__device__ static int junction_pair(const DevJunction& J, const double* jem, const double* ntt_lds, int lane, bool hi,
+                                    double f_in, int count_in, const double* __restrict__ germ_em,
+                                    const double* __restrict__ pad_trans, const double* __restrict__ pad_em,
+                                    double& g_out, double* __restrict__ fwd_out, int32_t* __restrict__ scal_out,
+                                    const int32_t* __restrict__ jrs, bool valid) {
+  const int W = J.n_rows, nL = J.n_left, nR = J.n_right;
+  const unsigned g = lane & 31;  // gene of this lane, left and right alike
+  int count = count_in;
+  double fL = f_in, fR = 0.0, fN[4] = {0.0, 0.0, 0.0, 0.0}, nli[4];
+  {
+    const double2* p = reinterpret_cast<const double2*>(J.right_gp_nli) + 2u * g;
+    const double2 a = p[0], b = p[1];
+    nli[0] = a.x, nli[1] = a.y, nli[2] = b.x, nli[3] = b.y;
+  }
+  const size_t row_stride = (size_t)nL + 5 * (size_t)nR;
+  auto mine = [&](const HalfPair& p) { return hi ? p.b : p.a; };
+  double A = mine(half_sums(f_in * J.enter_lo[g]));
+  for (int i = 0; i < W; ++i) {
+    const size_t ol = (size_t)i * J.left_pad, orr = (size_t)i * J.right_pad;
+    const double ltr = J.left_trans[ol + g], llo = J.left_lo[ol + g];
+    const int lidx = J.left_xmsa[ol + g];
+    const double2* pn = reinterpret_cast<const double2*>(J.right_nlo) + 2 * (orr + g);
+    const double2 n01 = pn[0], n23 = pn[1];
+    const int4 nx = reinterpret_cast<const int4*>(J.nti_xmsa)[orr + g];
+    const double rtr = J.right_trans[orr + g], rli = J.right_gp_li[orr + g];
+    const int ridx = J.right_xmsa[orr + g];
+
+    unsigned key = key_start<kExt>();
+    {
+      const double v = (fL * ltr) * jem[lidx];
+      fL = v;
+      key = key_add<kExt>(key, v);
+    }
+    const double part = fL * llo;
+    const double n0 = fN[0], n1 = fN[1], n2 = fN[2], n3 = fN[3];
+    const double2* tt = reinterpret_cast<const double2*>(ntt_lds) + 8u * g;
+    const int nxs[4] = {nx.x, nx.y, nx.z, nx.w};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const double2 t01 = tt[2 * b], t23 = tt[2 * b + 1];
+      double sacc = ((n0 * t01.x + n1 * t01.y) + n2 * t23.x) + n3 * t23.y;
+      sacc += A * nli[b];
+      const double v = sacc * jem[nxs[b]];
+      fN[b] = v;
+      key = key_add<kExt>(key, v);
+    }
+    {
+      double sacc = ((n0 * n01.x + n1 * n01.y) + n2 * n23.x) + n3 * n23.y;
+      sacc += fR * rtr;
+      sacc += A * rli;
+      const double v = sacc * jem[ridx];
+      fR = v;
+      key = key_add<kExt>(key, v);
+    }
+    A = mine(half_sums(part));
+    const HalfKeys hk = half_keys<kExt>(key);
+    const RowScale sa = row_scale(hk.a), sb = row_scale(hk.b);
+    if constexpr (kExt) count += jrs[i];
+    if ((sa.k | sb.k) != 0) {  // wave-uniform, a few rows per junction
+      const RowScale& sc = hi ? sb : sa;  // (per-lane choice between two wave-uniform scalings)
+      const double factor = hi ? sb.factor : sa.factor;
+      const bool extra = hi ? sb.extra : sa.extra;
+      auto apply = [&](double v) {
+        v *= factor;
+        if (extra) v *= kScaleFactor;
+        return v;
+      };
+      A = apply(A);
+      fL = apply(fL);
+      fR = apply(fR);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fN[b] = apply(fN[b]);
+      count += sc.k;
+    }
+    if (fwd_out && valid) {
+      double* o = fwd_out + (size_t)i * row_stride;
+      if ((int)g < nL) o[g] = fL;
+      if ((int)g < nR) {
+        o[nL + 4 * (size_t)g + 0] = fN[0];
+        o[nL + 4 * (size_t)g + 1] = fN[1];
+        o[nL + 4 * (size_t)g + 2] = fN[2];
+        o[nL + 4 * (size_t)g + 3] = fN[3];
+        o[nL + 4 * (size_t)nR + g] = fR;
+      }
+    }
+    if (scal_out && valid && g == 0) scal_out[i] = count;
+  }
+  unsigned key = key_start<kExt>();
+  {
+    const double2* xn = reinterpret_cast<const double2*>(J.exit_nlo) + 2u * g;
+    const double2 x01 = xn[0], x23 = xn[1];
+    double sacc = ((fN[0] * x01.x + fN[1] * x01.y) + fN[2] * x23.x) + fN[3] * x23.y;
+    sacc += fR * J.exit_trans[g];
+    sacc += A * J.exit_gp_li[g];
+    double v = 0.0;
+    if ((int)g < nR) {
+      v = sacc * germ_em[g];
+      if (pad_trans) v *= pad_trans[g];
+      if (pad_em) v *= pad_em[g];
+    }
+    key = key_add<kExt>(key, v);
+    g_out = v;
+  }
+  const HalfKeys hk = half_keys<kExt>(key);
+  const RowScale sa = row_scale(hk.a), sb = row_scale(hk.b);
+  const RowScale& last = hi ? sb : sa;
+  {
+    double v = g_out * (hi ? sb.factor : sa.factor);
+    if (hi ? sb.extra : sa.extra) v *= kScaleFactor;
+    g_out = v;
+  }
+  return count + last.k;
+}
+
+// The pair form (igh families with at most 32 D and 32 J alleles) as two kernels, because the two halves want
+// different launch shapes: junction_vd_kernel sweeps the V-D junction with a wave per sample (the V genes fill
+// its lanes, 156 VGPRs, three waves per SIMD) and leaves the D-germline forward vector and its scaler count in
+// dxf / dxc; junction_dj_kernel sweeps the D-J junctions of TWO samples per wave (junction_pair; few registers,
+// every wave slot of the CU in use).  Run inside one kernel -- waves 2 and 3 of a workgroup retiring after the
+// V-D half -- the freed slots could not be refilled before the whole workgroup had finished (K2 0.81 -> 0.80 ms
+// only).
+template <int GA, bool kExt>
+__global__ void __launch_bounds__(64 * kJunctionWaves)
+    junction_vd_kernel(const DevFamily fam, int n, const double* __restrict__ gem_all,
+                       const int32_t* __restrict__ gcnt_all, const double* __restrict__ jem_all,
+                       const int32_t* __restrict__ jrs_all, double* __restrict__ fwd_all,
+                       int32_t* __restrict__ scal_all, double* __restrict__ dxf, int32_t* __restrict__ dxc) {
+  extern __shared__ double jlds[];  // [NTI->NTI blocks of the vd right genes | kJunctionWaves jem slices]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.x * kJunctionWaves + wave;
+  const int NJ = fam.n_jcols;
+  double* ntt_vd = jlds;
+  double* jem = ntt_vd + 16 * (size_t)fam.vd.right_pad + (size_t)wave * (NJ + 1);
+  for (int t = threadIdx.x; t < 16 * fam.vd.right_pad; t += 64 * kJunctionWaves) ntt_vd[t] = fam.vd.right_ntt[t];
+  __syncthreads();
+  if (s >= n) return;  // whole waves leave; nothing below synchronises across waves
+  const int nV = fam.vgerm.n_genes, nD = fam.dgerm.n_genes;
+  const size_t vd_fwd = (size_t)fam.vd.n_rows * (fam.vd.n_left + 5 * (size_t)fam.vd.n_right);
+  {
+    const double* src = jem_all + (size_t)s * NJ;
+    for (int j = lane; j < NJ; j += 64) jem[j] = src[j];
+    if (lane == 0) jem[NJ] = 0.0;  // what a state that cannot emit at a site looks up
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const double* gem = gem_all + (size_t)s * fam.gem_size;
+  const int cv = gcnt_all[(size_t)s * 3 + 0], cd = gcnt_all[(size_t)s * 3 + 1];
+  double* fwd = fwd_all ? fwd_all + (size_t)s * fam.forward_size : nullptr;
+  int32_t* sco = scal_all ? scal_all + (size_t)s * fam.scaler_size : nullptr;
+  // initial forward over the V germline region (src/HMM.cpp:291-319)
+  double gV[GA];
+  unsigned key = key_start<kExt>();
+#pragma unroll
+  for (int q = 0; q < GA; ++q) {
+    const int t = lane + 64 * q;
+    double v = 0.0;
+    if (t < nV) {
+      v = fam.vgerm_gene_prob[t];
+      v *= fam.vpadding_transition[t];
+      v *= gem[t];
+      v *= fam.vgerm_trans_prod[t];
+      v *= gem[nV + t];
+    }
+    key = key_add<kExt>(key, v);
+    gV[q] = v;
+  }
+  int vcount = cv;
+  {
+    const RowScale sc = wave_row_scale<kExt>(key);
+#pragma unroll
+    for (int q = 0; q < GA; ++q) gV[q] = sc.apply(gV[q]);
+    vcount += sc.k;
+  }
+  if (fwd) {
+#pragma unroll
+    for (int q = 0; q < GA; ++q)
+      if (lane + 64 * q < nV) fwd[lane + 64 * q] = gV[q];
+  }
+  if (sco && lane == 0) sco[0] = vcount;
+  double gD[1];
+  const int dcount =
+      cd + junction_wave<GA, 1, kExt>(fam.vd, jem, ntt_vd, lane, gV, vcount, gem + 2 * (size_t)nV, nullptr, nullptr, gD,
+                                      fwd ? fwd + nV : nullptr, sco ? sco + 1 : nullptr,
+                                      kExt ? jrs_all + (size_t)s * (fam.vd.n_rows + fam.dj.n_rows) : nullptr);
+  if (fwd && lane < nD) fwd[nV + vd_fwd + lane] = gD[0];
+  if (sco && lane == 0) sco[1 + fam.vd.n_rows] = dcount;
+  if (lane < 32) dxf[(size_t)s * 32 + lane] = gD[0];  // zero beyond the last D gene
+  if (lane == 0) dxc[s] = dcount;
+}
+
+constexpr int kPairWaves = 4;  // waves per junction_dj_kernel workgroup (eight samples)
+
+template <bool kExt>
+__global__ void __launch_bounds__(64 * kPairWaves)
+    junction_dj_kernel(const DevFamily fam, int n, const double* __restrict__ gem_all,
+                       const int32_t* __restrict__ gcnt_all, const double* __restrict__ jem_all,
+                       const int32_t* __restrict__ jrs_all, const double* __restrict__ dxf,
+                       const int32_t* __restrict__ dxc, double* __restrict__ loglik, double* __restrict__ fwd_all,
+                       int32_t* __restrict__ scal_all) {
+  extern __shared__ double jlds[];  // [NTI->NTI blocks of the dj right genes | 2 * kPairWaves jem slices]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NJ = fam.n_jcols;
+  double* ntt_dj = jlds;
+  double* jem0 = ntt_dj + 16 * (size_t)fam.dj.right_pad + (size_t)(2 * wave) * (NJ + 1);
+  for (int t = threadIdx.x; t < 16 * fam.dj.right_pad; t += 64 * kPairWaves) ntt_dj[t] = fam.dj.right_ntt[t];
+  __syncthreads();
+  // this wave's two samples: lanes 0-31 -> sample 2 p, lanes 32-63 -> sample 2 p + 1
+  const int p = blockIdx.x * kPairWaves + wave;
+  if (2 * p >= n) return;  // neither sample exists
+  const bool hi = lane >= 32;
+  const int s2 = 2 * p + (hi ? 1 : 0);
+  const bool valid = s2 < n;
+  const int sr = valid ? s2 : n - 1;  // an absent second sample reads the last one's inputs and writes nothing
+  for (int h = 0; h < 2; ++h) {
+    const int sh = min(2 * p + h, n - 1);
+    const double* src = jem_all + (size_t)sh * NJ;
+    double* dst = jem0 + (size_t)h * (NJ + 1);
+    for (int j = lane; j < NJ; j += 64) dst[j] = src[j];
+    if (lane == 0) dst[NJ] = 0.0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int nV = fam.vgerm.n_genes, nD = fam.dgerm.n_genes, nJ = fam.jgerm.n_genes;
+  const size_t vd_fwd = (size_t)fam.vd.n_rows * (fam.vd.n_left + 5 * (size_t)fam.vd.n_right);
+  const unsigned g = lane & 31;
+  const double* gem = gem_all + (size_t)sr * fam.gem_size;
+  const double* jgerm_em = gem + 2 * (size_t)nV + nD;
+  const double* jpad_em = jgerm_em + nJ;
+  const int cj = gcnt_all[(size_t)sr * 3 + 2];
+  double* fwd = fwd_all ? fwd_all + (size_t)sr * fam.forward_size + nV + vd_fwd + nD : nullptr;
+  int32_t* sco = scal_all ? scal_all + (size_t)sr * fam.scaler_size + 2 + fam.vd.n_rows : nullptr;
+  const double f_in = valid ? dxf[(size_t)s2 * 32 + g] : 0.0;
+  const int dcount = valid ? dxc[s2] : 0;
+  double gJ;
+  const int jcount =
+      cj + junction_pair<kExt>(fam.dj, jem0 + (size_t)(hi ? 1 : 0) * (NJ + 1), ntt_dj, lane, hi, f_in, dcount, jgerm_em,
+                               fam.jpadding_transition, jpad_em, gJ, fwd, sco,
+                               kExt ? jrs_all + (size_t)sr * (fam.vd.n_rows + fam.dj.n_rows) + fam.vd.n_rows : nullptr,
+                               valid);
+  if (fwd && valid && (int)g < nJ) fwd[(size_t)fam.dj.n_rows * (fam.dj.n_left + 5 * (size_t)fam.dj.n_right) + g] = gJ;
+  if (sco && valid && g == 0) sco[fam.dj.n_rows] = jcount;
+  // HMM::LogLikelihood (src/HMM.cpp:352-353)
+  const HalfPair tot = half_sums(gJ);  // zero beyond the last J gene
+  const double part = hi ? tot.b : tot.a;
+  if (valid && g == 0) loglik[s2] = log(part) - jcount * kLogScaleFactor;
+}
+
 // GA: register slots for the V genes (ceil(nV / 64)); GB: slots for the D and J genes.
 template <int GA, int GB, bool kExt = false>
 __global__ void __launch_bounds__(64 * kJunctionWaves)
@@ -915,9 +1215,15 @@ static size_t junction_lds_bytes(const DevFamily& fam) {
          sizeof(double);
 }
 
+// Two samples per wave on the D-J junction (junction_kernel_pair): igh families with at most 32 D and J alleles.
+static bool junction_pair_form(const DevFamily& fam) {
+  static const bool off = getenv("LH_K2B_NO_PAIR") != nullptr;  // test hook: the one-sample-per-wave form
+  return !off && fam.has_d && fam.dgerm.n_genes <= 32 && fam.jgerm.n_genes <= 32;
+}
+
 static size_t emission_lds_bytes(const DevFamily& fam, bool ext) {
   const size_t cap = (size_t)cons_capacity(fam);
-  return (((size_t)fam.n_ucol + 2) & ~(size_t)1) * sizeof(double) + (2 * kFwdWaves + 2) * sizeof(int) +
+  return ((((size_t)fam.n_ucol + 2) & ~(size_t)1) + 6) * sizeof(double) + (2 * kFwdWaves + 2) * sizeof(int) +
          (cap ? (2 * cap + 4) * sizeof(double) + (cap + 4) * sizeof(int) : 0) +
          (ext ? ((size_t)fam.n_ucol + 2) * sizeof(int) : 0);
 }
@@ -972,8 +1278,32 @@ static void launch_emission_g(const DevFamily& fam, int n, int R, const double* 
 
 template <int GA, int GB>
 static void launch_junction_g(const DevFamily& fam, int n, const double* gem, const int32_t* gcnt, const double* jem,
-                              const int32_t* jrs, double* loglik, double* forward_out, int32_t* scaler_out, bool ext,
-                              hipStream_t stream) {
+                              const int32_t* jrs, double* dxf, int32_t* dxc, double* loglik, double* forward_out,
+                              int32_t* scaler_out, bool ext, hipStream_t stream) {
+  if (GB == 1 && junction_pair_form(fam)) {
+    const size_t lds_vd = ((size_t)kJunctionWaves * (fam.n_jcols + 1) + 16 * (size_t)fam.vd.right_pad) * sizeof(double);
+    const size_t lds_dj = ((size_t)2 * kPairWaves * (fam.n_jcols + 1) + 16 * (size_t)fam.dj.right_pad) * sizeof(double);
+    const dim3 grid_vd((n + kJunctionWaves - 1) / kJunctionWaves), grid_dj(((n + 1) / 2 + kPairWaves - 1) / kPairWaves);
+#define LH_PAIR_LAUNCH(E)                                                                                             \
+  {                                                                                                                   \
+    if (lds_vd > 64 * 1024)                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_vd_kernel<GA, E>),                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_vd);                             \
+    if (lds_dj > 64 * 1024)                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_dj_kernel<E>),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dj);                             \
+    hipLaunchKernelGGL((junction_vd_kernel<GA, E>), grid_vd, dim3(64 * kJunctionWaves), lds_vd, stream, fam, n, gem,  \
+                       gcnt, jem, jrs, forward_out, scaler_out, dxf, dxc);                                            \
+    hipLaunchKernelGGL((junction_dj_kernel<E>), grid_dj, dim3(64 * kPairWaves), lds_dj, stream, fam, n, gem, gcnt,    \
+                       jem, jrs, dxf, dxc, loglik, forward_out, scaler_out);                                          \
+  }
+    if (ext)
+      LH_PAIR_LAUNCH(true)
+    else
+      LH_PAIR_LAUNCH(false)
+#undef LH_PAIR_LAUNCH
+    return;
+  }
   const size_t lds = junction_lds_bytes(fam);
   const dim3 grid((n + kJunctionWaves - 1) / kJunctionWaves), block(64 * kJunctionWaves);
   if (ext) {
@@ -993,24 +1323,25 @@ static void launch_junction_g(const DevFamily& fam, int n, const double* gem, co
 
 template <int GA>
 static void launch_junction_a(int gb, const DevFamily& fam, int n, const double* gem, const int32_t* gcnt,
-                              const double* jem, const int32_t* jrs, double* loglik, double* forward_out,
-                              int32_t* scaler_out, bool ext, hipStream_t stream) {
+                              const double* jem, const int32_t* jrs, double* dxf, int32_t* dxc, double* loglik,
+                              double* forward_out, int32_t* scaler_out, bool ext, hipStream_t stream) {
   if (gb <= 1)
-    launch_junction_g<GA, 1>(fam, n, gem, gcnt, jem, jrs, loglik, forward_out, scaler_out, ext, stream);
+    launch_junction_g<GA, 1>(fam, n, gem, gcnt, jem, jrs, dxf, dxc, loglik, forward_out, scaler_out, ext, stream);
   else if (gb <= 2)
-    launch_junction_g<GA, 2>(fam, n, gem, gcnt, jem, jrs, loglik, forward_out, scaler_out, ext, stream);
+    launch_junction_g<GA, 2>(fam, n, gem, gcnt, jem, jrs, dxf, dxc, loglik, forward_out, scaler_out, ext, stream);
   else
-    launch_junction_g<GA, 4>(fam, n, gem, gcnt, jem, jrs, loglik, forward_out, scaler_out, ext, stream);
+    launch_junction_g<GA, 4>(fam, n, gem, gcnt, jem, jrs, dxf, dxc, loglik, forward_out, scaler_out, ext, stream);
 }
 
 // site_lik != null: emissions are assembled from K1's output (em_out optional);
 // site_lik == null: emissions are taken from em_in (SimpleHMM / lh_forward_batch).
 // gem [n][gem_size], gcnt [n][3], jem [n][n_jcols]: per-sample hand-off buffers between K2a and K2b
-// (+ jrs [n][junction rows] in the extended-range mode).
+// (+ jrs [n][junction rows] in the extended-range mode); dxf [n][32], dxc [n]: between the two K2b kernels of the
+// pair form.
 void launch_forward(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
                     const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt, double* jem,
-                    int32_t* jrs, double* loglik, double* forward_out, int32_t* scaler_out, bool ext,
-                    hipStream_t stream) {
+                    int32_t* jrs, double* dxf, int32_t* dxc, double* loglik, double* forward_out, int32_t* scaler_out,
+                    bool ext, hipStream_t stream) {
   const int slots = (fam.max_genes + kFwdThreads - 1) / kFwdThreads;
 #define LH_ARGS fam, n, R, site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, jrs, ext, stream
   if (slots <= 1)
@@ -1022,7 +1353,7 @@ void launch_forward(const DevFamily& fam, int n, int R, const double* site_lik, 
 #undef LH_ARGS
   const int ga = (fam.vgerm.n_genes + 63) / 64;
   const int gb = (std::max(fam.dgerm.n_genes, fam.jgerm.n_genes) + 63) / 64;
-#define LH_ARGS gb, fam, n, gem, gcnt, jem, jrs, loglik, forward_out, scaler_out, ext, stream
+#define LH_ARGS gb, fam, n, gem, gcnt, jem, jrs, dxf, dxc, loglik, forward_out, scaler_out, ext, stream
   if (ga <= 1)
     launch_junction_a<1>(LH_ARGS);
   else if (ga <= 2)

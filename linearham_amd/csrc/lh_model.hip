@@ -12,14 +12,8 @@ namespace lh {
 
 // ---- regularised incomplete gamma and its inverse (double) ---------------------------------------
 
-// 1/v to ~1 ulp from the hardware estimate and two Newton steps: the series and the continued fraction
-// below are chains of dependent divisions, and the IEEE division sequence is four times as long.
-__device__ static inline double fast_rcp(double v) {
-  double r = __builtin_amdgcn_rcp(v);
-  r = fma(fma(-v, r, 1.0), r, r);
-  r = fma(fma(-v, r, 1.0), r, r);
-  return r;
-}
+// (fast_rcp, lh_device.h: the series and the continued fraction below are chains of dependent divisions, and the
+// IEEE division sequence is four times as long.)
 
 __device__ static double gamma_p(double a, double x, double lga) {
   if (!(x > 0.0)) return 0.0;
