@@ -391,7 +391,7 @@ int run_forward(lh_family* f, int n, int R, const double* site_lik, const int32_
     LH_HIP(hipMalloc((void**)&w.gcnt, sizeof(int32_t) * (size_t)n * 3));
     w.n_cap = n;
   }
-  lh::launch_forward(f->host, n, R, site_lik, site_scal, pi, em_in, em_out, w.gem, w.gcnt, w.jem, w.jrs, w.dxf, w.dxc,
+  lh::launch_forward(f->host, f->dev, n, R, site_lik, site_scal, pi, em_in, em_out, w.gem, w.gcnt, w.jem, w.jrs, w.dxf, w.dxc,
                      loglik_dev, fwd, sco, f->extended, stream);
   LH_HIP(hipGetLastError());
   return 0;

@@ -158,8 +158,10 @@ size_t asr_slots(int L, int R);  // slots per sample in K3's CLV area: clv[n][T-
 // dxf[n][32], dxc[n]: scratch between the two K2b kernels of the pair form (lh_forward.hip).
 // extended: the opt-in extended-range mode (include/linearham_amd.h, lh_family_set_extended_range); jrs[n][rows
 // of both junctions] is then the K2a -> K2b hand-off of the junction rows' emission scaler counts.
-void launch_forward(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
-                    const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt, double* jem,
+// fam_dev: the device copy of fam (K2a reads the descriptor from memory instead of taking it by value).
+void launch_forward(const DevFamily& fam, const DevFamily* fam_dev, int n, int R, const double* site_lik,
+                    const int32_t* site_scal, const double* pi, const double* em_in, double* em_out, double* gem,
+                    int32_t* gcnt, double* jem,
                     int32_t* jrs, double* dxf, int32_t* dxc, double* loglik, double* forward_out, int32_t* scaler_out,
                     bool extended, hipStream_t stream);
 size_t forward_lds_bytes(const DevFamily& fam);

@@ -358,11 +358,14 @@ __device__ static int fill_consensus(const DevSegments& seg, const double* em, i
 }
 
 template <int kG, bool kFromSiteLik, bool kByteOff, bool kExt = false>
-__global__ void __launch_bounds__(kFwdThreads)
-    emission_kernel(const DevFamily fam, int R, const double* __restrict__ site_lik,
+__global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80)))  // 80: eight workgroups per CU
+    emission_kernel(const DevFamily* __restrict__ fam_dev, int R, const double* __restrict__ site_lik,
                     const int32_t* __restrict__ site_scal, const double* __restrict__ pi,
                     const double* __restrict__ em_in, double* __restrict__ em_out, double* __restrict__ gem_all,
                     int32_t* __restrict__ gcnt_all, double* __restrict__ jem_all, int32_t* __restrict__ jrs_all) {
+  // (the family descriptor is read from its device copy where a field is needed: passed by value it took more
+  // scalar registers than the 96 that still admit seven workgroups per CU)
+  const DevFamily& fam = *fam_dev;
   extern __shared__ double em[];  // [C + 1] emissions (em[C] = 1.0 sentinel) | reduction scratch
   const size_t s = blockIdx.x;
   const int tid = threadIdx.x;
@@ -1033,6 +1036,7 @@ __global__ void __launch_bounds__(64 * kJunctionWaves)
 
 constexpr int kPairWaves = 4;  // waves per junction_dj_kernel workgroup (eight samples)
 
+// (122 VGPRs, four waves per SIMD: capped at 80 / 64 registers the kernel spills and takes 2.9x / 4.9x as long)
 template <bool kExt>
 __global__ void __launch_bounds__(64 * kPairWaves)
     junction_dj_kernel(const DevFamily fam, int n, const double* __restrict__ gem_all,
@@ -1234,22 +1238,22 @@ size_t forward_lds_bytes(const DevFamily& fam) {
 }
 
 template <int kG, bool kSite, bool kByteOff, bool kExt>
-static void launch_emission_k(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
-                              const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt,
-                              double* jem, int32_t* jrs, hipStream_t stream) {
+static void launch_emission_k(const DevFamily& fam, const DevFamily* fam_dev, int n, int R, const double* site_lik,
+                              const int32_t* site_scal, const double* pi, const double* em_in, double* em_out,
+                              double* gem, int32_t* gcnt, double* jem, int32_t* jrs, hipStream_t stream) {
   const size_t lds = emission_lds_bytes(fam, kExt);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(emission_kernel<kG, kSite, kByteOff, kExt>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((emission_kernel<kG, kSite, kByteOff, kExt>), dim3(n), dim3(kFwdThreads), lds, stream, fam, R,
+  hipLaunchKernelGGL((emission_kernel<kG, kSite, kByteOff, kExt>), dim3(n), dim3(kFwdThreads), lds, stream, fam_dev, R,
                      site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, jrs);
 }
 
 template <int kG>
-static void launch_emission_g(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
-                              const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt,
-                              double* jem, int32_t* jrs, bool ext, hipStream_t stream) {
-#define LH_ARGS fam, n, R, site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, jrs, stream
+static void launch_emission_g(const DevFamily& fam, const DevFamily* fam_dev, int n, int R, const double* site_lik,
+                              const int32_t* site_scal, const double* pi, const double* em_in, double* em_out,
+                              double* gem, int32_t* gcnt, double* jem, int32_t* jrs, bool ext, hipStream_t stream) {
+#define LH_ARGS fam, fam_dev, n, R, site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, jrs, stream
   if (ext) {  // opt-in mode: one index form is enough
     if (site_lik) {
       if (fam.idx_byte_offsets)
@@ -1338,12 +1342,12 @@ static void launch_junction_a(int gb, const DevFamily& fam, int n, const double*
 // gem [n][gem_size], gcnt [n][3], jem [n][n_jcols]: per-sample hand-off buffers between K2a and K2b
 // (+ jrs [n][junction rows] in the extended-range mode); dxf [n][32], dxc [n]: between the two K2b kernels of the
 // pair form.
-void launch_forward(const DevFamily& fam, int n, int R, const double* site_lik, const int32_t* site_scal,
-                    const double* pi, const double* em_in, double* em_out, double* gem, int32_t* gcnt, double* jem,
-                    int32_t* jrs, double* dxf, int32_t* dxc, double* loglik, double* forward_out, int32_t* scaler_out,
-                    bool ext, hipStream_t stream) {
+void launch_forward(const DevFamily& fam, const DevFamily* fam_dev, int n, int R, const double* site_lik,
+                    const int32_t* site_scal, const double* pi, const double* em_in, double* em_out, double* gem,
+                    int32_t* gcnt, double* jem, int32_t* jrs, double* dxf, int32_t* dxc, double* loglik,
+                    double* forward_out, int32_t* scaler_out, bool ext, hipStream_t stream) {
   const int slots = (fam.max_genes + kFwdThreads - 1) / kFwdThreads;
-#define LH_ARGS fam, n, R, site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, jrs, ext, stream
+#define LH_ARGS fam, fam_dev, n, R, site_lik, site_scal, pi, em_in, em_out, gem, gcnt, jem, jrs, ext, stream
   if (slots <= 1)
     launch_emission_g<1>(LH_ARGS);
   else if (slots <= 2)

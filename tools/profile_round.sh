@@ -15,7 +15,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
 echo "[profile_round] kernel trace: bench.py $@"
-timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o run -- python3 $root/bench.py --no-cpu-baseline "$@" > $out/${tag}.json 2> $out/${tag}.err
+timeout -k 5 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o run -- python3 $root/bench.py --no-cpu-baseline --no-forward-rate "$@" > $out/${tag}.json 2> $out/${tag}.err
 cp "$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)" $out/${tag}_kernel_stats.csv
 dirs=""
 i=0
