@@ -367,6 +367,7 @@ def worker(args, rank, local_rank, world):
             "config": {"workload": WORKLOADS[args.preset],
                        "preset": args.preset, "tree_samples_per_step": n_total,
                        "tree_samples_per_gpu_per_step": n, "distinct_tree_samples": min(flat["n_rows"], n_total),
+                       "distinct_tree_samples_per_gpu": int(len(set(sharding.table_rows(ids, flat["n_rows"], world, n_total).tolist()))),
                        "n_tips": T, "n_sites": sizes["n_sites"], "xmsa_columns": Cx, "site_patterns": n_pat.value,
                        "distinct_xmsa_columns": n_ucol.value, "S_vd": sizes["s_vd"],
                        "S_dj": sizes["s_dj"], "W_vd": sizes["w_vd"], "W_dj": sizes["w_dj"],
@@ -414,14 +415,14 @@ def worker(args, rank, local_rank, world):
             # every rank's shard (global sample g was evaluated by rank g mod N)
             want_base = world == 1 and not args.no_cpu_baseline
             check_ids = list(range(min(n_total, 2 * world if world > 1 else 2)))
-            rows = [int(r) for r in sharding.table_rows(check_ids, flat["n_rows"])]
+            rows = [int(r) for r in sharding.table_rows(check_ids, flat["n_rows"], world, n_total)]
             if want_base or world > 1 or args.preset == "small":
                 ref_ll, base = cpu_oracle(fam_dir, rows, args.cpu_budget_s, 192 if want_base else 0)
                 if base:
                     out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
                     out["speedup_vs_cpu_all_cores"] = value / base["value"]
                     check_ids = [g for g in range(min(n_total, flat["n_rows"])) if g in ref_ll]
-                both = [(ll_all[g], ref_ll[int(g % flat["n_rows"])]) for g in check_ids]
+                both = [(ll_all[g], ref_ll[int(sharding.table_rows([g], flat["n_rows"], world, n_total)[0])]) for g in check_ids]
                 if any(np.isfinite(g) != np.isfinite(v) for g, v in both):
                     raise SystemExit("parity failure: GPU and CPU oracle disagree on which evaluations are finite")
                 rel = max([abs(g - v) / abs(v) for g, v in both if np.isfinite(v)] or [0.0])

@@ -28,17 +28,26 @@ def shard_size(n_total, world, rank):
     return (n_total - rank + world - 1) // world if n_total > rank else 0
 
 
-def table_rows(global_ids, n_rows):
-    """Row of the RevBayes table a global sample number reads (the table is reused cyclically when a
-    weak-scaling run asks for more samples than it holds)."""
-    return np.asarray(global_ids, dtype=np.int64) % n_rows
+ROTATE = 977   # rows by which consecutive ranks' passes through a reused table are offset
+
+
+def table_rows(global_ids, n_rows, world=1, n_total=None):
+    """Row of the RevBayes table a global sample number reads, for a run of `n_total` samples over `world` ranks.
+    A run that asks for no more samples than the table holds reads row g for sample g.  A weak-scaling run
+    (n_total > n_rows) reuses the table: rank r's j-th sample (g = r + world j) reads row (j + ROTATE r) mod
+    n_rows, so that every rank still works through distinct rows (as many as the table holds) instead of
+    world copies of a world-th of them."""
+    g = np.asarray(global_ids, dtype=np.int64)
+    if world <= 1 or n_total is None or n_total <= n_rows:
+        return g % n_rows
+    return (g // world + (g % world) * ROTATE) % n_rows
 
 
 def take_shard(flat, n_total, world, rank, keys=("ops", "brlen", "er", "pi", "alpha")):
     """This rank's slice of flattened per-sample input arrays (first axis = table row).
     Returns (dict of contiguous arrays, global sample numbers)."""
     ids = shard_ids(n_total, world, rank)
-    rows = table_rows(ids, flat["n_rows"])
+    rows = table_rows(ids, flat["n_rows"], world, n_total)
     return {k: np.ascontiguousarray(flat[k][rows]) for k in keys}, ids
 
 

@@ -409,3 +409,45 @@ def test_consensus_products_equal_the_factor_walk(hip, tmp_path, monkeypatch, lo
     np.testing.assert_allclose(ll, ll2, rtol=1e-12)
     np.testing.assert_array_equal(res["scaler_counts"], res2["scaler_counts"])
     np.testing.assert_allclose(res["forward"], res2["forward"], rtol=1e-11)
+
+
+def test_subnormal_entry_next_to_normal_ones_is_documented_corner(hip, data_dir):
+    """DESIGN.md section 2, "one deliberate corner": the ScaleMatrix tests of K2b look at the high word of a double,
+    so a positive forward entry below 2^-1042 counts as zero when a row's count is chosen.  Constructed here with
+    caller-supplied emissions (lh_forward_batch): one NTI column of a junction site emits 1e-306 (forward mass
+    ~1e-10 times that = 1e-316, a subnormal with a zero high word), everything else 0.1.  The reference multiplies
+    such a row by 2^256 four times (its other entries, probabilities <= 1, survive that: <= 2^1024 only for an entry
+    of exactly 1) and carries the count along; the device path leaves the row alone.  Both are exact power-of-two
+    scalings of the same numbers: the log-likelihood is the same, the scaler counts differ by those four, the
+    forward values by 2^1024."""
+    import linearham_amd
+    h = orc.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input.yaml"), 0, os.path.join(data_dir, "hmm_params"), 0)
+    desc = db.build_family_desc(h)
+    C = desc.n_xmsa
+    # a column that only NTI states emit from: in nti_xmsa, in no germline / padding segment, in no germline junction state
+    used = set()
+    for seg in (desc.vpadding, desc.vgerm, desc.dgerm, desc.jgerm, desc.jpadding):
+        used.update(int(x) for x in np.ravel(seg.xmsa_inds))
+    for J in (desc.vd, desc.dj):
+        used.update(int(x) for x in np.ravel(J.left_xmsa) if x >= 0)
+        used.update(int(x) for x in np.ravel(J.right_xmsa) if x >= 0)
+    nti_only = sorted(set(int(x) for x in np.ravel(desc.vd.nti_xmsa)) - used)
+    assert nti_only, "the toy family has junction columns that only NTI states use"
+    em = np.full(C, 0.1)
+    em[nti_only[0]] = 1e-306
+    h.vgerm_scaler_count = h.dgerm_scaler_count = h.jgerm_scaler_count = 0
+    h.xmsa_emission = em
+    h._initialize_emission()
+    h.cache_forward = True
+    with np.errstate(all="ignore"):
+        ref = h.log_likelihood()
+    assert np.isfinite(ref) and h.jgerm_scaler_count == 4          # the reference did rescale by 2^1024
+    pos = h.vd_junction_forward[h.vd_junction_forward > 0]
+    fam = linearham_amd.Family(desc, hip)
+    ll, res = fam.forward_batch(em[None], want=("forward", "scaler_counts"))
+    fam.close()
+    assert abs(ll[0] - ref) <= 1e-10 * abs(ref)
+    ex = expand_forward(h, desc, res["forward"][0], res["scaler_counts"][0])
+    assert ex["jgerm_scaler_count"] == 0                            # ... the device path did not
+    np.testing.assert_allclose(np.ldexp(ex["jgerm_forward"], 1024), h.jgerm_forward, rtol=1e-10)
+    assert pos.min() > 1e-20                                        # (what the reference holds after its rescaling)

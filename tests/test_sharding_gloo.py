@@ -27,6 +27,18 @@ def test_shard_ids_partition_every_sample_once():
         sharding.shard_ids(4, 2, 2)
 
 
+def test_table_reuse_keeps_every_rank_on_distinct_rows():
+    n_rows, world, batch = 24576, 8, 24576
+    for r in range(world):
+        ids = sharding.shard_ids(world * batch, world, r)
+        rows = sharding.table_rows(ids, n_rows, world, world * batch)
+        assert len(set(rows.tolist())) == n_rows                  # a whole pass over the table, not 8 x an eighth
+        # the mapping of one sample does not depend on which other samples are asked about
+        assert sharding.table_rows(ids[:3], n_rows, world, world * batch).tolist() == rows[:3].tolist()
+    # no reuse: sample g reads row g
+    np.testing.assert_array_equal(sharding.table_rows(np.arange(100), 10000, 8, 10000), np.arange(100))
+
+
 def test_unshard_inverts_sharding_with_padding():
     n_total, world = 11, 4
     vals = np.arange(n_total) * 1.5
@@ -48,7 +60,7 @@ def test_ranks_shard_gather_in_sample_order(world, n_rows, n_total):
     sys.path.insert(0, HERE)
     import sharding_worker as sw
     flat = sw.table(n_rows)
-    rows = sharding.table_rows(np.arange(n_total), n_rows)       # the table is reused cyclically
+    rows = sharding.table_rows(np.arange(n_total), n_rows, world, n_total)   # table reuse
     want = sw.fake_loglik({k: flat[k][rows] for k in ("ops", "brlen", "er", "pi", "alpha")})
     assert got["world"] == world
     np.testing.assert_array_equal(np.asarray(got["loglik"]), want)   # global sample order, nothing lost
