@@ -416,7 +416,7 @@ def worker(args, rank, local_rank, world):
             want_base = world == 1 and not args.no_cpu_baseline
             check_ids = list(range(min(n_total, 2 * world if world > 1 else 2)))
             rows = [int(r) for r in sharding.table_rows(check_ids, flat["n_rows"], world, n_total)]
-            if want_base or world > 1 or args.preset == "small":
+            if want_base or world > 1 or args.preset in ("small", "config3"):
                 ref_ll, base = cpu_oracle(fam_dir, rows, args.cpu_budget_s, 192 if want_base else 0)
                 if base:
                     out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}

@@ -153,7 +153,8 @@ int lh_family_set_extended_range(lh_family* fam, int enable);
 /* Tree in rooted-at-naive form: tips are nodes 0..T-1 (0 = `naive`, i = MSA row i-1), inner nodes
  * T..2T-3.  children[2*(v-T)+{0,1}] are the two children of inner node v when the tree is rooted at
  * `root`, the inner node adjacent to `naive`.  Writes the kernel's post-order schedule:
- * ops[4*k+{0..3}] for k < T-2 (the last op computes the root).  *max_depth receives the number of
+ * ops[4*k+{0..3}] for k < T-2 (the last op computes the root; word 0 = kind | flags | running matrix count,
+ * words 1-2 = children, word 3 = stack slot: an internal format, validated by lh_eval_batch).  *max_depth receives the number of
  * stack slots the schedule needs.  Pure host integer work. */
 int lh_schedule_tree(int32_t n_tips, const int32_t* children, int32_t root, int32_t* ops,
                      int32_t* max_depth);

@@ -709,6 +709,7 @@ int lh_schedule_tree(int32_t T, const int32_t* children, int32_t root, int32_t* 
   std::vector<Frame> fs;
   fs.push_back({root, 0, 0, 0});
   int n_out = 0, depth = 0, maxd = 0;
+  int n_inner_mats = 0;       // inner-branch P-matrices needed by the ops written so far (K1 packs its prologue by it)
   bool acc_live = false;      // accumulator holds a result that a later op still needs
   bool push_pending = false;  // the next cherry must push the accumulator first
   while (!fs.empty()) {
@@ -737,7 +738,8 @@ int lh_schedule_tree(int32_t T, const int32_t* children, int32_t root, int32_t* 
         fr.phase = 1;
         fs.push_back({inner, 0, 0, 0});
       } else {
-        op[0] = lh::OP_TIP_ACC;
+        op[0] = lh::OP_TIP_ACC | (n_inner_mats << lh::OP_RANK_SHIFT);
+        n_inner_mats += 1;
         op[1] = tip;
         op[2] = inner;
         op[3] = 0;
@@ -757,7 +759,8 @@ int lh_schedule_tree(int32_t T, const int32_t* children, int32_t root, int32_t* 
         const int second = fr.second;
         fs.push_back({second, 0, 0, 0});
       } else {
-        op[0] = lh::OP_POP_ACC;
+        op[0] = lh::OP_POP_ACC | (n_inner_mats << lh::OP_RANK_SHIFT);
+        n_inner_mats += 2;
         op[1] = fr.first;
         op[2] = fr.second;
         op[3] = --depth;
@@ -880,7 +883,8 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
 static bool valid_op(const int32_t* op, int T, int nodes, int max_depth) {
   const int kind = op[0] & 15;
   const bool push = op[0] & lh::OP_PUSH_FLAG;
-  bool ok = (op[0] & ~31) == 0 && kind <= 2;
+  const int rank = op[0] >> lh::OP_RANK_SHIFT;  // bits 5-7 unused
+  bool ok = (op[0] & 0xe0) == 0 && op[0] >= 0 && kind <= 2 && rank <= T - 3;
   if (kind == lh::OP_CHERRY) ok = ok && op[1] >= 1 && op[1] < T && op[2] >= 1 && op[2] < T;
   if (kind == lh::OP_TIP_ACC) ok = ok && !push && op[1] >= 1 && op[1] < T && op[2] >= T && op[2] < nodes;
   if (kind == lh::OP_POP_ACC) ok = ok && !push && op[1] >= T && op[1] < nodes && op[2] >= T && op[2] < nodes;

@@ -12,7 +12,9 @@ constexpr double kScaleThreshold = 0x1p-256;  // SCALE_THRESHOLD, src/utils.hpp:
 constexpr double kLogScaleFactor = 177.445678223345993274;  // log(2^256)
 
 // schedule op kinds (ops[4k] & 15); bit 4 = push the accumulator to stack slot ops[4k+3] first
-enum : int { OP_CHERRY = 0, OP_TIP_ACC = 1, OP_POP_ACC = 2, OP_PUSH_FLAG = 16 };
+// bits 8..: for a tip-into-accumulator / pop op, the number of inner-branch P-matrices the earlier ops need (its own
+// one or two follow): K1's prologue packs its matrix work by it
+enum : int { OP_CHERRY = 0, OP_TIP_ACC = 1, OP_POP_ACC = 2, OP_PUSH_FLAG = 16, OP_RANK_SHIFT = 8 };
 
 // Device copy of lh_segments / lh_junction / family constants (all pointers are device pointers).
 struct DevSegments {
@@ -101,17 +103,18 @@ __device__ static inline double fast_rcp(double v) {
 
 // P = I + U expm1(lambda * t*r) Uinv, clamped at 0 (K1's prologue).
 // e: lambda[4] | U[4][4] | Uinv[4][4]
+// (mode 0 is the stationary one, eigenvalue 0 -- K0a orders them so -- and contributes nothing: three modes are summed)
 __device__ static inline void compute_pmatrix(const double* __restrict__ e, double tr, double P[4][4]) {
   double ex[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) ex[k] = expm1(e[k] * tr);
+  for (int k = 1; k < 4; ++k) ex[k] = expm1(e[k] * tr);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       double v = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v = fma(e[4 + i * 4 + k] * ex[k], e[20 + k * 4 + j], v);
+      for (int k = 1; k < 4; ++k) v = fma(e[4 + i * 4 + k] * ex[k], e[20 + k * 4 + j], v);
       P[i][j] = fmax(v, 0.0);
     }
 }

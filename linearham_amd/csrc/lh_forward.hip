@@ -964,6 +964,7 @@ __device__ static int junction_pair(const DevJunction& J, const double* jem, con
 // every wave slot of the CU in use).  Run inside one kernel -- waves 2 and 3 of a workgroup retiring after the
 // V-D half -- the freed slots could not be refilled before the whole workgroup had finished (K2 0.81 -> 0.80 ms
 // only).
+// (113 VGPRs, four waves per SIMD; a 96-register budget for five waves: 0.28 -> 0.32 ms, 80 for six: 0.75 ms)
 template <int GA, bool kExt>
 __global__ void __launch_bounds__(64 * kJunctionWaves)
     junction_vd_kernel(const DevFamily fam, int n, const double* __restrict__ gem_all,

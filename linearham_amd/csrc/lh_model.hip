@@ -174,8 +174,30 @@ __global__ void __launch_bounds__(64) model_setup_kernel(int n, int R, const dou
       }
     }
   }
+  // The stationary mode (eigenvalue 0: the largest, every other one is negative) goes first: its term of
+  // P = I + U expm1(lambda t) U^-1 is expm1(0) = 0, and compute_pmatrix (lh_device.h) leaves it out.
+  // (Bubbled down with statically indexed conditional swaps: a run-time column index would put W in scratch.)
+  double lam[4] = {A[0][0], A[1][1], A[2][2], A[3][3]};
+#pragma unroll
+  for (int k = 3; k >= 1; --k) {
+    bool up = true;  // is lam[k] the largest of lam[0..k]?
+#pragma unroll
+    for (int j = 0; j < k; ++j) up = up && lam[k] > lam[j];
+    if (up) {
+      const double t = lam[k];
+      lam[k] = lam[k - 1];
+      lam[k - 1] = t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double w = W[i][k];
+        W[i][k] = W[i][k - 1];
+        W[i][k - 1] = w;
+      }
+    }
+  }
   double* o = eig + (size_t)s * 36;
-  for (int k = 0; k < 4; ++k) o[k] = A[k][k];
+  o[0] = 0.0;
+  for (int k = 1; k < 4; ++k) o[k] = lam[k];
   for (int i = 0; i < 4; ++i)
     for (int k = 0; k < 4; ++k) {
       o[4 + i * 4 + k] = W[i][k] / sq[i];   // U[i][k]

@@ -384,10 +384,49 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
     const double rt = rates[(size_t)sample * R + rate];
     const double* __restrict__ bl = brlen + (size_t)sample * (2 * (size_t)T - 2);
     double* pw = pmat_w + pm_off;
+    double P[4][4];
+    if constexpr (kFused) {
+      // Packed form: the T - 3 inner-branch matrices are numbered by the schedule (lh_schedule_tree leaves each
+      // op's running count in its descriptor); every op thread notes where its one or two matrices go in a
+      // list in LDS (the same for every rate: one copy per workgroup, behind the tip tables), and after a
+      // barrier thread t of a rate takes items t, t + nthr, ... of [inner matrices | tips]: no lane idles on a
+      // cherry, none computes two matrices while its neighbours compute one.
+      uint16_t* mat_list = reinterpret_cast<uint16_t*>(reinterpret_cast<double*>(smem2) + (size_t)R * T * 16);
+      if (rate == 0) {
+        for (int k = rtid; k < n_ops; k += nthr) {
+          const int4 op = op_ptr[k];
+          const int kind = op.x & 15, rank = op.x >> OP_RANK_SHIFT;
+          if (kind == OP_CHERRY) continue;
+          mat_list[rank] = (uint16_t)(2 * k);          // the accumulator child's matrix: node op.z, slot [k][0]
+          if (kind == OP_POP_ACC) mat_list[rank + 1] = (uint16_t)(2 * k + 1);  // the popped child's: node op.y, slot [k][1]
+        }
+      }
+      __syncthreads();
+      const int n_inner = T - 3;
+      for (int it = rtid; it < n_inner + T; it += nthr) {
+        if (it < n_inner) {
+          const int code = mat_list[it], k = code >> 1;
+          const int4 op = op_ptr[k];
+          compute_pmatrix(e, bl[(code & 1) ? op.y : op.z] * rt, P);
+          double* o = pw + (size_t)k * 32 + (code & 1) * 16;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[i * 4 + q] = P[i][q];
+        } else {
+          const int j = it - n_inner;
+          compute_pmatrix(e, bl[j] * rt, P);
+          double* o = tiptab + j * 16;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
+        }
+      }
+    } else {
     const int half = nthr >= 128 ? (nthr / 128) * 64 : 0;  // whole waves on either side
     const bool do_ops = half == 0 || rtid < half;
     const bool do_tips = half == 0 || rtid >= half;
-    double P[4][4];
     if (do_ops) {
       const int stride = half ? half : nthr;
       for (int k = rtid; k < n_ops; k += stride) {
@@ -420,6 +459,7 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
 #pragma unroll
           for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
       }
+    }
     }
   }
   SegCtx seg{eig + (size_t)sample * 36, brlen + (size_t)sample * (2 * (size_t)T - 2),
@@ -588,7 +628,8 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   // all rates of a sample in one workgroup, mixed there: at most 8 waves, and R tip tables (later reused
   // as the exchange area [R][5][pad] doubles + [R][pad] ints) within a third of a CU's LDS
   const size_t pad = (size_t)n2 * 128 + (size_t)n1 * 64;
-  const size_t fused_lds = std::max((size_t)R * tip_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
+  const size_t fused_lds = std::max((size_t)R * tip_bytes + (((size_t)T * sizeof(uint16_t) + 15) & ~(size_t)15),
+                                    (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
   static const bool seg_env = getenv("LH_K1_SEGMENTS") != nullptr;  // test hook: segments on small trees too
   static const int seg_waves = getenv("LH_K1_SEG_WAVES") ? atoi(getenv("LH_K1_SEG_WAVES")) : 4;  // measured: 4 (128 VGPRs, few spills) beats 5 by 9 %
   const bool fused = allow_fused && two && R * wpr <= 8 && fused_lds <= 53 * 1024 && !seg_env;

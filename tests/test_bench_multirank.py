@@ -45,6 +45,20 @@ def test_bench_single_rank_small():
     assert out["evals_per_s_with_forward"] > 0 and out["cpu_baseline"]["cores"] >= 1
 
 
+@pytest.mark.gpu
+def test_bench_config3_preset():
+    """BASELINE.json configs[3] on one rank: 10 000 DISTINCT tree samples of the configs[2] family (NNI-perturbed
+    topologies, LogNormal(0, 0.3) branch-length factors), every one evaluated once per step; with N ranks the same
+    10 000 are divided (strong scaling).  The first samples are checked against the CPU oracle."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preset", "config3", "--steps", "2", "--warmup",
+                        "1", "--no-cpu-baseline"], env=_clean_env(), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["config"]["tree_samples_per_step"] == 10000
+    assert out["config"]["distinct_tree_samples"] == 10000 and out["config"]["distinct_tree_samples_per_gpu"] == 10000
+    assert out["delta_logl_vs_cpu_max_rel"] < 1e-9 and out["value"] > 0
+
+
 def test_bench_launcher_fails_loudly_without_gpu():
     """On a box without a GPU the ranks refuse to run (no CPU fallback) and the launcher reports failure."""
     import torch
