@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-le
 # 32 lanes x 2 flop x 2.4 GHz); FP64 FMAs issue at half that rate (measured: tools/microbench/mfma_f64.hip
 # sustains 63-72 TFLOP/s at the clock the chip holds under load), so the peak used here is 157.3 / 2.
 FP64_VALU_PEAK_TFLOPS = 78.6
-DEFAULT_BATCH = 24576          # tree samples per GPU per step (= one launch group of the C ABI)
+DEFAULT_BATCH = 49152          # tree samples per GPU per step (= one launch group of the C ABI)
 WORKLOADS = {
     "config2": "BASELINE.json configs[2]: synthetic 100-leaf random tree, 400-site MSA, full V/D/J germline set "
                "(200 V / 30 D / 12 J alleles), R=4 rate categories",

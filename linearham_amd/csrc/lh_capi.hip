@@ -363,7 +363,8 @@ int stage(lh_family* f, int slot, size_t bytes, void** out) {
   return 0;
 }
 
-constexpr int kChunk = 24576;  // samples per launch group (bounds the workspace: ~110 KB per sample for a
+// LH_CHUNK: test hook (several groups inside one small call)
+static const int kChunk = getenv("LH_CHUNK") ? std::max(256, atoi(getenv("LH_CHUNK"))) : 49152;  // samples per launch group (bounds the workspace: ~150 KB per sample for a
                                // 100-tip tree; a multiple of 6144 = whole rounds of all three kernels on
                                // 256 CUs for configs[2]-like shapes)
 
@@ -844,9 +845,9 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
   if ((size_t)T * 128 > 160 * 1024) return fail("lh_eval_batch: too many tips for the LDS tip table");
   if (!ops || !brlen || !er || !pi || !alpha || !loglik) return fail("lh_eval_batch: null array");
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-  // launch groups of at most kChunk samples and at most ~6 GB of per-sample workspace
+  // launch groups of at most kChunk samples and at most ~16 GB of per-sample workspace
   const size_t per_sample = sizeof(double) * R * (scratch_doubles(T) + 6 * (size_t)std::max(f->host.n_prune, 1));
-  const int by_memory = (int)std::max<size_t>(1024, ((size_t)6 << 30) / per_sample);
+  const int by_memory = (int)std::max<size_t>(1024, ((size_t)16 << 30) / per_sample);
   const int chunk = std::min<int>(n, std::min(kChunk, by_memory));
   if (ensure_workspace(f, chunk, R, T)) return 1;
   Workspace& w = f->ws;

@@ -160,9 +160,11 @@ def test_batch_of_varied_models_on_toy_family(hip, data_dir):
 
 
 def test_more_samples_than_one_launch_group(hip, data_dir):
-    """More samples than one launch group (24576) run as several groups over the same workspace: the
+    """More samples than one launch group run as several groups over the same workspace: the
     P-matrix scratch area is rewritten with different matrices at the same addresses and read back through
-    the scalar cache, the K2a -> K2b hand-off buffers are reused."""
+    the scalar cache, the K2a -> K2b hand-off buffers are reused.  (The host-pointer entry point moves the batch
+    in sub-chunks of 6144, each a device call of its own; test_launch_groups_inside_one_device_call makes one
+    such call span several groups.)"""
     import linearham_amd
     h = orc.PhyloHMM(os.path.join(data_dir, "phylo_hmm_input_extra.yaml"), 0,
                      os.path.join(data_dir, "hmm_params"), 0)
@@ -194,6 +196,20 @@ def test_more_samples_than_one_launch_group(hip, data_dir):
     fam.close()
     want = np.array([ref[j] for j in pick])
     np.testing.assert_allclose(ll, want, rtol=1e-10)
+
+
+def test_launch_groups_inside_one_device_call(data_dir):
+    """lh_eval_batch_device splits a call that exceeds the launch-group size (49152 samples, or what 16 GB of
+    workspace hold) into groups run back to back over one workspace; LH_CHUNK (read once per process) makes the
+    group small enough for the test above to cross it: 6144-sample calls become groups of 4096 + 2048."""
+    import subprocess
+    import sys
+    code = ("import linearham_amd, tests.test_gpu_parity as t; "
+            "t.test_more_samples_than_one_launch_group(linearham_amd.load_library(), %r)" % data_dir)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, LH_CHUNK="4096"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("preset", ["small", "medium", "igk", "igl", "many_alleles", "many_alleles_igk"])

@@ -6,7 +6,7 @@
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh r02_bench [evals-per-launch] [bench.py args...]
 set -e
 tag=${1:-r02_bench}
-epl=${2:-24576}
+epl=${2:-49152}
 shift || true
 shift || true
 root=${GRAFT_REPO_ROOT:-$(pwd)}
