@@ -150,6 +150,55 @@ int lh_family_consensus_sets(const lh_family* fam);
  * then in this mode's scaling (value x 2^(-256 count) is what agrees), which is the documented divergence. */
 int lh_family_set_extended_range(lh_family* fam, int enable);
 
+/* ---- naive-sequence sampling on the device (HMM::SampleNaiveSequence's draws, src/HMM.cpp:323-341,358-431,
+ * 1222-1353) ----
+ * One junction in the unfused form FillTransition (src/HMM.cpp:964-1089) multiplies together, so that the
+ * sampler's weights carry the bits of the reference's dense transition matrices.  [W][nL] / [W][nR] tables,
+ * unpadded; "dense" = index in the junction's state vector (HMM::*_junction_state_strs_). */
+typedef struct {
+  int32_t n_rows, n_left, n_right, n_states;
+  const int32_t* left_rows;    /* [nL] junction rows the gene has states on (rows 0 .. left_rows-1) */
+  const int32_t* left_dense;   /* [nL] dense index of its row-0 state */
+  const double* left_lo;       /* [W][nL] landing_out[p] of the row-i state */
+  const double* left_trans;    /* [W][nL] transition[p-1] into the row-i state; row 0: out of the germline region */
+  const double* enter_lo;      /* [nL] landing_out of the last germline-region position */
+  const int32_t* right_dense;  /* [nR] dense index of the gene's NTI state A */
+  const int32_t* right_first;  /* [nR] first row with a germline state of the gene (W: none) */
+  const double* gene_prob;     /* [nR] */
+  const double* nti_landing_in;  /* [nR][4] */
+  const double* nti_transition;  /* [nR][4][4] from a to b */
+  const double* nti_landing_out; /* [W][nR][4] into the row-i germline state */
+  const double* landing_in;    /* [W][nR] of the row-i germline state */
+  const double* right_trans;   /* [W][nR] transition[q-1] into the row-i germline state from the row before */
+  const double* exit_nlo;      /* [nR][4] nti_landing_out[b][q0] * prod */
+  const double* exit_trans;    /* [nR] transition[q0-1] * prod (0 if the gene has no last-row state) */
+  const double* exit_li;       /* [nR] landing_in[q0] */
+  const double* prod;          /* [nR] product of the in-region transitions (src/HMM.cpp:872-876) */
+} lh_sampler_junction;
+
+typedef struct {
+  lh_sampler_junction vd, dj; /* dj unused when has_d == 0 */
+} lh_sampler_desc;
+
+/* Registers the sampler tables of a family (copied to the device).  Fails if the genes of a junction are not laid
+ * out as two blocks in its state vector (all left genes before all right genes or the reverse: true of every IG
+ * locus, whose gene names sort by segment). */
+int lh_family_set_sampler(lh_family* fam, const lh_sampler_desc* desc);
+
+/* std::mt19937 outputs one sample consumes (two per draw; a draw per junction row and per germline region with
+ * more than one allele) and ints per sample in `states`. */
+int32_t lh_sample_words(const lh_family* fam);
+int32_t lh_sample_states(const lh_family* fam);
+
+/* lh_eval_batch followed by the draws of SampleNaiveSequence for every sample, the forward arrays staying on the
+ * device.  words [n][lh_sample_words()]: each sample's slice of the engine's output stream, in the order the
+ * reference's loop would consume it.  states [n][lh_sample_states()]: J gene | D-J junction rows 0..W-1 | D gene |
+ * V-D junction rows | V gene (light chains: J gene | V-J rows | V gene), as indices into the reference's state
+ * vectors -- the values HMM::*_state_ind_samp(s)_ take.  rates [n][R] may be NULL. */
+int lh_eval_sample_batch(lh_family* fam, int32_t n, int32_t n_tips, int32_t max_depth, const int32_t* ops,
+                         const double* brlen, const double* er, const double* pi, const double* alpha,
+                         int32_t num_rates, const uint32_t* words, double* loglik, double* rates, int32_t* states);
+
 /* Tree in rooted-at-naive form: tips are nodes 0..T-1 (0 = `naive`, i = MSA row i-1), inner nodes
  * T..2T-3.  children[2*(v-T)+{0,1}] are the two children of inner node v when the tree is rooted at
  * `root`, the inner node adjacent to `naive`.  Writes the kernel's post-order schedule:

@@ -9,7 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib")
-HIP_SOURCES = ["lh_model.hip", "lh_prune.hip", "lh_forward.hip", "lh_asr.hip", "lh_capi.hip"]
+HIP_SOURCES = ["lh_model.hip", "lh_prune.hip", "lh_forward.hip", "lh_asr.hip", "lh_sample.hip", "lh_capi.hip"]
 
 
 def _run(cmd, verbose):

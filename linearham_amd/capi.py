@@ -43,7 +43,8 @@ class _EvalOutputs(C.Structure):
 EXPORTS = ["lh_last_error", "lh_device_count", "lh_family_create", "lh_family_destroy",
            "lh_forward_size", "lh_scaler_size", "lh_family_info", "lh_family_consensus_sets", "lh_schedule_tree", "lh_eval_batch",
            "lh_eval_batch_device", "lh_forward_batch", "lh_asr_batch", "lh_asr_batch_device",
-           "lh_profile_enable", "lh_profile_read", "lh_asr_profile_read", "lh_family_set_extended_range", "lh_warmup", "lh_host_alloc", "lh_host_free"]
+           "lh_profile_enable", "lh_profile_read", "lh_asr_profile_read", "lh_family_set_extended_range", "lh_warmup", "lh_host_alloc", "lh_host_free", "lh_family_set_sampler",
+           "lh_sample_words", "lh_sample_states", "lh_eval_sample_batch"]
 
 
 def library_path():

@@ -680,6 +680,197 @@ JunctionTables HMM::BuildJunctionTables(const RegionStates& J, const RegionState
   return t;
 }
 
+lh_sampler_junction HMM::SamplerJunction::c() const {
+  lh_sampler_junction j;
+  j.n_rows = n_rows;
+  j.n_left = n_left;
+  j.n_right = n_right;
+  j.n_states = n_states;
+  j.left_rows = left_rows.data();
+  j.left_dense = left_dense.data();
+  j.left_lo = left_lo.data();
+  j.left_trans = left_trans.data();
+  j.enter_lo = enter_lo.data();
+  j.right_dense = right_dense.data();
+  j.right_first = right_first.data();
+  j.gene_prob = gene_prob.data();
+  j.nti_landing_in = nti_landing_in.data();
+  j.nti_transition = nti_transition.data();
+  j.nti_landing_out = nti_landing_out.data();
+  j.landing_in = landing_in.data();
+  j.right_trans = right_trans.data();
+  j.exit_nlo = exit_nlo.data();
+  j.exit_trans = exit_trans.data();
+  j.exit_li = exit_li.data();
+  j.prod = prod.data();
+  return j;
+}
+
+// The factors FillTransition (src/HMM.cpp:964-1089) multiplies, kept apart, per (junction row, gene): the device
+// sampler forms every transition value with the reference's own association (see lh_sample.hip).
+HMM::SamplerJunction HMM::BuildSamplerJunction(const RegionStates& J, const RegionStates& G_left,
+                                               const RegionStates& G_right, std::pair<int, int> left_fb,
+                                               std::pair<int, int> right_fb) const {
+  SamplerJunction t;
+  const int js = left_fb.first;
+  const int W = right_fb.second - left_fb.first;
+  const int nL = (int)G_left.ggene_ranges.size(), nR = (int)G_right.ggene_ranges.size();
+  t.n_rows = W;
+  t.n_left = nL;
+  t.n_right = nR;
+  t.n_states = (int)J.state_strs.size();
+  t.left_rows.assign(nL, 0);
+  t.left_dense.assign(nL, 0);
+  t.left_lo.assign((std::size_t)W * nL, 0.0);
+  t.left_trans.assign((std::size_t)W * nL, 0.0);
+  t.enter_lo.assign(nL, 0.0);
+  t.right_dense.assign(nR, 0);
+  t.right_first.assign(nR, W);
+  t.gene_prob.assign(nR, 0.0);
+  t.nti_landing_in.assign((std::size_t)nR * 4, 0.0);
+  t.nti_transition.assign((std::size_t)nR * 16, 0.0);
+  t.nti_landing_out.assign((std::size_t)W * nR * 4, 0.0);
+  t.landing_in.assign((std::size_t)W * nR, 0.0);
+  t.right_trans.assign((std::size_t)W * nR, 0.0);
+  t.exit_nlo.assign((std::size_t)nR * 4, 0.0);
+  t.exit_trans.assign(nR, 0.0);
+  t.exit_li.assign(nR, 0.0);
+  t.prod.assign(nR, 1.0);
+  int l = 0;
+  for (auto it = G_left.ggene_ranges.begin(); it != G_left.ggene_ranges.end(); ++it, ++l) {
+    const Germline& g = *ggenes_.at(it->first).germ_ptr;
+    const int p_last = G_left.germ_inds[it->second.second - 1];
+    t.enter_lo[l] = g.landing_out()[p_last];
+    const auto& rg = J.ggene_ranges.at(it->first);
+    const int cnt = rg.second - rg.first;
+    t.left_rows[l] = cnt;
+    t.left_dense[l] = rg.first;
+    if (cnt > 0) t.left_trans[l] = g.transition().at(p_last);  // row 0: out of the germline region
+    for (int i = 0; i < cnt; ++i) {
+      const int p = J.germ_inds[rg.first + i];
+      if (i >= 1) t.left_trans[(std::size_t)i * nL + l] = g.transition()[p - 1];
+      t.left_lo[(std::size_t)i * nL + l] = g.landing_out()[p];
+    }
+  }
+  int r = 0;
+  for (auto it = G_right.ggene_ranges.begin(); it != G_right.ggene_ranges.end(); ++it, ++r) {
+    const GermlineGene& gg = ggenes_.at(it->first);
+    const Germline& g = *gg.germ_ptr;
+    const NTInsertion& nti = gg.nti();
+    const auto& rg = J.ggene_ranges.at(it->first);
+    t.right_dense[r] = rg.first;
+    t.gene_prob[r] = g.gene_prob();
+    for (int b = 0; b < 4; ++b) {
+      t.nti_landing_in[(std::size_t)r * 4 + b] = nti.nti_landing_in()[b];
+      for (int c = 0; c < 4; ++c) t.nti_transition[(std::size_t)r * 16 + b * 4 + c] = nti.nti_transition()(b, c);
+    }
+    bool first = true;
+    int last_row = -1;
+    for (int k = rg.first + 4; k < rg.second; ++k) {
+      const int q = J.germ_inds[k];
+      const int i = J.site_inds[k] - js;
+      if (first) t.right_first[r] = i;
+      for (int b = 0; b < 4; ++b) t.nti_landing_out[((std::size_t)i * nR + r) * 4 + b] = nti.nti_landing_out()(b, q);
+      if (!first) t.right_trans[(std::size_t)i * nR + r] = g.transition()[q - 1];
+      t.landing_in[(std::size_t)i * nR + r] = g.landing_in()[q];
+      first = false;
+      last_row = i;
+    }
+    const int trs = it->second.first, tre = it->second.second;
+    const int q0 = G_right.germ_inds[trs];
+    double prod = 1.0;
+    for (int k = 0; k < tre - trs - 1; ++k) prod *= g.transition()[q0 + k];
+    t.prod[r] = prod;
+    for (int b = 0; b < 4; ++b) t.exit_nlo[(std::size_t)r * 4 + b] = nti.nti_landing_out()(b, q0) * prod;
+    if (last_row == W - 1) t.exit_trans[r] = g.transition().at(q0 - 1) * prod;
+    t.exit_li[r] = g.landing_in()[q0];
+  }
+  return t;
+}
+
+namespace {
+
+// What SampleJunctionStates (src/HMM.cpp:1222-1278) does with the drawn states, in its order (last row first).
+void ApplyJunctionStates(const int32_t* k_of_row, const RegionStates& J, int W, GermlineType left_gtype,
+                         GermlineType right_gtype, int site_start, const std::string& alphabet, std::string& naive_seq,
+                         int& germ_left_del, std::vector<std::string>& strs, std::vector<int>& inds,
+                         std::string& insertion, int& germ_right_del) {
+  strs.assign(W, "");
+  inds.assign(W, -1);
+  insertion = "";
+  germ_right_del = -1;
+  for (int i = W - 1; i >= 0; i--) {
+    const int k = k_of_row[i];
+    inds[i] = k;
+    strs[i] = J.state_strs[k];
+    naive_seq[site_start + i] = alphabet[J.naive_bases[k]];
+    if (J.ggene_types[k] == right_gtype) {
+      if (J.del[k] != -1) {
+        germ_left_del = J.del[k];
+      } else {
+        insertion = alphabet[J.naive_bases[k]] + insertion;
+      }
+    } else if (J.ggene_types[k] == left_gtype && germ_right_del == -1) {
+      germ_right_del = J.del[k];
+    }
+  }
+}
+
+// ... and SampleGermlineState (src/HMM.cpp:1316-1353)
+void ApplyGermlineState(int ind, const RegionStates& G, const std::string& alphabet, std::string& naive_seq,
+                        std::string& str, int& state_ind, int& left_del, int& right_del) {
+  state_ind = ind;
+  str = G.state_strs[ind];
+  left_del = G.left_del[ind];
+  if (right_del == -1) right_del = G.right_del[ind];
+  const auto& rg = G.ggene_ranges.at(str);
+  for (int i = rg.first; i < rg.second; i++) naive_seq[G.site_inds[i]] = alphabet[G.naive_bases[i]];
+}
+
+}  // namespace
+
+void HMM::ApplySampledStates(RowSampler& s, const int32_t* st) const {
+  const bool igh = locus_ == "igh";
+  s.naive_seq.assign(msa_.cols(), 'N');
+  int o = 0;
+  {  // SampleInitialState
+    s.jgerm_state_ind = st[o++];
+    s.jgerm_state_str = jgerm_.state_strs[s.jgerm_state_ind];
+    s.jgerm_left_del = jgerm_.left_del[s.jgerm_state_ind];
+    s.jgerm_right_del = jgerm_.right_del[s.jgerm_state_ind];
+    const auto& rg = jgerm_.ggene_ranges.at(s.jgerm_state_str);
+    for (int i = rg.first; i < rg.second; i++) s.naive_seq[jgerm_.site_inds[i]] = alphabet_[jgerm_.naive_bases[i]];
+  }
+  const int W1 = flexbounds_.at(igh ? "d_l" : "j_l").second - flexbounds_.at("v_r").first;
+  if (igh) {
+    const int W2 = flexbounds_.at("j_l").second - flexbounds_.at("d_r").first;
+    ApplyJunctionStates(st + o, dj_junction_, W2, GermlineType::D, GermlineType::J, flexbounds_.at("d_r").first, alphabet_,
+                        s.naive_seq, s.jgerm_left_del, s.dj_junction_state_strs, s.dj_junction_state_inds,
+                        s.dj_junction_insertion, s.dgerm_right_del);
+    o += W2;
+    ApplyGermlineState(st[o++], dgerm_, alphabet_, s.naive_seq, s.dgerm_state_str, s.dgerm_state_ind, s.dgerm_left_del,
+                       s.dgerm_right_del);
+    ApplyJunctionStates(st + o, vd_junction_, W1, GermlineType::V, GermlineType::D, flexbounds_.at("v_r").first, alphabet_,
+                        s.naive_seq, s.dgerm_left_del, s.vd_junction_state_strs, s.vd_junction_state_inds,
+                        s.vd_junction_insertion, s.vgerm_right_del);
+  } else {
+    ApplyJunctionStates(st + o, vd_junction_, W1, GermlineType::V, GermlineType::J, flexbounds_.at("v_r").first, alphabet_,
+                        s.naive_seq, s.jgerm_left_del, s.vd_junction_state_strs, s.vd_junction_state_inds,
+                        s.vd_junction_insertion, s.vgerm_right_del);
+  }
+  o += W1;
+  ApplyGermlineState(st[o], vgerm_, alphabet_, s.naive_seq, s.vgerm_state_str, s.vgerm_state_ind, s.vgerm_left_del,
+                     s.vgerm_right_del);
+  const std::string& q = s.naive_seq;
+  std::size_t a = 0, b = q.size();
+  while (a < q.size() && q[a] == 'N') ++a;
+  while (b > a && q[b - 1] == 'N') --b;
+  bool ok = b > a;
+  for (std::size_t i = a; i < b && ok; ++i) ok = alphabet_.find(q[i]) != std::string::npos && q[i] != 'N';
+  s.vgerm_left_insertion = ok ? q.substr(0, a) : "";
+  s.jgerm_right_insertion = ok ? q.substr(b) : "";
+}
+
 ColumnLists ColumnLists::Build(const MatrixXd& M) {
   ColumnLists c;
   const int R = M.rows(), C = M.cols();

@@ -97,6 +97,7 @@ class HMM {
 
   // GPU side
   lh_family* family_ = nullptr;
+  bool device_sampler_ = false;  // lh_family_set_sampler accepted this family's junctions
 
   void InitializeMsa();
   void InitializeStateSpace();
@@ -129,6 +130,20 @@ class HMM {
   /// more weights takes one generate_canonical<double, 53> = two outputs, and the number of draws per sample is
   /// fixed by the family (one per germline region with more than one allele, one per junction site).
   int RawDrawsPerSample() const;
+  /// The rest of a sample once its states are known (drawn on the device, lh_eval_sample_batch): naive sequence,
+  /// gene names, deletions and insertions exactly as SampleRow derives them from the same state indices.
+  /// states: J gene | D-J junction rows | D gene | V-D junction rows | V gene (light chains: J | V-J rows | V).
+  void ApplySampledStates(RowSampler& s, const int32_t* states) const;
+  /// Sampler tables of the device path (lh_family_set_sampler) with their storage.
+  struct SamplerJunction {
+    int n_rows = 0, n_left = 0, n_right = 0, n_states = 0;
+    std::vector<int32_t> left_rows, left_dense, right_dense, right_first;
+    std::vector<double> left_lo, left_trans, enter_lo, gene_prob, nti_landing_in, nti_transition, nti_landing_out,
+        landing_in, right_trans, exit_nlo, exit_trans, exit_li, prod;
+    lh_sampler_junction c() const;
+  };
+  SamplerJunction BuildSamplerJunction(const RegionStates& J, const RegionStates& G_left, const RegionStates& G_right,
+                                       std::pair<int, int> left_fb, std::pair<int, int> right_fb) const;
 
  protected:
   /// Runs the device forward pass if needed (pure virtual: the derived class knows how the

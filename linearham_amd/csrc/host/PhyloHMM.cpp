@@ -131,6 +131,24 @@ void PhyloHMM::CreateFamily() {
   StageTimer timer;
   CheckHip(lh_family_create(&d, &family_), "lh_family_create");
   timer.Mark("lh_family_create (+ HIP init)");
+  // Device-side naive-sequence sampling (lh_eval_sample_batch).  The one structural condition it has -- the left and
+  // the right genes of a junction occupy two blocks of the junction's state vector, true for gene names that start
+  // with their locus and segment letters -- is checked by the library; a family that does not meet it keeps the
+  // host sampler (the same algorithm, HMM::SampleRow), and so does LH_HOST_SAMPLING=1.
+  if (std::getenv("LH_HOST_SAMPLING") == nullptr) {
+    SamplerJunction svd, sdj;
+    lh_sampler_desc sd{};
+    if (igh) {
+      svd = BuildSamplerJunction(vd_junction_, vgerm_, dgerm_, flexbounds_.at("v_r"), flexbounds_.at("d_l"));
+      sdj = BuildSamplerJunction(dj_junction_, dgerm_, jgerm_, flexbounds_.at("d_r"), flexbounds_.at("j_l"));
+      sd.dj = sdj.c();
+    } else {
+      svd = BuildSamplerJunction(vd_junction_, vgerm_, jgerm_, flexbounds_.at("v_r"), flexbounds_.at("j_l"));
+    }
+    sd.vd = svd.c();
+    device_sampler_ = lh_family_set_sampler(family_, &sd) == 0 && lh_sample_words(family_) == RawDrawsPerSample();
+    timer.Mark("lh_family_set_sampler");
+  }
 }
 
 // src/PhyloHMM.cpp:350-361
@@ -600,13 +618,16 @@ PhyloHMM::DeviceBatch PhyloHMM::FlattenTsv(const std::string& path, int* n_rows)
 }
 
 // src/PhyloHMM.cpp:393-446.  The reference evaluates, samples and writes row by row on one core.  Here the table
-// is read once, and per batch of rows: worker threads parse and schedule the trees, the GPU evaluates the batch,
-// and worker threads draw the naive sequences and format the output lines, which are written in file order.
+// is read once, and per batch of rows: worker threads parse and schedule the trees, the GPU evaluates the batch and
+// draws every row's states (lh_eval_sample_batch), and worker threads derive the naive sequences from the states and
+// format the output lines, which are written in file order.
 // Sampling consumes ONE std::mt19937 stream in file order (src/HMM.cpp:56); a sample takes a fixed number of
-// engine outputs (HMM::RawDrawsPerSample), so the worker that starts at row r copies the engine and skips
-// r samples' worth of outputs: every row sees exactly the numbers it would see in the serial loop (checked on
-// the first row of every run, and by the seed-0 goldens).  The last row goes through the object's own members,
-// which are then in the state the reference's loop leaves behind.
+// engine outputs (HMM::RawDrawsPerSample), so a row's outputs can be handed to whoever draws for it: the device
+// gets them as words[row][...], a host worker that starts at row r copies the engine and skips r samples' worth
+// (LH_HOST_SAMPLING=1, or a family whose junction genes do not form two blocks of the state vector).  Every row
+// sees exactly the numbers it would see in the serial loop (the host sampler repeats the device's first and last
+// row on every run; the seed-0 goldens).  The last row also goes through the object's own members, which are then
+// in the state the reference's loop leaves behind.
 void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& output_path, int num_rates) {
   const bool timing = std::getenv("LH_PIPELINE_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
@@ -635,13 +656,18 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
   const std::size_t FS = lh_forward_size(family_), SS = lh_scaler_size(family_);
   const int T = (int)xmsa_labels_.size();
   const int raw_per_sample = RawDrawsPerSample();
+  // Sampling on the device when the family has its sampler tables: the forward arrays then never leave the GPU, the
+  // host sends each row's slice of the engine's output stream and gets the sampled states back.
+  const bool dev_sampling = device_sampler_;
+  const std::size_t NS = dev_sampling ? (std::size_t)lh_sample_states(family_) : 0;
   // Two stages, two batches in flight: a producer thread parses / schedules batch k + 1 and has the GPU
   // evaluate it into one of two page-locked result slots while this thread's workers sample and format batch k.
   const std::size_t kBatch = std::min<std::size_t>(2048, std::max<std::size_t>(N, 1));
   struct Slot {
     TableBatch tb;
     double *ll = nullptr, *rates = nullptr, *fwd = nullptr;
-    int32_t* sco = nullptr;
+    int32_t *sco = nullptr, *states = nullptr;
+    std::vector<uint32_t> words;
     std::size_t off = 0, m = 0;
     int state = 0;  // 0 free, 1 filled
   };
@@ -654,9 +680,12 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
   auto alloc_slot = [&](Slot& s) {
     s.ll = static_cast<double*>(lh_host_alloc(sizeof(double) * kBatch));
     s.rates = static_cast<double*>(lh_host_alloc(sizeof(double) * kBatch * num_rates));
-    s.fwd = static_cast<double*>(lh_host_alloc(sizeof(double) * kBatch * FS));
-    s.sco = static_cast<int32_t*>(lh_host_alloc(sizeof(int32_t) * kBatch * SS));
-    if (!s.ll || !s.rates || !s.fwd || !s.sco) throw std::runtime_error(lh_last_error());
+    // device sampling keeps forward arrays for two rows only: the table's first (cross-check) and last (members)
+    const std::size_t fwd_rows = dev_sampling ? 2 : kBatch;
+    s.fwd = static_cast<double*>(lh_host_alloc(sizeof(double) * fwd_rows * FS));
+    s.sco = static_cast<int32_t*>(lh_host_alloc(sizeof(int32_t) * fwd_rows * SS));
+    if (dev_sampling) s.states = static_cast<int32_t*>(lh_host_alloc(sizeof(int32_t) * kBatch * NS));
+    if (!s.ll || !s.rates || !s.fwd || !s.sco || (dev_sampling && !s.states)) throw std::runtime_error(lh_last_error());
   };
   auto free_slots = [&] {
     for (Slot& s : slots) {
@@ -664,11 +693,14 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       lh_host_free(s.rates);
       lh_host_free(s.fwd);
       lh_host_free(s.sco);
+      lh_host_free(s.states);
     }
   };
+  double t_words = 0;
   std::thread producer([&] {
     try {
       int k = 0;
+      std::mt19937 word_rng = rng_;  // rows are produced in file order: the engine copy just runs on
       for (std::size_t off = 0; off < N; off += kBatch, k ^= 1) {
         Slot& s = slots[k];
         const std::size_t m = std::min(kBatch, N - off);
@@ -685,11 +717,30 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
         s.off = off;
         s.m = m;
         const DeviceBatch& b = s.tb.dev;
-        lh_eval_outputs outs{s.rates, nullptr, s.fwd, s.sco};
         const auto t2 = now();
-        CheckHip(lh_eval_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(),
-                               b.pi.data(), b.alpha.data(), num_rates, s.ll, &outs),
-                 "lh_eval_batch");
+        if (dev_sampling) {
+          s.words.resize(m * (std::size_t)raw_per_sample);
+          for (uint32_t& w : s.words) w = (uint32_t)word_rng();
+          t_words += secs(t2, now());
+          CheckHip(lh_eval_sample_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(),
+                                        b.pi.data(), b.alpha.data(), num_rates, s.words.data(), s.ll, s.rates, s.states),
+                   "lh_eval_sample_batch");
+          auto one_row = [&](std::size_t i, int k_fwd) {  // forward arrays of one row, for the host-side checks
+            const std::size_t n_ops = (std::size_t)(b.n_tips - 2) * 4, nodes = 2 * (std::size_t)b.n_tips - 2;
+            double ll1 = 0;
+            lh_eval_outputs outs{nullptr, nullptr, s.fwd + k_fwd * FS, s.sco + k_fwd * SS};
+            CheckHip(lh_eval_batch(family_, 1, b.n_tips, b.max_depth, b.ops.data() + i * n_ops, b.brlen.data() + i * nodes,
+                                   b.er.data() + i * 6, b.pi.data() + i * 4, b.alpha.data() + i, num_rates, &ll1, &outs),
+                     "lh_eval_batch");
+          };
+          if (off == 0) one_row(0, 0);
+          if (off + m == N) one_row(m - 1, 1);
+        } else {
+          lh_eval_outputs outs{s.rates, nullptr, s.fwd, s.sco};
+          CheckHip(lh_eval_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(),
+                                 b.pi.data(), b.alpha.data(), num_rates, s.ll, &outs),
+                   "lh_eval_batch");
+        }
         const auto t3 = now();
         t_flat += secs(t0, t1);
         t_eval += secs(t2, t3);
@@ -750,11 +801,21 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       try {
         RowSampler s;
         std::mt19937 rng = rng_;
-        rng.discard((unsigned long long)(off + lo) * (unsigned long long)raw_per_sample);
+        if (!dev_sampling) rng.discard((unsigned long long)(off + lo) * (unsigned long long)raw_per_sample);
         std::string& o = chunks[w];
         o.reserve((hi - lo) * (tb.exported.empty() ? 512 : tb.exported[lo].size() + 1024));
         for (std::size_t i = lo; i < hi; ++i) {
-          if (off + i == 0) {  // the bookkeeping above rests on this count: check it where it is cheap
+          if (dev_sampling) {
+            ApplySampledStates(s, slot.states + i * NS);
+            if (off + i == 0) {  // the device's draws against the host sampler's, where it is cheap
+              RowSampler h;
+              SampleRow(h, fwd, rng);
+              if (h.naive_seq != s.naive_seq || h.vd_junction_state_inds != s.vd_junction_state_inds ||
+                  h.dj_junction_state_inds != s.dj_junction_state_inds || h.vgerm_state_ind != s.vgerm_state_ind ||
+                  h.dgerm_state_ind != s.dgerm_state_ind || h.jgerm_state_ind != s.jgerm_state_ind)
+                throw std::runtime_error("RunPipeline: the device sampler and the host sampler disagree on the first row");
+            }
+          } else if (off + i == 0) {  // the bookkeeping above rests on this count: check it where it is cheap
             std::mt19937 expect = rng;
             SampleRow(s, fwd + i * FS, rng);
             expect.discard((unsigned long long)raw_per_sample);
@@ -791,6 +852,9 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
     if (m_par < m) {
       // the last row of the table, through the members (as every row goes in the reference)
       const std::size_t i = m - 1;
+      // (with device sampling the forward arrays of this row sit in the slot's second place)
+      const double* fwd_i = dev_sampling ? slot.fwd + FS : fwd + i * FS;
+      const int32_t* sco_i = dev_sampling ? slot.sco + SS : sco + i * SS;
       rng_.discard((unsigned long long)(N - 1) * (unsigned long long)raw_per_sample);
       iteration_ = tb.iteration[i];
       rb_loglikelihood_ = tb.lik[i];
@@ -811,13 +875,19 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       have_tree_ = true;
       pending_newick_ = &tb.exported[i];
       sr_.assign(rates + i * num_rates, rates + (i + 1) * num_rates);
-      pending_forward_.assign(fwd + i * FS, fwd + (i + 1) * FS);
-      pending_scalers_.assign(sco + i * SS, sco + (i + 1) * SS);
+      pending_forward_.assign(fwd_i, fwd_i + FS);
+      pending_scalers_.assign(sco_i, sco_i + SS);
       pending_loglik_ = ll[i];
       cache_forward_ = true;
       lh_loglikelihood_ = LogLikelihood();
       logweight_ = lh_loglikelihood_ - rb_loglikelihood_;
       naive_sequence_ = SampleNaiveSequence();
+      if (dev_sampling) {
+        RowSampler d;
+        ApplySampledStates(d, slot.states + i * NS);
+        if (d.naive_seq != naive_sequence_)
+          throw std::runtime_error("RunPipeline: the device sampler and the host sampler disagree on the last row");
+      }
       WriteOutputLine(outfile);
       pending_newick_ = nullptr;
     }
@@ -834,9 +904,11 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
   outfile.close();
   if (timing)
     std::fprintf(stderr,
-                 "[RunPipeline] %zu rows: read %.3f s; producer: parse+schedule %.3f s, device (incl. copies) %.3f s; "
-                 "consumer: waiting %.3f s, sample+format %.3f s, write %.3f s; total %.3f s\n",
-                 N, secs(t_start, t_read), t_flat, t_eval, t_wait, t_samp, t_write, secs(t_start, now()));
+                 "[RunPipeline] %zu rows: read %.3f s; producer: parse+schedule %.3f s, device (incl. copies%s) %.3f s; "
+                 "consumer (%s): waiting %.3f s, sample+format %.3f s, write %.3f s; total %.3f s\n",
+                 N, secs(t_start, t_read), t_flat, dev_sampling ? (", engine words " + std::to_string(t_words) + " s").c_str() : "",
+                 t_eval, dev_sampling ? "device sampler" : "host sampler", t_wait, t_samp,
+                 t_write, secs(t_start, now()));
 }
 
 // scripts/run_bootstrap_asr_ess.R:86-101: the tree rooted on the naive branch (the added root node sits at

@@ -1,6 +1,8 @@
 // `linearham` command line (same sub-commands and flag names as src/linearham.cpp:268-455 of the
 // reference, without TCLAP): --compute-logl | --sample | --pipeline; plus --asr, the per-tree body of
 // scripts/run_bootstrap_asr_ess.R:48-104 on a --pipeline output table.
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <iostream>
 #include <map>
@@ -56,6 +58,9 @@ int main(int argc, char** argv) {
                    "--hmm-param-dir <string> [--seed <int>] [--num-rates <int>] [--extended-range <0|1>] ...\n";
       return argc < 2 ? EXIT_FAILURE : EXIT_SUCCESS;
     }
+    const auto t_main = std::chrono::steady_clock::now();
+    const bool timing = std::getenv("LH_PIPELINE_TIMING") != nullptr;
+    auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(); };
     const std::string subcmd = argv[1];
     const Args a = Parse(argc, argv, 2);
     if (subcmd != "--compute-logl" && subcmd != "--sample" && subcmd != "--pipeline" && subcmd != "--asr")
@@ -76,10 +81,14 @@ int main(int argc, char** argv) {
     linearham::PhyloHMMPtr phylo_hmm_ptr =
         std::make_shared<linearham::PhyloHMM>(yaml_path, cluster_ind, hmm_param_dir, seed);
     warmup.join();
+    if (timing) std::fprintf(stderr, "[main] family object + HIP context ready at %.3f s\n", since_start());
     // not in the reference: finite log-likelihoods where its scaling over/underflows (include/linearham_amd.h)
     if (std::stoi(a.opt("extended-range", "0")) != 0) phylo_hmm_ptr->SetExtendedRange(true);
     if (subcmd == "--pipeline") {
       phylo_hmm_ptr->RunPipeline(a.one("input-path"), a.one("output-path"), num_rates);
+      if (timing) std::fprintf(stderr, "[main] RunPipeline returned at %.3f s\n", since_start());
+      phylo_hmm_ptr.reset();
+      if (timing) std::fprintf(stderr, "[main] family released at %.3f s\n", since_start());
       return EXIT_SUCCESS;
     }
     if (subcmd == "--asr") {

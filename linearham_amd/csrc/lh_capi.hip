@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -86,6 +87,14 @@ struct lh_family {
   HostPipe pipe;
   bool profile = false;
   bool extended = false;  // lh_family_set_extended_range
+  bool have_sampler = false;
+  lh::DevSampler sampler{};  // device pointers inside (arena)
+  struct {                   // lh_eval_sample_batch's device buffers (grow-only)
+    size_t cap[9] = {0};
+    void* ptr[9] = {nullptr};
+    void* pinned = nullptr;  // page-locked staging of the six input arrays
+    size_t pinned_cap = 0;
+  } smp;
   std::vector<EventSet> events;
   double ms[3] = {0, 0, 0};
   int64_t launches = 0;
@@ -638,6 +647,9 @@ void lh_family_destroy(lh_family* f) {
   }
   for (EventSet& es : f->events)
     for (hipEvent_t e : es.e) (void)hipEventDestroy(e);
+  for (void* p : f->smp.ptr)
+    if (p) (void)hipFree(p);
+  if (f->smp.pinned) (void)hipHostFree(f->smp.pinned);
   for (void* p : f->pipe.pinned)
     if (p) (void)hipHostFree(p);
   for (hipEvent_t e : f->pipe.staged)
@@ -782,6 +794,85 @@ int lh_family_set_extended_range(lh_family* f, int enable) {
   f->extended = enable != 0;
   return 0;
 }
+
+static int upload_sampler_junction(lh_family* f, const lh_sampler_junction& j, lh::DevSampleJunction* d) {
+  const size_t W = j.n_rows, nL = j.n_left, nR = j.n_right;
+  if (j.n_rows < 1 || j.n_left < 1 || j.n_right < 1 || j.n_states < 2) return fail("lh_family_set_sampler: bad dimensions");
+  if (!j.left_rows || !j.left_dense || !j.left_lo || !j.left_trans || !j.enter_lo || !j.right_dense || !j.right_first ||
+      !j.gene_prob || !j.nti_landing_in || !j.nti_transition || !j.nti_landing_out || !j.landing_in || !j.right_trans ||
+      !j.exit_nlo || !j.exit_trans || !j.exit_li || !j.prod)
+    return fail("lh_family_set_sampler: null array in descriptor");
+  // the genes must form two blocks of the dense state vector, each in gene order, with consistent lengths
+  int lo_l = INT32_MAX, hi_l = -1, lo_r = INT32_MAX, hi_r = -1;
+  for (size_t l = 0; l < nL; ++l) {
+    if (j.left_rows[l] < 0 || j.left_rows[l] > j.n_rows || j.left_dense[l] < 0) return fail("lh_family_set_sampler: bad left gene");
+    if (l > 0 && j.left_dense[l] < j.left_dense[l - 1] + j.left_rows[l - 1]) return fail("lh_family_set_sampler: left genes out of order");
+    lo_l = std::min(lo_l, j.left_dense[l]);
+    hi_l = std::max(hi_l, j.left_dense[l] + j.left_rows[l]);
+  }
+  for (size_t r = 0; r < nR; ++r) {
+    if (j.right_first[r] < 0 || j.right_first[r] > j.n_rows || j.right_dense[r] < 0) return fail("lh_family_set_sampler: bad right gene");
+    const int len = 4 + (j.n_rows - j.right_first[r]);
+    if (r > 0 && j.right_dense[r] < j.right_dense[r - 1] + 4) return fail("lh_family_set_sampler: right genes out of order");
+    lo_r = std::min(lo_r, j.right_dense[r]);
+    hi_r = std::max(hi_r, j.right_dense[r] + len);
+  }
+  if (!(hi_r <= lo_l || hi_l <= lo_r) || std::max(hi_l, hi_r) > j.n_states)
+    return fail("lh_family_set_sampler: the junction's genes do not form two blocks of its state vector");
+  d->n_rows = j.n_rows;
+  d->n_left = j.n_left;
+  d->n_right = j.n_right;
+  d->n_states = j.n_states;
+  d->right_first_block = hi_r <= lo_l ? 1 : 0;
+  std::vector<int32_t> cls((size_t)j.n_states, 0);
+  for (size_t l = 0; l < nL; ++l)
+    for (int i = 0; i < j.left_rows[l]; ++i) cls[(size_t)j.left_dense[l] + i] = 0 | (int32_t)(l << 4);
+  for (size_t r = 0; r < nR; ++r) {
+    for (int b = 0; b < 4; ++b) cls[(size_t)j.right_dense[r] + b] = 1 | (b << 2) | (int32_t)(r << 4);
+    for (int i = j.right_first[r]; i < j.n_rows; ++i) cls[(size_t)j.right_dense[r] + 4 + (i - j.right_first[r])] = 2 | (int32_t)(r << 4);
+  }
+  if (upload(f, cls.data(), cls.size(), &d->state_class)) return 1;
+  if (upload(f, j.left_rows, nL, &d->left_rows) || upload(f, j.left_dense, nL, &d->left_dense) ||
+      upload(f, j.left_lo, W * nL, &d->left_lo) || upload(f, j.left_trans, W * nL, &d->left_trans) ||
+      upload(f, j.enter_lo, nL, &d->enter_lo) || upload(f, j.right_dense, nR, &d->right_dense) ||
+      upload(f, j.right_first, nR, &d->right_first) || upload(f, j.gene_prob, nR, &d->gp) ||
+      upload(f, j.nti_landing_in, nR * 4, &d->nli) || upload(f, j.nti_transition, nR * 16, &d->ntt) ||
+      upload(f, j.nti_landing_out, W * nR * 4, &d->nlo) || upload(f, j.landing_in, W * nR, &d->li) ||
+      upload(f, j.right_trans, W * nR, &d->rtrans) || upload(f, j.exit_nlo, nR * 4, &d->exit_nlo) ||
+      upload(f, j.exit_trans, nR, &d->exit_trans) || upload(f, j.exit_li, nR, &d->exit_li) ||
+      upload(f, j.prod, nR, &d->prod))
+    return 1;
+  return 0;
+}
+
+int lh_family_set_sampler(lh_family* f, const lh_sampler_desc* desc) {
+  if (!f || !desc) return fail("lh_family_set_sampler: null argument");
+  const lh::DevFamily& h = f->host;
+  lh::DevSampler s{};
+  s.has_d = h.has_d;
+  s.n_v = h.vgerm.n_genes;
+  s.n_d = h.dgerm.n_genes;
+  s.n_j = h.jgerm.n_genes;
+  if (desc->vd.n_rows != h.vd.n_rows || desc->vd.n_left != h.vd.n_left || desc->vd.n_right != h.vd.n_right)
+    return fail("lh_family_set_sampler: V-D junction dimensions differ from the family's");
+  if (upload_sampler_junction(f, desc->vd, &s.vd)) return 1;
+  int draws = (s.n_j >= 2) + (s.n_v >= 2) + s.vd.n_rows;
+  s.states_per_sample = 2 + s.vd.n_rows;
+  if (h.has_d) {
+    if (desc->dj.n_rows != h.dj.n_rows || desc->dj.n_left != h.dj.n_left || desc->dj.n_right != h.dj.n_right)
+      return fail("lh_family_set_sampler: D-J junction dimensions differ from the family's");
+    if (upload_sampler_junction(f, desc->dj, &s.dj)) return 1;
+    draws += (s.n_d >= 2) + s.dj.n_rows;
+    s.states_per_sample += 1 + s.dj.n_rows;
+  }
+  s.words_per_sample = 2 * draws;
+  f->sampler = s;
+  f->have_sampler = true;
+  return 0;
+}
+
+int32_t lh_sample_words(const lh_family* f) { return f && f->have_sampler ? f->sampler.words_per_sample : 0; }
+int32_t lh_sample_states(const lh_family* f) { return f && f->have_sampler ? f->sampler.states_per_sample : 0; }
 
 int lh_profile_enable(lh_family* f, int enable) {
   if (!f) return fail("null family");
@@ -1014,6 +1105,89 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
     if (outs->scaler_counts)
       LH_HIP(hipMemcpy(outs->scaler_counts, d_outs.scaler_counts, sizeof(int32_t) * SS * n,
                        hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int lh_eval_sample_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const int32_t* ops,
+                         const double* brlen, const double* er, const double* pi, const double* alpha, int32_t R,
+                         const uint32_t* words, double* loglik, double* rates, int32_t* states) {
+  if (!f) return fail("lh_eval_sample_batch: null family");
+  if (!f->have_sampler) return fail("lh_eval_sample_batch: lh_family_set_sampler has not been called");
+  if (n <= 0) return n == 0 ? 0 : fail("lh_eval_sample_batch: negative batch size");
+  if (T < 3) return fail("lh_eval_sample_batch: need at least 3 tips");
+  if (!ops || !brlen || !er || !pi || !alpha || !words || !loglik || !states) return fail("lh_eval_sample_batch: null array");
+  const size_t nodes = 2 * (size_t)T - 2, n_ops = (size_t)T - 2, FS = f->host.forward_size;
+  static const bool timing = std::getenv("LH_SAMPLE_TIMING") != nullptr;  // stage times of every call, on stderr
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t0 = now();
+  for (size_t k = 0; k < (size_t)n * n_ops; ++k)
+    if (!valid_op(ops + k * 4, T, (int)nodes, max_depth))
+      return fail("lh_eval_sample_batch: malformed schedule op (use lh_schedule_tree)");
+  auto t1 = now();
+  const lh::DevSampler& smp = f->sampler;
+  const size_t bytes[9] = {sizeof(int32_t) * 4 * n_ops * n, sizeof(double) * nodes * n, sizeof(double) * 6 * n,
+                           sizeof(double) * 4 * n, sizeof(double) * n, sizeof(uint32_t) * smp.words_per_sample * (size_t)n,
+                           sizeof(double) * n /* loglik */, sizeof(double) * R * n /* rates */,
+                           sizeof(int32_t) * smp.states_per_sample * (size_t)n};
+  LH_HIP(hipDeviceSynchronize());  // earlier calls may still be using the buffers
+  void* d[9];
+  for (int a = 0; a < 9; ++a) {
+    if (bytes[a] > f->smp.cap[a]) {
+      if (f->smp.ptr[a]) LH_HIP(hipFree(f->smp.ptr[a]));
+      f->smp.ptr[a] = nullptr;
+      f->smp.cap[a] = 0;
+      LH_HIP(hipMalloc(&f->smp.ptr[a], bytes[a]));
+      f->smp.cap[a] = bytes[a];
+    }
+    d[a] = f->smp.ptr[a];
+  }
+  void* d_fwd;  // the forward arrays never leave the device
+  if (stage(f, 8, sizeof(double) * FS * n, &d_fwd)) return 1;
+  // The caller's arrays are ordinary pageable memory: copied from there, every transfer has the driver lock and
+  // unlock their pages, which stalls for milliseconds whenever other threads of the process are busy allocating
+  // (RunPipeline's formatting workers are).  One memcpy into a page-locked slot costs a fraction of that.
+  size_t in_bytes = 0;
+  for (int a = 0; a < 6; ++a) in_bytes += (bytes[a] + 63) & ~(size_t)63;
+  if (in_bytes > f->smp.pinned_cap) {
+    if (f->smp.pinned) LH_HIP(hipHostFree(f->smp.pinned));
+    f->smp.pinned = nullptr;
+    f->smp.pinned_cap = 0;
+    LH_HIP(hipHostMalloc(&f->smp.pinned, in_bytes, hipHostMallocDefault));
+    f->smp.pinned_cap = in_bytes;
+  }
+  auto t2 = now();
+  const void* src[6] = {ops, brlen, er, pi, alpha, words};
+  {
+    char* slot = static_cast<char*>(f->smp.pinned);
+    for (int a = 0; a < 6; ++a) {
+      memcpy(slot, src[a], bytes[a]);
+      LH_HIP(hipMemcpyAsync(d[a], slot, bytes[a], hipMemcpyHostToDevice, nullptr));
+      slot += (bytes[a] + 63) & ~(size_t)63;
+    }
+  }
+  auto t3 = now();
+  lh_eval_outputs outs{(double*)d[7], nullptr, (double*)d_fwd, nullptr};
+  if (lh_eval_batch_device(f, n, T, max_depth, (const int32_t*)d[0], (const double*)d[1], (const double*)d[2],
+                           (const double*)d[3], (const double*)d[4], R, (double*)d[6], &outs, nullptr))
+    return 1;
+  if (timing) LH_HIP(hipDeviceSynchronize());
+  auto t4 = now();
+  lh::launch_sample(smp, n, (const double*)d_fwd, FS, (const uint32_t*)d[5], smp.words_per_sample, (int32_t*)d[8], nullptr);
+  LH_HIP(hipGetLastError());
+  if (timing) LH_HIP(hipDeviceSynchronize());
+  auto t5 = now();
+  LH_HIP(hipMemcpy(loglik, d[6], bytes[6], hipMemcpyDeviceToHost));
+  if (rates) LH_HIP(hipMemcpy(rates, d[7], bytes[7], hipMemcpyDeviceToHost));
+  LH_HIP(hipMemcpy(states, d[8], bytes[8], hipMemcpyDeviceToHost));
+  if (timing) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    std::fprintf(stderr,
+                 "[lh_eval_sample_batch] n=%d: check ops %.2f ms, buffers %.2f, copies in %.2f, evaluation %.2f, sampling %.2f, "
+                 "copies out %.2f\n",
+                 n, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, now()));
   }
   return 0;
 }

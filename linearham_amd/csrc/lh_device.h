@@ -101,6 +101,42 @@ __device__ static inline double fast_rcp(double v) {
   return r;
 }
 
+// K4 (lh_sample.hip): what a backward sampling step needs of one junction, in the unfused form FillTransition
+// multiplies it together (src/HMM.cpp:964-1089), so that every weight has the bits of the dense matrices.
+// Unpadded [W][nL] / [W][nR] tables; dense = index in the reference's junction state vector.
+struct DevSampleJunction {
+  int32_t n_rows, n_left, n_right, n_states;
+  int32_t right_first_block;     // 1: the right genes' states precede the left genes' in the dense vector
+  const int32_t* state_class;    // [S] kind (0 left, 1 NTI, 2 right germline) | NTI base << 2 | gene << 4
+  const int32_t* left_rows;      // [nL] the gene has states on rows 0 .. left_rows - 1
+  const int32_t* left_dense;     // [nL] dense index of its row-0 state
+  const double* left_lo;         // [W][nL] landing_out of the row-i state
+  const double* left_trans;      // [W][nL] transition into the row-i state (row 0: out of the germline region)
+  const double* enter_lo;        // [nL] landing_out of the last germline-region position
+  const int32_t* right_dense;    // [nR] dense index of the gene's NTI state A
+  const int32_t* right_first;    // [nR] first row with a germline state of the gene (W: none)
+  const double* gp;              // [nR] gene_prob
+  const double* nli;             // [nR][4] nti_landing_in
+  const double* ntt;             // [nR][4][4] nti_transition a -> b
+  const double* nlo;             // [W][nR][4] nti_landing_out into the row-i germline state
+  const double* li;              // [W][nR] landing_in of the row-i germline state
+  const double* rtrans;          // [W][nR] transition into the row-i germline state from the row before
+  const double* exit_nlo;        // [nR][4] nti_landing_out into the germline region x prod
+  const double* exit_trans;      // [nR] transition into the germline region x prod (0: no last-row state)
+  const double* exit_li;         // [nR] landing_in of the germline region's first position
+  const double* prod;            // [nR] product of the in-region transitions (src/HMM.cpp:872-876)
+};
+
+struct DevSampler {
+  int32_t has_d, n_v, n_d, n_j, states_per_sample, words_per_sample;
+  DevSampleJunction vd, dj;
+};
+
+// K4: states[n][states_per_sample] from the compact forward arrays fwd[n][forward_size] and each sample's
+// std::mt19937 outputs words[n][words_per_sample].
+void launch_sample(const DevSampler& smp, int n, const double* fwd, size_t forward_size, const uint32_t* words,
+                   int words_per_sample, int32_t* states, hipStream_t stream);
+
 // P = I + U expm1(lambda * t*r) Uinv, clamped at 0 (K1's prologue).
 // e: lambda[4] | U[4][4] | Uinv[4][4]
 // (mode 0 is the stationary one, eigenvalue 0 -- K0a orders them so -- and contributes nothing: three modes are summed)

@@ -254,6 +254,43 @@ def test_cli_pipeline(tmp_path):
     assert bad.returncode != 0 and "ERROR:" in bad.stderr
 
 
+@pytest.mark.parametrize("locus, seed", [("igh", 3), ("igk", 4), ("igh", 11)])
+def test_device_sampler_matches_host_sampler(tmp_path, locus, seed):
+    """The states K4 (lh_eval_sample_batch) draws on the device are the ones HMM::SampleRow draws on the host from
+    the same forward arrays and the same std::mt19937 stream (src/HMM.cpp:358-431): `linearham --pipeline` writes the
+    same bytes with and without LH_HOST_SAMPLING, over several launch batches (5000 rows > RunPipeline's 2048)."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_samples=64, seed=seed, locus=locus), out)
+    yaml_path, pdir, tsv = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params"), os.path.join(out, "trees.tsv")
+    lines = open(tsv).read().splitlines()
+    big = os.path.join(out, "big.tsv")
+    with open(big, "w") as f:
+        f.write(lines[0] + "\n")
+        for i in range(5000):
+            f.write(lines[1 + i % (len(lines) - 1)] + "\n")
+    common = ["--yaml-path", yaml_path, "--cluster-ind", "0", "--hmm-param-dir", pdir, "--input-path", big,
+              "--num-rates", "4", "--seed", str(seed)]
+    outs = {}
+    for mode in ("device", "host"):
+        env = dict(os.environ)
+        if mode == "host":
+            env["LH_HOST_SAMPLING"] = "1"
+        else:
+            env.pop("LH_HOST_SAMPLING", None)
+        env["LH_PIPELINE_TIMING"] = "1"
+        o = os.path.join(out, mode + ".tsv")
+        r = subprocess.run([_exe(), "--pipeline"] + common + ["--output-path", o], capture_output=True, text=True,
+                           timeout=600, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[mode] = open(o).read()
+        assert ("device sampler" in r.stderr) == (mode == "device"), r.stderr
+    assert outs["device"] == outs["host"]
+    rows = [ln.split("\t") for ln in outs["device"].splitlines()]
+    c = rows[0].index("NaiveSequence")
+    assert len(rows) == 5001 and len({r[c] for r in rows[1:]}) > 1   # the draws do vary over the rows
+
+
 def test_full_size_family_properties(tmp_path):
     """BASELINE.json configs[2] at full size (100 leaves x 400 sites, 200 V / 30 D / 12 J alleles) through the C++
     host and the C ABI -- properties that need no oracle run: rows repeated in a batch give identical bits wherever

@@ -28,6 +28,7 @@ common = ["--yaml-path", os.path.join(fam, "cluster.yaml"), "--cluster-ind", "0"
           os.path.join(fam, "hmm_params")]
 out, asr = os.path.join(fam, "lh.tsv"), os.path.join(fam, "asr.trees")
 t = time.time()
+print("[e2e] starting the pipeline process at wall %.3f" % t, flush=True)
 subprocess.check_call([exe, "--pipeline"] + common + ["--input-path", big, "--output-path", out, "--num-rates", "4",
                                                       "--seed", "1"])
 t1 = time.time() - t

@@ -11,7 +11,7 @@ for spec in "$@"; do
   flags=${spec#*=}
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result $flags -I include -I linearham_amd/csrc \
     linearham_amd/csrc/lh_model.hip linearham_amd/csrc/lh_prune.hip linearham_amd/csrc/lh_forward.hip \
-    linearham_amd/csrc/lh_asr.hip linearham_amd/csrc/lh_capi.hip -o linearham_amd/lib/liblinearham_hip.so 2> /dev/null
+    linearham_amd/csrc/lh_asr.hip linearham_amd/csrc/lh_sample.hip linearham_amd/csrc/lh_capi.hip -o linearham_amd/lib/liblinearham_hip.so 2> /dev/null
   rm -rf /tmp/prof_exp_$label
   (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_exp_$label -o run -- \
     python3 $root/bench.py --no-cpu-baseline --no-forward-rate $EXP_BENCH_ARGS > $root/gpurun_out/exp_$label.json 2> /dev/null)
