@@ -957,6 +957,183 @@ __device__ static int junction_pair(const DevJunction& J, const double* jem, con
   return count + last.k;
 }
 
+// ---- two samples per wave on the V-D junction --------------------------------------------------------------
+// The V-D sweep's lanes are full on its left (V) genes but not on its right (D) genes: 30 of 64 on configs[2], and
+// the right genes are where most of a row's arithmetic is (five states per gene).  Two samples per wave: the left
+// genes of both samples go through the same lanes one after the other on ONE set of row-table registers (the
+// tables are family constants -- half the table loads per sample), the right genes of sample A sit in lanes
+// 0-31 and those of sample B in lanes 32-63 as in junction_pair.  The rank-one sums are whole-wave sums per
+// sample; the ScaleMatrix key of a sample covers its left entries on all lanes and its right entries on its half.
+// Per sample the operations and their order are those of junction_wave<GL, 1>.
+template <int GL, bool kExt>
+__device__ static void junction_vd_pair(const DevJunction& J, const double* jemA, const double* jemB,
+                                        const double* ntt_lds, int lane, bool hi, const double (&fA_in)[GL],
+                                        const double (&fB_in)[GL], int countA_in, int countB_in,
+                                        const double* __restrict__ germ_em_mine, double& g_out, int& count_mine,
+                                        double* __restrict__ fwdA, double* __restrict__ fwdB,
+                                        int32_t* __restrict__ scoA, int32_t* __restrict__ scoB,
+                                        const int32_t* __restrict__ jrsA, const int32_t* __restrict__ jrsB) {
+  const int W = J.n_rows, nL = J.n_left, nR = J.n_right;
+  const unsigned g = lane & 31;  // right gene of this lane (its half's sample)
+  const double* jemM = hi ? jemB : jemA;
+  int countA = countA_in, countB = countB_in;
+  double fA[GL], fB[GL], fN[4] = {0.0, 0.0, 0.0, 0.0}, fR = 0.0, nli[4];
+#pragma unroll
+  for (int q = 0; q < GL; ++q) {
+    fA[q] = fA_in[q];
+    fB[q] = fB_in[q];
+  }
+  {
+    const double2* p = reinterpret_cast<const double2*>(J.right_gp_nli) + 2u * g;
+    const double2 a = p[0], b = p[1];
+    nli[0] = a.x, nli[1] = a.y, nli[2] = b.x, nli[3] = b.y;
+  }
+  const size_t row_stride = (size_t)nL + 5 * (size_t)nR;
+  double AA, AB;
+  {
+    double pa = 0.0, pb = 0.0;
+#pragma unroll
+    for (int q = 0; q < GL; ++q) {
+      const double lo = J.enter_lo[lane + 64u * q];
+      pa += fA_in[q] * lo;
+      pb += fB_in[q] * lo;
+    }
+    AA = wave_sum(pa);
+    AB = wave_sum(pb);
+  }
+  auto combine = [](unsigned a, unsigned b) { return kExt ? max(a, b) : min(a, b); };
+  for (int i = 0; i < W; ++i) {
+    const size_t ol = (size_t)i * J.left_pad, orr = (size_t)i * J.right_pad;
+    unsigned keyA = key_start<kExt>(), keyB = key_start<kExt>();
+    double partA = 0.0, partB = 0.0;
+    {
+      const double* lt = J.left_trans + ol;
+      const double* ll = J.left_lo + ol;
+      const int32_t* lx = J.left_xmsa + ol;
+#pragma unroll
+      for (int q = 0; q < GL; ++q) {
+        const double ltr = lt[lane + 64u * q], llo = ll[lane + 64u * q];
+        const int lidx = lx[lane + 64u * q];
+        const double va = (fA[q] * ltr) * jemA[lidx];
+        const double vb = (fB[q] * ltr) * jemB[lidx];
+        fA[q] = va;
+        fB[q] = vb;
+        keyA = key_add<kExt>(keyA, va);
+        keyB = key_add<kExt>(keyB, vb);
+        partA += va * llo;
+        partB += vb * llo;
+      }
+    }
+    {
+      const double AM = hi ? AB : AA;
+      const double2* pn = reinterpret_cast<const double2*>(J.right_nlo) + 2 * (orr + g);
+      const double2 n01 = pn[0], n23 = pn[1];
+      const int4 nx = reinterpret_cast<const int4*>(J.nti_xmsa)[orr + g];
+      const double rtr = J.right_trans[orr + g], rli = J.right_gp_li[orr + g];
+      const int ridx = J.right_xmsa[orr + g];
+      unsigned keyR = key_start<kExt>();
+      const double n0 = fN[0], n1 = fN[1], n2 = fN[2], n3 = fN[3];
+      const double2* tt = reinterpret_cast<const double2*>(ntt_lds) + 8u * g;
+      const int nxs[4] = {nx.x, nx.y, nx.z, nx.w};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const double2 t01 = tt[2 * b], t23 = tt[2 * b + 1];
+        double sacc = ((n0 * t01.x + n1 * t01.y) + n2 * t23.x) + n3 * t23.y;
+        sacc += AM * nli[b];
+        const double v = sacc * jemM[nxs[b]];
+        fN[b] = v;
+        keyR = key_add<kExt>(keyR, v);
+      }
+      {
+        double sacc = ((n0 * n01.x + n1 * n01.y) + n2 * n23.x) + n3 * n23.y;
+        sacc += fR * rtr;
+        sacc += AM * rli;
+        const double v = sacc * jemM[ridx];
+        fR = v;
+        keyR = key_add<kExt>(keyR, v);
+      }
+      if (hi)
+        keyB = combine(keyB, keyR);
+      else
+        keyA = combine(keyA, keyR);
+    }
+    AA = wave_sum(partA);
+    AB = wave_sum(partB);
+    const RowScale sa = wave_row_scale<kExt>(keyA), sb = wave_row_scale<kExt>(keyB);
+    if constexpr (kExt) {
+      countA += jrsA[i];
+      countB += jrsB[i];
+    }
+    if ((sa.k | sb.k) != 0) {  // wave-uniform, a few rows per junction
+      AA = sa.apply(AA);
+      AB = sb.apply(AB);
+#pragma unroll
+      for (int q = 0; q < GL; ++q) {
+        fA[q] = sa.apply(fA[q]);
+        fB[q] = sb.apply(fB[q]);
+      }
+      const double factor = hi ? sb.factor : sa.factor;
+      const bool extra = hi ? sb.extra : sa.extra;
+      auto apply = [&](double v) {
+        v *= factor;
+        if (extra) v *= kScaleFactor;
+        return v;
+      };
+      fR = apply(fR);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fN[b] = apply(fN[b]);
+      countA += sa.k;
+      countB += sb.k;
+    }
+    if (fwdA) {  // (fwdB is null when the second sample does not exist)
+      double* oa = fwdA + (size_t)i * row_stride;
+      double* ob = fwdB ? fwdB + (size_t)i * row_stride : nullptr;
+#pragma unroll
+      for (int q = 0; q < GL; ++q) {
+        const int t = lane + 64 * q;
+        if (t < nL) {
+          oa[t] = fA[q];
+          if (ob) ob[t] = fB[q];
+        }
+      }
+      double* om = hi ? ob : oa;
+      if (om && (int)g < nR) {
+        om[nL + 4 * (size_t)g + 0] = fN[0];
+        om[nL + 4 * (size_t)g + 1] = fN[1];
+        om[nL + 4 * (size_t)g + 2] = fN[2];
+        om[nL + 4 * (size_t)g + 3] = fN[3];
+        om[nL + 4 * (size_t)nR + g] = fR;
+      }
+    }
+    if (lane == 0) {
+      if (scoA) scoA[i] = countA;
+      if (scoB) scoB[i] = countB;
+    }
+  }
+  // hand-off into the D germline region, each half for its sample
+  unsigned key = key_start<kExt>();
+  {
+    const double AM = hi ? AB : AA;
+    const double2* xn = reinterpret_cast<const double2*>(J.exit_nlo) + 2u * g;
+    const double2 x01 = xn[0], x23 = xn[1];
+    double sacc = ((fN[0] * x01.x + fN[1] * x01.y) + fN[2] * x23.x) + fN[3] * x23.y;
+    sacc += fR * J.exit_trans[g];
+    sacc += AM * J.exit_gp_li[g];
+    double v = 0.0;
+    if ((int)g < nR) v = sacc * germ_em_mine[g];
+    key = key_add<kExt>(key, v);
+    g_out = v;
+  }
+  const HalfKeys hk = half_keys<kExt>(key);
+  const RowScale la = row_scale(hk.a), lb = row_scale(hk.b);
+  {
+    double v = g_out * (hi ? lb.factor : la.factor);
+    if (hi ? lb.extra : la.extra) v *= kScaleFactor;
+    g_out = v;
+  }
+  count_mine = (hi ? countB + lb.k : countA + la.k);
+}
+
 // The pair form (igh families with at most 32 D and 32 J alleles) as two kernels, because the two halves want
 // different launch shapes: junction_vd_kernel sweeps the V-D junction with a wave per sample (the V genes fill
 // its lanes, 156 VGPRs, three waves per SIMD) and leaves the D-germline forward vector and its scaler count in
@@ -1033,6 +1210,113 @@ __global__ void __launch_bounds__(64 * kJunctionWaves)
   if (sco && lane == 0) sco[1 + fam.vd.n_rows] = dcount;
   if (lane < 32) dxf[(size_t)s * 32 + lane] = gD[0];  // zero beyond the last D gene
   if (lane == 0) dxc[s] = dcount;
+}
+
+// V-D half of the pair form with two samples per wave (junction_vd_pair); same outputs as junction_vd_kernel.
+constexpr int kVdPairWaves = 4;  // waves per workgroup (eight samples)
+// (167 VGPRs, three waves = six samples per SIMD: 0.327 ms per 49 152 against 0.567 for junction_vd_kernel; forced to
+// four waves it spills: 0.358, two waves: 0.393)
+template <int GA, bool kExt>
+__global__ void __launch_bounds__(64 * kVdPairWaves)
+    junction_vd2_kernel(const DevFamily fam, int n, const double* __restrict__ gem_all,
+                        const int32_t* __restrict__ gcnt_all, const double* __restrict__ jem_all,
+                        const int32_t* __restrict__ jrs_all, double* __restrict__ fwd_all,
+                        int32_t* __restrict__ scal_all, double* __restrict__ dxf, int32_t* __restrict__ dxc) {
+  extern __shared__ double jlds[];  // [NTI->NTI blocks of the vd right genes | 2 * kVdPairWaves jem slices]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NJ = fam.n_jcols;
+  double* ntt_vd = jlds;
+  double* jem0 = ntt_vd + 16 * (size_t)fam.vd.right_pad + (size_t)(2 * wave) * (NJ + 1);
+  for (int t = threadIdx.x; t < 16 * fam.vd.right_pad; t += 64 * kVdPairWaves) ntt_vd[t] = fam.vd.right_ntt[t];
+  __syncthreads();
+  const int p = blockIdx.x * kVdPairWaves + wave;
+  if (2 * p >= n) return;  // neither sample exists; nothing below synchronises across waves
+  const bool hi = lane >= 32;
+  const int sA = 2 * p, sB = min(2 * p + 1, n - 1);
+  const bool validB = 2 * p + 1 < n;  // an absent second sample reads the first one's inputs and writes nothing
+  for (int h = 0; h < 2; ++h) {
+    const double* src = jem_all + (size_t)(h ? sB : sA) * NJ;
+    double* dst = jem0 + (size_t)h * (NJ + 1);
+    for (int j = lane; j < NJ; j += 64) dst[j] = src[j];
+    if (lane == 0) dst[NJ] = 0.0;  // what a state that cannot emit at a site looks up
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int nV = fam.vgerm.n_genes, nD = fam.dgerm.n_genes;
+  const size_t vd_fwd = (size_t)fam.vd.n_rows * (fam.vd.n_left + 5 * (size_t)fam.vd.n_right);
+  const double* gemA = gem_all + (size_t)sA * fam.gem_size;
+  const double* gemB = gem_all + (size_t)sB * fam.gem_size;
+  double* fwdA = fwd_all ? fwd_all + (size_t)sA * fam.forward_size : nullptr;
+  double* fwdB = fwd_all && validB ? fwd_all + (size_t)sB * fam.forward_size : nullptr;
+  int32_t* scoA = scal_all ? scal_all + (size_t)sA * fam.scaler_size : nullptr;
+  int32_t* scoB = scal_all && validB ? scal_all + (size_t)sB * fam.scaler_size : nullptr;
+  // initial forward over the V germline region (src/HMM.cpp:291-319), both samples
+  double gA[GA], gB[GA];
+  unsigned keyA = key_start<kExt>(), keyB = key_start<kExt>();
+#pragma unroll
+  for (int q = 0; q < GA; ++q) {
+    const int t = lane + 64 * q;
+    double va = 0.0, vb = 0.0;
+    if (t < nV) {
+      const double c0 = fam.vgerm_gene_prob[t], c1 = fam.vpadding_transition[t], c2 = fam.vgerm_trans_prod[t];
+      va = c0;
+      va *= c1;
+      va *= gemA[t];
+      va *= c2;
+      va *= gemA[nV + t];
+      vb = c0;
+      vb *= c1;
+      vb *= gemB[t];
+      vb *= c2;
+      vb *= gemB[nV + t];
+    }
+    keyA = key_add<kExt>(keyA, va);
+    keyB = key_add<kExt>(keyB, vb);
+    gA[q] = va;
+    gB[q] = vb;
+  }
+  int countA = gcnt_all[(size_t)sA * 3 + 0], countB = gcnt_all[(size_t)sB * 3 + 0];
+  {
+    const RowScale sa = wave_row_scale<kExt>(keyA), sb = wave_row_scale<kExt>(keyB);
+#pragma unroll
+    for (int q = 0; q < GA; ++q) {
+      gA[q] = sa.apply(gA[q]);
+      gB[q] = sb.apply(gB[q]);
+    }
+    countA += sa.k;
+    countB += sb.k;
+  }
+  if (fwdA) {
+#pragma unroll
+    for (int q = 0; q < GA; ++q)
+      if (lane + 64 * q < nV) {
+        fwdA[lane + 64 * q] = gA[q];
+        if (fwdB) fwdB[lane + 64 * q] = gB[q];
+      }
+  }
+  if (lane == 0) {
+    if (scoA) scoA[0] = countA;
+    if (scoB) scoB[0] = countB;
+  }
+  const size_t jr = (size_t)fam.vd.n_rows + fam.dj.n_rows;
+  double gD;
+  int count_mine;
+  junction_vd_pair<GA, kExt>(fam.vd, jem0, jem0 + (NJ + 1), ntt_vd, lane, hi, gA, gB, countA, countB,
+                             (hi ? gemB : gemA) + 2 * (size_t)nV, gD, count_mine, fwdA ? fwdA + nV : nullptr,
+                             fwdB ? fwdB + nV : nullptr, scoA ? scoA + 1 : nullptr, scoB ? scoB + 1 : nullptr,
+                             kExt ? jrs_all + (size_t)sA * jr : nullptr, kExt ? jrs_all + (size_t)sB * jr : nullptr);
+  const unsigned g = lane & 31;
+  const int dcount = gcnt_all[(size_t)(hi ? sB : sA) * 3 + 1] + count_mine;
+  if (!hi || validB) {
+    const int sM = hi ? sB : sA;
+    double* fwdM = hi ? fwdB : fwdA;
+    int32_t* scoM = hi ? scoB : scoA;
+    if (fwdM && (int)g < nD) fwdM[nV + vd_fwd + g] = gD;
+    if (scoM && g == 0) scoM[1 + fam.vd.n_rows] = dcount;
+    dxf[(size_t)sM * 32 + g] = gD;  // zero beyond the last D gene
+    if (g == 0) dxc[sM] = dcount;
+  }
 }
 
 constexpr int kPairWaves = 4;  // waves per junction_dj_kernel workgroup (eight samples)
@@ -1215,7 +1499,8 @@ __global__ void __launch_bounds__(64 * kJunctionWaves)
 }
 
 static size_t junction_lds_bytes(const DevFamily& fam) {
-  return ((size_t)kJunctionWaves * (fam.n_jcols + 1) +
+  // (the pair-form kernels keep two jem slices per wave and one junction's NTI blocks: never more than this)
+  return ((size_t)2 * kJunctionWaves * (fam.n_jcols + 1) +
           16 * ((size_t)fam.vd.right_pad + (fam.has_d ? fam.dj.right_pad : 0))) *
          sizeof(double);
 }
@@ -1289,6 +1574,30 @@ static void launch_junction_g(const DevFamily& fam, int n, const double* gem, co
     const size_t lds_vd = ((size_t)kJunctionWaves * (fam.n_jcols + 1) + 16 * (size_t)fam.vd.right_pad) * sizeof(double);
     const size_t lds_dj = ((size_t)2 * kPairWaves * (fam.n_jcols + 1) + 16 * (size_t)fam.dj.right_pad) * sizeof(double);
     const dim3 grid_vd((n + kJunctionWaves - 1) / kJunctionWaves), grid_dj(((n + 1) / 2 + kPairWaves - 1) / kPairWaves);
+    static const bool vd_single = getenv("LH_K2B_VD_SINGLE") != nullptr;  // test hook: one sample per V-D wave
+    if (!vd_single) {
+      const size_t lds_vd2 = ((size_t)2 * kVdPairWaves * (fam.n_jcols + 1) + 16 * (size_t)fam.vd.right_pad) * sizeof(double);
+      const dim3 grid_vd2(((n + 1) / 2 + kVdPairWaves - 1) / kVdPairWaves);
+#define LH_PAIR2_LAUNCH(E)                                                                                            \
+  {                                                                                                                   \
+    if (lds_vd2 > 64 * 1024)                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_vd2_kernel<GA, E>),                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_vd2);                            \
+    if (lds_dj > 64 * 1024)                                                                                           \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(junction_dj_kernel<E>),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dj);                             \
+    hipLaunchKernelGGL((junction_vd2_kernel<GA, E>), grid_vd2, dim3(64 * kVdPairWaves), lds_vd2, stream, fam, n, gem, \
+                       gcnt, jem, jrs, forward_out, scaler_out, dxf, dxc);                                            \
+    hipLaunchKernelGGL((junction_dj_kernel<E>), grid_dj, dim3(64 * kPairWaves), lds_dj, stream, fam, n, gem, gcnt,    \
+                       jem, jrs, dxf, dxc, loglik, forward_out, scaler_out);                                          \
+  }
+      if (ext)
+        LH_PAIR2_LAUNCH(true)
+      else
+        LH_PAIR2_LAUNCH(false)
+#undef LH_PAIR2_LAUNCH
+      return;
+    }
 #define LH_PAIR_LAUNCH(E)                                                                                             \
   {                                                                                                                   \
     if (lds_vd > 64 * 1024)                                                                                           \
