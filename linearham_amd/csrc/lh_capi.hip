@@ -95,6 +95,7 @@ struct lh_family {
     void* pinned = nullptr;  // page-locked staging of the six input arrays
     size_t pinned_cap = 0;
   } smp;
+  int32_t n_ucol_used = 0;  // (naive base, pattern) pairs some xMSA column has (lh_family_info)
   std::vector<EventSet> events;
   double ms[3] = {0, 0, 0};
   int64_t launches = 0;
@@ -512,20 +513,27 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
       std::vector<uint8_t> pmsa(N * std::max<size_t>(h.n_prune, 1));
       for (size_t i = 0; i < N; ++i)
         for (size_t p = 0; p < (size_t)h.n_prune; ++p) pmsa[i * h.n_prune + p] = desc->msa[i * L + first_site[p]];
-      // u-columns: distinct (naive base, pattern) pairs, sorted by base then pattern
-      std::map<std::pair<int, int32_t>, int32_t> pairs;
-      for (size_t c = 0; c < C; ++c) pairs.emplace(std::make_pair((int)desc->xmsa_naive_base[c], pat_of_site[desc->xmsa_site[c]]), 0);
-      std::vector<int32_t> u_pat, col_of_ucol(pairs.size(), -1);
-      std::vector<uint8_t> u_base;
-      for (auto& kv : pairs) {
-        kv.second = (int32_t)u_pat.size();
-        u_base.push_back((uint8_t)kv.first.first);
-        u_pat.push_back(kv.first.second);
-      }
+      // u-columns: the (naive base, pattern) pairs, numbered by their place in K1's output planes --
+      // base * n_prune + pattern, then the five bases of the all-N pattern -- so that K2a fills its emission vector
+      // with one pass over the planes and no look-up (lh_device.h).  Pairs no xMSA column has keep u_base = 0xff.
+      const int32_t NPr = h.n_prune;
+      const size_t n_u = 5 * (size_t)NPr + 5;
+      std::vector<int32_t> u_pat(n_u), col_of_ucol(n_u, -1);
+      std::vector<uint8_t> u_base(n_u, 0xff);
+      for (size_t u = 0; u < n_u; ++u) u_pat[u] = u < 5 * (size_t)NPr ? (int32_t)(u % NPr) : NPr;
+      int32_t n_used = 0;
       for (size_t c = 0; c < C; ++c) {
-        ucol[c] = pairs[std::make_pair((int)desc->xmsa_naive_base[c], pat_of_site[desc->xmsa_site[c]])];
-        if (col_of_ucol[ucol[c]] < 0) col_of_ucol[ucol[c]] = (int32_t)c;
+        const int b = desc->xmsa_naive_base[c];
+        const int32_t pat = pat_of_site[desc->xmsa_site[c]];
+        const int32_t u = pat < NPr ? b * NPr + pat : 5 * NPr + b;
+        ucol[c] = u;
+        if (col_of_ucol[u] < 0) {
+          col_of_ucol[u] = (int32_t)c;
+          u_base[u] = (uint8_t)b;
+          ++n_used;
+        }
       }
+      f->n_ucol_used = n_used;
       h.n_ucol = (int32_t)u_pat.size();
       pat_of_site_all = pat_of_site;
       rc = rc || upload(f, pmsa.data(), pmsa.size(), &h.msa);
@@ -541,6 +549,7 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
     h.n_prune = 0;
     h.msa_mixed_n = 0;
     h.n_ucol = (int32_t)C;
+    f->n_ucol_used = (int32_t)C;
     rc = rc || upload<uint8_t>(f, nullptr, 0, &h.msa);
     rc = rc || upload<int32_t>(f, nullptr, 0, &h.site_pat);
     rc = rc || upload<int32_t>(f, nullptr, 0, &h.u_pat);
@@ -671,7 +680,7 @@ int lh_family_consensus_sets(const lh_family* f) {
 int lh_family_info(const lh_family* f, int32_t* n_patterns, int32_t* n_unique_columns) {
   if (!f) return fail("lh_family_info: null family");
   if (n_patterns) *n_patterns = f->host.n_prune;  // the all-N padding pattern, if any, costs nothing
-  if (n_unique_columns) *n_unique_columns = f->host.n_ucol;
+  if (n_unique_columns) *n_unique_columns = f->n_ucol_used;
   return 0;
 }
 int64_t lh_scaler_size(const lh_family* f) { return f ? f->host.scaler_size : 0; }

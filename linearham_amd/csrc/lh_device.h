@@ -72,15 +72,16 @@ struct DevFamily {
   int32_t n_prune;                         // K1's site dimension: n_pat minus the all-N pattern, which
                                            // comes last and whose emission is 1 whatever the tree
   int32_t msa_mixed_n;                     // 1 if some pattern mixes N with bases (K1 then handles N tips)
-  int32_t n_ucol;                          // distinct (naive base, pattern) pairs (K2's column dimension)
+  int32_t n_ucol;                          // (naive base, pattern) pairs (K2's column dimension): with an alignment
+                                           // 5 n_prune + 5, u = base * n_prune + pattern (the all-N pattern's five last)
   int32_t idx_byte_offsets;                // 1: the segment index chunks hold byte offsets (index * 8),
                                            // possible when (n_ucol + 1) * 8 fits 16 bits
   const uint8_t* msa;                      // [n_seqs][n_prune]
   const int32_t* site_pat;                 // [n_sites] pattern of alignment site j (n_prune = the all-N pattern)
   const int32_t* u_pat;                    // [n_ucol] pattern of u-column u
-  const uint8_t* u_base;                   // [n_ucol] its naive base (4 = N)
+  const uint8_t* u_base;                   // [n_ucol] its naive base (4 = N; 0xff: no xMSA column is this pair)
   const int32_t* ucol_of_col;              // [n_xmsa] u-column of the caller's column c
-  const int32_t* col_of_ucol;              // [n_ucol] one caller column per u-column
+  const int32_t* col_of_ucol;              // [n_ucol] one caller column per u-column (-1: none)
   DevSegments vpadding, vgerm, dgerm, jgerm, jpadding;
   const double *vgerm_gene_prob, *vpadding_transition, *vgerm_trans_prod, *jpadding_transition;
   DevJunction vd, dj;

@@ -390,43 +390,49 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
     const double w = 1.0 / R;
     // (the naive correction divides a column's likelihood by pi of its naive base: one reciprocal per base and
     // sample, above, instead of a division per column)
-    for (int u = tid; u < C; u += kFwdThreads) {
-      const int pat = fam.u_pat[u];
-      const int b = fam.u_base[u];
-      if (pat >= NP) {  // the all-N padding pattern: likelihood pi_b, emission 1 -- and for the naive
-                        // base N the sum of the sample's pi, which is 1 only as far as its digits go
-        const double* q = pi + s * 4;
-        em[u] = b == 4 ? ((q[0] + q[1]) + q[2]) + q[3] : 1.0;
-        continue;
-      }
+    // u-columns are numbered by their place in K1's planes (base * NP + pattern): a thread takes a pattern, asks for
+    // its 6 R plane entries at once -- no look-up in front of the loads -- and writes the pattern's five emissions.
+    for (int pat = tid; pat < NP; pat += kFwdThreads) {
       int smin = 0x7fffffff;
       for (int r = 0; r < R; ++r) smin = min(smin, site_scal[(s * R + r) * NP + pat]);
-      double acc = 0.0;
+      double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
       for (int r = 0; r < R; ++r) {
-        double v = site_lik[((s * R + r) * 5 + b) * (size_t)NP + pat];
         const int d = site_scal[(s * R + r) * NP + pat] - smin;
-        for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
-        acc += w * v;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          double v = site_lik[((s * R + r) * 5 + b) * (size_t)NP + pat];
+          for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
+          acc[b] += w * v;
+        }
       }
-      // The reference forms exp(log(site_lik) - smin*log(2^256) - log(pi_b)) (src/PhyloHMM.cpp:226-237);
-      // the same quantity is computed here without the log/exp round trip (two FP64 transcendentals
-      // per column): site_lik / pi_b scaled down by 2^(256*smin), which also underflows to 0 like exp().
-      double e = acc * inv_pi[b];
-      if constexpr (kExt) {
-        ems[u] = smin;  // the emission is e * 2^(-256 smin); the count travels beside the value
-      } else {
-        for (int q = 0; q < smin && e != 0.0; ++q) e *= kScaleThreshold;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const int u = b * NP + pat;
+        // The reference forms exp(log(site_lik) - smin*log(2^256) - log(pi_b)) (src/PhyloHMM.cpp:226-237);
+        // the same quantity is computed here without the log/exp round trip (two FP64 transcendentals
+        // per column): site_lik / pi_b scaled down by 2^(256*smin), which also underflows to 0 like exp().
+        double e = acc[b] * inv_pi[b];
+        if constexpr (kExt) {
+          ems[u] = smin;  // the emission is e * 2^(-256 smin); the count travels beside the value
+        } else {
+          for (int q = 0; q < smin && e != 0.0; ++q) e *= kScaleThreshold;
+        }
+        em[u] = e;
+        // (a pair no xMSA column has is never read below: it cannot send the sample down the slow path)
+        my_bad |= fam.u_base[u] != 0xff && !(e >= 0x1p-1000 && e <= 1.0 + 1e-9);
       }
-      em[u] = e;
-      my_bad |= !(e >= 0x1p-1000 && e <= 1.0 + 1e-9);
     }
-    if constexpr (kExt) {  // the all-N pattern's columns (skipped above) carry no count
-      for (int u = tid; u < C; u += kFwdThreads)
-        if (fam.u_pat[u] >= NP) ems[u] = 0;
+    if (tid < 5) {
+      // the all-N padding pattern: likelihood pi_b, emission 1 -- and for the naive base N the sum of the
+      // sample's pi, which is 1 only as far as its digits go
+      const double* q = pi + s * 4;
+      em[5 * NP + tid] = tid == 4 ? ((q[0] + q[1]) + q[2]) + q[3] : 1.0;
+      if constexpr (kExt) ems[5 * NP + tid] = 0;
     }
   } else {
     for (int u = tid; u < C; u += kFwdThreads) {
-      const double e = em_in[s * fam.n_xmsa + fam.col_of_ucol[u]];
+      const int c = fam.col_of_ucol[u];
+      const double e = c >= 0 ? em_in[s * fam.n_xmsa + c] : 1.0;  // (no column: the pair is never read)
       em[u] = e;
       if constexpr (kExt) ems[u] = 0;
       my_bad |= !(e >= 0x1p-1000 && e <= 1.0 + 1e-9);
