@@ -30,12 +30,22 @@
 //       (gene g in lane g % 64, register slot g / 64) stays in VGPRs, and a CU holds 16 samples instead
 //       of 4, which is what hides the per-row table-load latency.  The row's 2^256 scaling is applied
 //       lazily, as an exact power-of-two factor, when the row is consumed and when it is written out.
+#include <cstdio>
 #include <cstdlib>
 
 #include "lh_device.h"
 
 namespace lh {
 
+// -DLH_EXP_K2A_STAMPS: cycle counter at K2a's phase boundaries for workgroups 20000..21023 of the third launch,
+// means printed on stderr (an instrument for experiments; never in the shipped build).
+#ifdef LH_EXP_K2A_STAMPS
+__device__ unsigned long long k2a_stamps[1024][12];
+#define LH_STAMP(i) \
+  if (threadIdx.x == 0 && blockIdx.x >= 20000 && blockIdx.x < 21024) k2a_stamps[blockIdx.x - 20000][i] = __builtin_readcyclecounter();
+#else
+#define LH_STAMP(i)
+#endif
 constexpr int kFwdThreads = 256;
 constexpr int kFwdWaves = kFwdThreads / 64;
 constexpr int kJunctionWaves = 4;  // samples per K2b workgroup
@@ -293,6 +303,7 @@ __device__ static int fill_consensus(const DevSegments& seg, const double* em, i
     cons_pk[j0 + 1] = p1.k;
   }
   __syncthreads();
+  LH_STAMP(9)
 
   double v[kG];
   int c[kG];
@@ -378,50 +389,71 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
   double* cons_pv = cons_inv + cons_cap;                                    // [cap + 4]
   int* cons_pk = reinterpret_cast<int*>(cons_pv + cons_cap + 4);            // [cap + 4]
   int* ems = cons_pk + (cons_cap ? cons_cap + 4 : 0);                       // [C + 1] (kExt only): 2^-256 counts
+  LH_STAMP(0)
   if (tid == 0) *em_bad = 0;
-  if (kFromSiteLik && tid < 5) inv_pi[tid] = tid < 4 ? 1.0 / pi[s * 4 + tid] : 1.0;
-  __syncthreads();
   bool my_bad = false;
 
   if constexpr (kFromSiteLik) {
     // PhyloHMM::FillXmsaEmission tail: mix the rate categories (equal weights, scalers aligned to the
-    // smallest one) and apply the naive correction, once per distinct (naive base, pattern) pair.
-    const int NP = fam.n_prune;
-    const double w = 1.0 / R;
-    // (the naive correction divides a column's likelihood by pi of its naive base: one reciprocal per base and
-    // sample, above, instead of a division per column)
+    // smallest one) and apply the naive correction, once per (naive base, pattern) pair.
     // u-columns are numbered by their place in K1's planes (base * NP + pattern): a thread takes a pattern, asks for
     // its 6 R plane entries at once -- no look-up in front of the loads -- and writes the pattern's five emissions.
-    for (int pat = tid; pat < NP; pat += kFwdThreads) {
-      int smin = 0x7fffffff;
-      for (int r = 0; r < R; ++r) smin = min(smin, site_scal[(s * R + r) * NP + pat]);
-      double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    // The first pattern's loads are in flight while the sample's 1 / pi are formed (the naive correction divides a
+    // column's likelihood by pi of its naive base: one reciprocal per base and sample instead of a division per
+    // column).
+    const int NP = fam.n_prune;
+    const double w = 1.0 / R;
+    struct Mixed {
+      double acc[5];
+      int smin;
+      unsigned used;  // bit b: some xMSA column is the pair (b, pattern)
+    };
+    auto mix = [&](int pat) {
+      Mixed m;
+      m.smin = 0x7fffffff;
+      m.used = 0;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) m.used |= (fam.u_base[b * NP + pat] != 0xff ? 1u : 0u) << b;
+      for (int r = 0; r < R; ++r) m.smin = min(m.smin, site_scal[(s * R + r) * NP + pat]);
+#pragma unroll
+      for (int b = 0; b < 5; ++b) m.acc[b] = 0.0;
       for (int r = 0; r < R; ++r) {
-        const int d = site_scal[(s * R + r) * NP + pat] - smin;
+        const int d = site_scal[(s * R + r) * NP + pat] - m.smin;
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
           double v = site_lik[((s * R + r) * 5 + b) * (size_t)NP + pat];
           for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
-          acc[b] += w * v;
+          m.acc[b] += w * v;
         }
       }
+      return m;
+    };
+    auto finish = [&](int pat, const Mixed& m) {
 #pragma unroll
       for (int b = 0; b < 5; ++b) {
         const int u = b * NP + pat;
         // The reference forms exp(log(site_lik) - smin*log(2^256) - log(pi_b)) (src/PhyloHMM.cpp:226-237);
         // the same quantity is computed here without the log/exp round trip (two FP64 transcendentals
         // per column): site_lik / pi_b scaled down by 2^(256*smin), which also underflows to 0 like exp().
-        double e = acc[b] * inv_pi[b];
+        double e = m.acc[b] * inv_pi[b];
         if constexpr (kExt) {
-          ems[u] = smin;  // the emission is e * 2^(-256 smin); the count travels beside the value
+          ems[u] = m.smin;  // the emission is e * 2^(-256 smin); the count travels beside the value
         } else {
-          for (int q = 0; q < smin && e != 0.0; ++q) e *= kScaleThreshold;
+          for (int q = 0; q < m.smin && e != 0.0; ++q) e *= kScaleThreshold;
         }
         em[u] = e;
         // (a pair no xMSA column has is never read below: it cannot send the sample down the slow path)
-        my_bad |= fam.u_base[u] != 0xff && !(e >= 0x1p-1000 && e <= 1.0 + 1e-9);
+        my_bad |= ((m.used >> b) & 1u) && !(e >= 0x1p-1000 && e <= 1.0 + 1e-9);
       }
-    }
+    };
+    Mixed first;
+    if (tid < NP) first = mix(tid);
+    LH_STAMP(10)
+    if (tid < 5) inv_pi[tid] = tid < 4 ? 1.0 / pi[s * 4 + tid] : 1.0;
+    __syncthreads();
+    LH_STAMP(11)
+    if (tid < NP) finish(tid, first);
+    for (int pat = tid + kFwdThreads; pat < NP; pat += kFwdThreads) finish(pat, mix(pat));
     if (tid < 5) {
       // the all-N padding pattern: likelihood pi_b, emission 1 -- and for the naive base N the sum of the
       // sample's pi, which is 1 only as far as its digits go
@@ -430,6 +462,7 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
       if constexpr (kExt) ems[5 * NP + tid] = 0;
     }
   } else {
+    __syncthreads();  // (the flag word is cleared before anyone sets it)
     for (int u = tid; u < C; u += kFwdThreads) {
       const int c = fam.col_of_ucol[u];
       const double e = c >= 0 ? em_in[s * fam.n_xmsa + c] : 1.0;  // (no column: the pair is never read)
@@ -444,9 +477,11 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
   // The consensus form of the germline products needs every emission in (0, 1] (see fill_consensus) and its
   // reciprocal finite; a sample with a zero or nearly subnormal emission (underflow), a NaN or an emission above 1
   // walks its products factor by factor as the reference does.
+  LH_STAMP(1)
   if (my_bad) *em_bad = 1;
   if (tid == 0) em[C] = 1.0;
   __syncthreads();
+  LH_STAMP(2)
   if (em_out) {  // the caller's view: one value per xMSA column
     const int CX = fam.n_xmsa;
     for (int c = tid; c < CX; c += kFwdThreads) {
@@ -488,13 +523,19 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
       return fill_consensus<kG, kByteOff>(seg, em, tid, out, redi, phase, cons_inv, cons_pv, cons_pk, cons_cap);
     return fill_segments<kG, kByteOff>(seg, em, tid, out, redi, phase);
   };
+  LH_STAMP(3)
   int cv = fill(fam.vpadding, gem, 0);
+  LH_STAMP(4)
   cv += fill(fam.vgerm, gem + nV, 1);
+  LH_STAMP(5)
   int cd = 0, cj;
   if (fam.has_d) {
     cd = fill(fam.dgerm, gem + 2 * (size_t)nV, 0);
+    LH_STAMP(6)
     cj = fill(fam.jgerm, gem + 2 * (size_t)nV + nD, 1);
+    LH_STAMP(7)
     cj += fill(fam.jpadding, gem + 2 * (size_t)nV + nD + nJ, 0);
+    LH_STAMP(8)
   } else {
     cj = fill(fam.jgerm, gem + 2 * (size_t)nV, 0);
     cj += fill(fam.jpadding, gem + 2 * (size_t)nV + nJ, 1);
@@ -1671,6 +1712,26 @@ void launch_forward(const DevFamily& fam, const DevFamily* fam_dev, int n, int R
   else
     launch_emission_g<4>(LH_ARGS);
 #undef LH_ARGS
+#ifdef LH_EXP_K2A_STAMPS
+  {
+    static int calls = 0;
+    if (++calls == 3) {
+      (void)hipDeviceSynchronize();
+      static unsigned long long h[1024][12];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(k2a_stamps), sizeof(h));
+      double acc[12] = {0};
+      const int m = std::min(std::max(n - 20000, 0), 1024);
+      for (int b = 0; b < m; ++b)
+        for (int i = 1; i < 12; ++i) acc[i] += (double)(h[b][i] - h[b][0]);
+      const char* names[10] = {"start", "emissions done", "barrier", "jem written", "vpadding", "vgerm", "dgerm", "jgerm",
+                               "jpadding", "vgerm scan done"};
+      fprintf(stderr, "[K2a stamps, cycles since kernel start, mean of %d workgroups]", m);
+      for (int i = 1; i < 10; ++i) fprintf(stderr, " %s %.0f;", names[i], acc[i] / std::max(m, 1));
+      fprintf(stderr, " [plane loads issued %.0f; 1/pi barrier passed %.0f]", acc[10] / std::max(m, 1), acc[11] / std::max(m, 1));
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   const int ga = (fam.vgerm.n_genes + 63) / 64;
   const int gb = (std::max(fam.dgerm.n_genes, fam.jgerm.n_genes) + 63) / 64;
 #define LH_ARGS gb, fam, n, gem, gcnt, jem, jrs, dxf, dxc, loglik, forward_out, scaler_out, ext, stream
