@@ -1622,7 +1622,7 @@ static void launch_junction_g(const DevFamily& fam, int n, const double* gem, co
     const size_t lds_dj = ((size_t)2 * kPairWaves * (fam.n_jcols + 1) + 16 * (size_t)fam.dj.right_pad) * sizeof(double);
     const dim3 grid_vd((n + kJunctionWaves - 1) / kJunctionWaves), grid_dj(((n + 1) / 2 + kPairWaves - 1) / kPairWaves);
     static const bool vd_single = getenv("LH_K2B_VD_SINGLE") != nullptr;  // test hook: one sample per V-D wave
-    if (!vd_single) {
+    if (!vd_single && GA <= 4) {  // (beyond 256 V alleles the second sample's left-gene registers no longer fit)
       const size_t lds_vd2 = ((size_t)2 * kVdPairWaves * (fam.n_jcols + 1) + 16 * (size_t)fam.vd.right_pad) * sizeof(double);
       const dim3 grid_vd2(((n + 1) / 2 + kVdPairWaves - 1) / kVdPairWaves);
 #define LH_PAIR2_LAUNCH(E)                                                                                            \
