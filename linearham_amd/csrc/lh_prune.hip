@@ -31,6 +31,8 @@
 //    and 5 doubles out, instead of the 2*I*R*32 bytes per column of a CLV-streaming kernel.
 #include <cstdlib>
 
+#include <cstdio>
+
 #include "lh_device.h"
 
 namespace lh {
@@ -79,6 +81,16 @@ namespace {
 // (The scalar cache cannot hold a stale copy: it is invalidated at kernel boundaries, and inside a launch a
 // scratch line is never read before the workgroup that reads it has written it.)
 typedef const double __attribute__((address_space(4))) * pmat_ptr;
+
+// -DLH_EXP_K1_STAMPS: latency of the first P-matrix load of every non-cherry op and the length of the walk, per wave,
+// for 128 workgroups in the middle of the grid (an instrument; it perturbs the schedule it measures)
+#ifdef LH_EXP_K1_STAMPS
+__device__ unsigned long long k1_stamps[1024][4];
+__device__ unsigned long long k1_phase[128][8];
+#define LH_K1_PHASE(i) if (threadIdx.x == 0 && blockIdx.z >= 20000 && blockIdx.z < 20128) k1_phase[blockIdx.z - 20000][i] = __builtin_readcyclecounter();
+#else
+#define LH_K1_PHASE(i)
+#endif
 
 __device__ __forceinline__ pmat_ptr pmat_after_barrier(const double* p) {
   // the address is the same in every lane; say so in a form the register allocator has to honour
@@ -195,6 +207,10 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
       if (kd == OP_CHERRY) sb[s] = msa[(unsigned)((op.z - 1) * L) + usite[s]];
     }
   }
+#ifdef LH_EXP_K1_STAMPS
+  unsigned long long st_wait = 0, st_n = 0;
+  const unsigned long long st_begin = __builtin_readcyclecounter();
+#endif
   int seg_k0 = 0;  // first op of the segment whose tip matrices are in the table (kSeg)
   for (int k = 0; k < n_ops; ++k) {
     const int4 op_next = op_ptr[k + 1 < n_ops ? k + 1 : k];
@@ -233,6 +249,16 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
       }
     } else {
       const pmat_ptr pb = pm + (size_t)k * 32;
+#ifdef LH_EXP_K1_STAMPS
+      {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        double p0 = pb[0];
+        asm volatile("" : "+s"(p0));
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        st_wait += t1 - t0;
+        ++st_n;
+      }
+#endif
 #pragma unroll
       for (int s = 0; s < S; ++s) matvec(pb, a[s], v[s]);
       if (kind == OP_TIP_ACC) {
@@ -310,6 +336,14 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
     }
   }
 
+#ifdef LH_EXP_K1_STAMPS
+  if (S == 2 && blockIdx.z >= 20000 && blockIdx.z < 20128 && (threadIdx.x & 63) == 0) {
+    const int w = (blockIdx.z - 20000) * 8 + (threadIdx.x >> 6);
+    k1_stamps[w][0] = st_wait;
+    k1_stamps[w][1] = st_n;
+    k1_stamps[w][2] = __builtin_readcyclecounter() - st_begin;
+  }
+#endif
   // epilogue: close the naive branch for each possible naive state b (A,C,G,T,N):
   //   L_b = sum_i pi_i * clv_root[i] * P_naive[i][b]        (N: row sums of P_naive)
 #pragma unroll
@@ -355,6 +389,7 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
                                            const double* __restrict__ pi,
                                            double* __restrict__ site_lik, int32_t* __restrict__ site_scal) {
   extern __shared__ double2 smem2[];
+  LH_K1_PHASE(0)
   const int tid = threadIdx.x;
   const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rate = kFused ? wave_all / wpr : (int)blockIdx.y;
@@ -402,6 +437,7 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
         }
       }
       __syncthreads();
+      LH_K1_PHASE(1)
       const int n_inner = T - 3;
       for (int it = rtid; it < n_inner + T; it += nthr) {
         if (it < n_inner) {
@@ -467,9 +503,11 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
   if constexpr (kSeg) seg_fill(seg, op_ptr, n_ops, 0);
   // every storing wave's stores have reached L2 (which is where the scalar cache fills from) before any
   // wave passes the barrier
+  LH_K1_PHASE(2)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __threadfence_block();
   __syncthreads();
+  LH_K1_PHASE(3)
 
   // P-matrices in schedule order (addresses depend on the op number only), readable from here on
   const pmat_ptr pm = pmat_after_barrier(pmat_w + pm_off);
@@ -514,7 +552,9 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
   } else {
     // exchange through LDS (over the tip tables, which no wave needs any more), then mix the rates
     const int pad = n2 * 128 + (wpr - n2) * 64;  // sites a rate's waves cover
+    LH_K1_PHASE(4)
     __syncthreads();
+    LH_K1_PHASE(5)
     double* X = reinterpret_cast<double*>(smem2);                 // [R][5][pad]
     int* SC = reinterpret_cast<int*>(X + (size_t)R * 5 * pad);    // [R][pad]
 #pragma unroll
@@ -547,6 +587,7 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
       lik_out[(size_t)b * L + tile0 + p] = acc;
       if (b == 0) scal_out[tile0 + p] = smin;
     }
+    LH_K1_PHASE(6)
   }
 }
 
@@ -685,6 +726,35 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
 #undef LH_LAUNCH_SHALLOW
 #undef LH_LAUNCH_BUDGET
 #undef LH_LAUNCH_K
+#ifdef LH_EXP_K1_STAMPS
+  {
+    static int calls = 0;
+    if (++calls == 3) {
+      (void)hipDeviceSynchronize();
+      static unsigned long long h[1024][4];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(k1_stamps), sizeof(h));
+      double wait = 0, cnt = 0, walk = 0;
+      int m = 0;
+      for (int w = 0; w < 1024; ++w)
+        if (h[w][1]) {
+          wait += (double)h[w][0];
+          cnt += (double)h[w][1];
+          walk += (double)h[w][2];
+          ++m;
+        }
+      static unsigned long long ph[128][8];
+      (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(k1_phase), sizeof(ph));
+      double acc[8] = {0};
+      for (int b = 0; b < 128; ++b)
+        for (int i = 1; i < 7; ++i) acc[i] += (double)(ph[b][i] - ph[b][0]);
+      fprintf(stderr, "[K1 phases, wave 0 of 128 workgroups, cycles since its start] matrix list %.0f; matrices computed %.0f; stores drained + barrier %.0f; "
+              "walk done %.0f; all waves done %.0f; rates mixed and written %.0f\n", acc[1] / 128, acc[2] / 128, acc[3] / 128, acc[4] / 128, acc[5] / 128, acc[6] / 128);
+      fprintf(stderr, "[K1 stamps] %d waves: walk %.0f cycles, %.1f stamped ops per wave, first P load %.0f cycles per op = %.1f %% of the walk "
+              "(two counter reads per stamp included)\n", m, walk / std::max(m, 1), cnt / std::max(m, 1), wait / std::max(cnt, 1.0),
+              100.0 * wait / std::max(walk, 1.0));
+    }
+  }
+#endif
   return fused ? 1 : R;
 }
 
