@@ -188,6 +188,7 @@ int upload_consensus(lh_family* f, const lh_segments& s, const std::vector<int32
       if (u != cons[p]) diffs[g].push_back((uint32_t)p | ((uint32_t)(u * scale) << 16));
     }
     max_diff = std::max(max_diff, diffs[g].size());
+    rng[g] |= (uint32_t)((diffs[g].size() + 7) / 8) << 25;  // rounds of eight departures (<= 64: at most 510 sites)
   }
   max_diff = (max_diff + 7) & ~(size_t)7;  // the kernel takes the departures eight at a time
   // worth it?  work of the consensus form (scan + per gene a division and its diffs) against the plain walk

@@ -27,7 +27,7 @@ struct DevSegments {
   int32_t cons_sites;        // covered sites (<= 510)
   int32_t cons_diffs;        // diff entries per gene (padded)
   const uint16_t* cons_col;  // [cons_sites] consensus u-column (index or byte offset like inds_c)
-  const uint32_t* cons_rng;  // [n_genes] first | (last + 1) << 16, in consensus positions
+  const uint32_t* cons_rng;  // [n_genes] first | (last + 1) << 16 | rounds of 8 departures << 25, in consensus positions
   const uint32_t* cons_dif;  // [cons_diffs][n_genes] position | own u-column << 16; padding = position
                              // cons_sites (reciprocal 1.0) | the sentinel column (emission 1.0)
   const uint4* inds_c;   // [n_chunks][n_genes] eight 16-bit u-column indices (or byte offsets, see

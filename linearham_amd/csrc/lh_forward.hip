@@ -153,6 +153,63 @@ __device__ static int fill_segments(const DevSegments& seg, const double* em, in
   return mx;
 }
 
+// fill_segments for a set of at most 64 genes, run by ONE wave (gene = lane): the largest count is taken inside
+// the wave, no LDS, no barrier -- the three small sets of a heavy-chain family (D, J, J padding) then walk side by
+// side on three waves instead of one after the other on all four.
+template <bool kByteOff>
+__device__ static int fill_segments_wave(const DevSegments& seg, const double* em, int lane, double* __restrict__ out) {
+  const int n = seg.n_genes;
+  double v = 1.0;
+  int c = 0;
+  if (n > 0) {
+    const int g = min(lane, n - 1);  // lanes beyond the last gene shadow gene n-1 (result dropped)
+    const uint4* chunk = seg.inds_c + g;
+    const int nc = seg.n_chunks;
+    uint4 w_next = nc > 0 ? chunk[0] : uint4{0, 0, 0, 0};
+    for (int j = 0; j < nc; ++j) {
+      const uint4 w = w_next;
+      if (j + 1 < nc) w_next = chunk[(size_t)(j + 1) * n];  // the next chunk's indices travel while this one is applied
+      const unsigned packed[4] = {w.x, w.y, w.z, w.w};
+      double e[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned x = (packed[u >> 1] >> (16 * (u & 1))) & 0xffffu;
+        e[u] = kByteOff ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(em) + x) : em[x];
+      }
+      const double v0 = v;
+      double p = v0, m = v0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {  // (see fill_segments for the three cases)
+        p *= e[u];
+        m = fmin(m, p);
+      }
+      if (__ballot(!(m >= kScaleThreshold)) == 0) {
+        v = p;
+      } else if (m >= 0x1p-768) {
+        const int k = (m < kScaleThreshold) + (m < 0x1p-512);
+        v = p * (k == 0 ? 1.0 : k == 1 ? 0x1p256 : 0x1p512);
+        c += k;
+      } else {
+        double x = v0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          x *= e[u];
+          while (x > 0.0 && x < kScaleThreshold) {
+            x *= kScaleFactor;
+            ++c;
+          }
+        }
+        v = x;
+      }
+    }
+  }
+  int mx = lane < n ? c : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+  if (lane < n) out[lane] = v * pow_scale(mx - c);
+  return mx;
+}
+
 // Extended-range mode (lh_family_set_extended_range): every factor is a pair (em[x], ems[x]) = value and
 // 2^-256 count of the column's emission; the running product carries the counts along, and the region is
 // equalised to its SMALLEST count -- alleles more than 2^-1024 below the best one underflow to 0 -- instead of
@@ -313,15 +370,23 @@ __device__ static int fill_consensus(const DevSegments& seg, const double* em, i
     c[q] = 0;
     const int g = tid + kFwdThreads * q;
     if (g < n) {
-      const unsigned rng = seg.cons_rng[g];
-      const int a = rng & 0xffffu, b = rng >> 16;
+      const unsigned rng = seg.cons_rng[g];  // first | (last + 1) << 16 | rounds of eight departures << 25
+      const int a = rng & 0xffffu, b = (rng >> 16) & 0x1ffu;
       double r = cons_pv[b] * fast_rcp(cons_pv[a]);  // in (2^-256, 2^256)
       int k = cons_pk[b] - cons_pk[a];     // value = r * 2^(-256 k)
       const uint32_t* dp = seg.cons_dif + g;
-      for (int d = 0; d < seg.cons_diffs; d += 8) {  // eight departures at a time: their loads overlap
+      const int n_dif = 8 * (int)(rng >> 25);  // this gene's own departures (the table is padded to the set's longest list)
+      uint32_t w_next[8];  // the next round's entries travel while this round's are applied
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w_next[i] = n_dif > 0 ? dp[(size_t)i * n] : 0u;
+      for (int d = 0; d < n_dif; d += 8) {  // eight departures at a time: their loads overlap
         uint32_t w[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = dp[(size_t)(d + i) * n];
+        for (int i = 0; i < 8; ++i) w[i] = w_next[i];
+        if (d + 8 < n_dif) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) w_next[i] = dp[(size_t)(d + 8 + i) * n];
+        }
         double fct[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) fct[i] = em_at(w[i] >> 16) * cons_inv[w[i] & 0xffffu];
@@ -529,7 +594,20 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
   cv += fill(fam.vgerm, gem + nV, 1);
   LH_STAMP(5)
   int cd = 0, cj;
-  if (fam.has_d) {
+  if (!kExt && fam.has_d && nD <= 64 && nJ <= 64 &&
+      (direct || (fam.dgerm.cons_sites == 0 && fam.jgerm.cons_sites == 0 && fam.jpadding.cons_sites == 0))) {
+    // three small sets, three waves, side by side (fill_segments_wave); the counts meet in LDS
+    const int wave = tid >> 6, lane = tid & 63;
+    int m = 0;
+    if (wave == 1) m = fill_segments_wave<kByteOff>(fam.dgerm, em, lane, gem + 2 * (size_t)nV);
+    if (wave == 2) m = fill_segments_wave<kByteOff>(fam.jgerm, em, lane, gem + 2 * (size_t)nV + nD);
+    if (wave == 3) m = fill_segments_wave<kByteOff>(fam.jpadding, em, lane, gem + 2 * (size_t)nV + nD + nJ);
+    if (lane == 0) redi[wave] = m;  // (the first half of redi: last read before vgerm's barriers)
+    __syncthreads();
+    cd = redi[1];
+    cj = redi[2] + redi[3];
+    LH_STAMP(8)
+  } else if (fam.has_d) {
     cd = fill(fam.dgerm, gem + 2 * (size_t)nV, 0);
     LH_STAMP(6)
     cj = fill(fam.jgerm, gem + 2 * (size_t)nV + nD, 1);
