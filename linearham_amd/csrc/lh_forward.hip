@@ -594,14 +594,16 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
   cv += fill(fam.vgerm, gem + nV, 1);
   LH_STAMP(5)
   int cd = 0, cj;
-  if (!kExt && fam.has_d && nD <= 64 && nJ <= 64 &&
+  if (!kExt && nD <= 64 && nJ <= 64 &&
       (direct || (fam.dgerm.cons_sites == 0 && fam.jgerm.cons_sites == 0 && fam.jpadding.cons_sites == 0))) {
-    // three small sets, three waves, side by side (fill_segments_wave); the counts meet in LDS
+    // the small sets (D, J, J padding; light chains: J, J padding), a wave each, side by side (fill_segments_wave);
+    // the counts meet in LDS
     const int wave = tid >> 6, lane = tid & 63;
+    double* jg = gem + 2 * (size_t)nV + (fam.has_d ? nD : 0);
     int m = 0;
-    if (wave == 1) m = fill_segments_wave<kByteOff>(fam.dgerm, em, lane, gem + 2 * (size_t)nV);
-    if (wave == 2) m = fill_segments_wave<kByteOff>(fam.jgerm, em, lane, gem + 2 * (size_t)nV + nD);
-    if (wave == 3) m = fill_segments_wave<kByteOff>(fam.jpadding, em, lane, gem + 2 * (size_t)nV + nD + nJ);
+    if (wave == 1 && fam.has_d) m = fill_segments_wave<kByteOff>(fam.dgerm, em, lane, gem + 2 * (size_t)nV);
+    if (wave == 2) m = fill_segments_wave<kByteOff>(fam.jgerm, em, lane, jg);
+    if (wave == 3) m = fill_segments_wave<kByteOff>(fam.jpadding, em, lane, jg + nJ);
     if (lane == 0) redi[wave] = m;  // (the first half of redi: last read before vgerm's barriers)
     __syncthreads();
     cd = redi[1];

@@ -673,7 +673,8 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
                                     (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
   static const bool seg_env = getenv("LH_K1_SEGMENTS") != nullptr;  // test hook: segments on small trees too
   static const int seg_waves = getenv("LH_K1_SEG_WAVES") ? atoi(getenv("LH_K1_SEG_WAVES")) : 4;  // measured: 4 (128 VGPRs, few spills) beats 5 by 9 %
-  const bool fused = allow_fused && two && R * wpr <= 8 && fused_lds <= 53 * 1024 && !seg_env;
+  static const bool no_fuse = getenv("LH_K1_NO_FUSE") != nullptr;  // test hook: one workgroup per (sample, rate)
+  const bool fused = allow_fused && !no_fuse && two && R * wpr <= 8 && fused_lds <= 53 * 1024 && !seg_env;
   // large trees: with the whole tip table in LDS fewer than five waves per SIMD would be resident
   const bool seg = two && !fused && ((160 * 1024 / tip_bytes) * wpr / 4 < 5 || seg_env);
   const size_t lds = fused ? fused_lds : seg ? (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) : tip_bytes;
