@@ -76,7 +76,7 @@ def test_phylo_hmm(goldens, data_dir, case, params, R):
             assert s[k] == want[k], k
 
 
-@pytest.mark.parametrize("locus,n_rows", [("igh", 9), ("igk", 9), ("igh", 150)])
+@pytest.mark.parametrize("locus,n_rows", [("igh", 9), ("igk", 9), ("igh", 150), ("igh", 1), ("igk", 2)])
 def test_run_pipeline_matches_oracle(tmp_path, locus, n_rows):
     """PhyloHMM::RunPipeline (src/PhyloHMM.cpp:393-446) on a synthetic RevBayes table: batched GPU
     evaluation + host sampling must reproduce the row-by-row oracle, including the RNG stream -- also when the
