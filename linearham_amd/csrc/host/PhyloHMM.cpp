@@ -265,6 +265,71 @@ void PhyloHMM::InitializePhyloEmission() {
   cache_forward_ = true;
 }
 
+namespace {
+
+// the state word whose tempered value is y (inverse of std::mt19937's output transformation)
+uint32_t Untemper(uint32_t y) {
+  y ^= y >> 18;
+  y ^= (y << 15) & 0xEFC60000u;
+  uint32_t t = y;
+  for (int i = 0; i < 5; ++i) t = y ^ ((t << 7) & 0x9D2C5680u);
+  y = t;
+  t = y;
+  for (int i = 0; i < 3; ++i) t = y ^ (t >> 11);
+  return t;
+}
+
+}  // namespace
+
+void PhyloHMM::SampleStatesWithWords(const uint32_t* words, int n_words, std::vector<int32_t>& device_states,
+                                     std::vector<int32_t>& host_states) {
+  Require(have_tree_, "InitializePhyloParameters must be called first");
+  CreateFamily();
+  Require(device_sampler_, "the family has no device sampler");
+  const int raw = RawDrawsPerSample();
+  Require(n_words >= raw && n_words <= 624, "SampleStatesWithWords: need RawDrawsPerSample() .. 624 words");
+  const int T = tree_.n_tips;
+  std::vector<int32_t> ops((std::size_t)(T - 2) * 4);
+  int32_t depth = 0;
+  CheckHip(lh_schedule_tree(T, tree_.children.data(), tree_.root, ops.data(), &depth), "lh_schedule_tree");
+  // device
+  device_states.assign(lh_sample_states(family_), -1);
+  double ll = 0;
+  std::vector<double> rates(num_rates_);
+  CheckHip(lh_eval_sample_batch(family_, 1, T, depth, ops.data(), tree_.brlen.data(), er_.data(), pi_.data(), &alpha_,
+                                num_rates_, words, &ll, rates.data(), device_states.data()),
+           "lh_eval_sample_batch");
+  // host: the same forward arrays, an engine that returns the same words
+  std::vector<double> fwd(lh_forward_size(family_));
+  std::vector<int32_t> sco(lh_scaler_size(family_));
+  lh_eval_outputs outs{nullptr, nullptr, fwd.data(), sco.data()};
+  CheckHip(lh_eval_batch(family_, 1, T, depth, ops.data(), tree_.brlen.data(), er_.data(), pi_.data(), &alpha_,
+                         num_rates_, &ll, &outs),
+           "lh_eval_batch");
+  std::ostringstream st;
+  for (int i = 0; i < 624; ++i) st << Untemper(i < n_words ? words[i] : 0u) << ' ';
+  st << 0;  // position: the next output is the first word
+  std::istringstream in(st.str());
+  std::mt19937 rng;
+  in >> rng;
+  for (int i = 0; i < std::min(n_words, 4); ++i) {
+    std::mt19937 probe = rng;
+    probe.discard(i);
+    Require((uint32_t)probe() == words[i], "SampleStatesWithWords: engine state construction failed");
+  }
+  EnsureSamplingLists();
+  RowSampler s;
+  SampleRow(s, fwd.data(), rng);
+  host_states.clear();
+  host_states.push_back(s.jgerm_state_ind);
+  if (locus_ == "igh") {
+    host_states.insert(host_states.end(), s.dj_junction_state_inds.begin(), s.dj_junction_state_inds.end());
+    host_states.push_back(s.dgerm_state_ind);
+  }
+  host_states.insert(host_states.end(), s.vd_junction_state_inds.begin(), s.vd_junction_state_inds.end());
+  host_states.push_back(s.vgerm_state_ind);
+}
+
 void PhyloHMM::RunForwardAlgorithm() {
   UnpackForward(pending_forward_.data(), pending_scalers_.data());
   loglikelihood_ = pending_loglik_;

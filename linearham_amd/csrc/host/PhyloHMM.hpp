@@ -87,6 +87,12 @@ class PhyloHMM : public HMM {
                                            const std::vector<double>& pi, double alpha, int num_rates);
   void InitializePhyloEmission();
   void RunPipeline(const std::string& input_path, const std::string& output_path, int num_rates);
+  /// Test entry: the state draws of SampleNaiveSequence for the current tree and parameters with the engine's
+  /// outputs GIVEN (n_words >= RawDrawsPerSample(), at most 624), once by the device sampler (lh_eval_sample_batch)
+  /// and once by the host sampler (HMM::SampleRow on a std::mt19937 whose state is set so that it returns exactly these
+  /// words).  States as lh_eval_sample_batch lays them out.
+  void SampleStatesWithWords(const uint32_t* words, int n_words, std::vector<int32_t>& device_states,
+                             std::vector<int32_t>& host_states);
 
   /// The per-tree body of scripts/run_bootstrap_asr_ess.R:48-104 for every row of a RunPipeline output table
   /// (columns er[1..6], pi[1..4], tree, sr[1..R], NaiveSequence): per alignment site a rate category is drawn

@@ -228,6 +228,19 @@ int lhh_sample(void* h, const char** out) {
     *out = g_out.c_str();
   });
 }
+// Test entry (PhyloHMM::SampleStatesWithWords): device_states / host_states [n_states]; returns the count in *n_states.
+int lhh_phylo_sample_words(void* h, const uint32_t* words, int n_words, int32_t* device_states, int32_t* host_states,
+                           int cap, int* n_states) {
+  return Guard([&] {
+    std::vector<int32_t> d, s;
+    static_cast<linearham::PhyloHMM*>(h)->SampleStatesWithWords(words, n_words, d, s);
+    if ((int)d.size() > cap || d.size() != s.size()) throw std::runtime_error("lhh_phylo_sample_words: state count");
+    std::copy(d.begin(), d.end(), device_states);
+    std::copy(s.begin(), s.end(), host_states);
+    *n_states = (int)d.size();
+  });
+}
+
 int lhh_run_pipeline(void* h, const char* input_path, const char* output_path, int num_rates) {
   return Guard([&] { dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h)).RunPipeline(input_path, output_path, num_rates); });
 }

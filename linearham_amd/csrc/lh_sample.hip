@@ -82,6 +82,9 @@ __device__ int wave_draw(int n_dense, const double* pre, int n_pre, int n_mid, F
   for (int a = 0; a < n_post; ++a) sum += post[a];
   const double p = canonical(d);
   if (!(p > 0.0)) return kFirst;
+  // no positive weight at all: every quotient is 0 / 0, no partial sum compares below the uniform, and lower_bound
+  // -- which only ever moves left then -- ends on element 0
+  if (!(sum > 0.0)) return kFirst;
   double cum = 0.0;
   int pos = 0;
   for (int a = 0; a < n_pre; ++a, ++pos) {
@@ -114,11 +117,19 @@ struct Succ {
   int kind;  // 3: gene `gene` of the germline region right of the junction
   int gene;
   int base;
+  int row;   // the junction row a germline state belongs to (kinds 0 and 2); -1: any row (NTI states)
 };
 
+// The sampled state of row i + 1 normally belongs to row i + 1.  It need not: when the uniform exceeds the last
+// partial sum, discrete_distribution returns the LAST element of the state vector whatever it is, and the reference
+// carries on from there with the dense transition column of that state.  `row` lets the steps below reproduce
+// that: a transition into a germline state exists only from the row before its own.
 __device__ inline Succ classify(const DevSampleJunction& J, int dense) {
   const int c = J.state_class[dense];
-  return Succ{c & 3, c >> 4, (c >> 2) & 3};
+  Succ s{c & 3, c >> 4, (c >> 2) & 3, -1};
+  if (s.kind == 0) s.row = dense - J.left_dense[s.gene];
+  if (s.kind == 2) s.row = J.right_first[s.gene] + (dense - J.right_dense[s.gene] - 4);
+  return s;
 }
 
 // One backward step: draws the state of junction row i given its successor (row i + 1, or the gene of the region
@@ -133,7 +144,8 @@ __device__ int draw_row(const DevSampleJunction& J, int i, const Succ& sc, const
   if (sc.kind == 0) {
     // the only predecessor of a left gene's state is the gene's state on the row before: the distribution has one
     // non-zero weight, but the host still draws (and the uniform may be 0, or the weight's quotient below it)
-    const double w = J.left_trans[(size_t)(i + 1) * nL + r1] * fL[r1];
+    // (a state that does not belong to row i + 1 has no predecessor with a forward entry on row i)
+    const double w = sc.row == i + 1 ? J.left_trans[(size_t)(i + 1) * nL + r1] * fL[r1] : 0.0;
     const int pos = wave_draw(J.n_states, &w, 1, 0, [](int) { return 0.0; }, nullptr, 0, d);
     return pos == kFirst ? 0 : pos == kPastEnd ? J.n_states - 1 : J.left_dense[r1] + i;
   }
@@ -143,7 +155,7 @@ __device__ int draw_row(const DevSampleJunction& J, int i, const Succ& sc, const
   if (sc.kind == 1)
     x = J.nli[(size_t)r1 * 4 + sc.base];
   else if (sc.kind == 2)
-    x = J.li[(size_t)(i + 1) * nR + r1];
+    x = sc.row == i + 1 ? J.li[(size_t)sc.row * nR + r1] : 0.0;  // left states reach it from the row before its own only
   else {
     x = J.exit_li[r1];
     exitp = J.prod[r1];
@@ -162,14 +174,15 @@ __device__ int draw_row(const DevSampleJunction& J, int i, const Succ& sc, const
     if (sc.kind == 1)
       t = J.ntt[(size_t)r1 * 16 + a * 4 + sc.base];
     else if (sc.kind == 2)
-      t = J.nlo[((size_t)(i + 1) * nR + r1) * 4 + a];
+      t = J.nlo[((size_t)sc.row * nR + r1) * 4 + a];  // NTI states live on every row: into the state's own position
     else
       t = J.exit_nlo[(size_t)r1 * 4 + a];
     own[a] = t * fN[(size_t)r1 * 4 + a];
   }
   own[4] = 0.0;
   const int first = J.right_first[r1];
-  if (i >= first && sc.kind != 1) own[4] = (sc.kind == 2 ? J.rtrans[(size_t)(i + 1) * nR + r1] : J.exit_trans[r1]) * fR[r1];
+  if (i >= first && sc.kind == 2 && sc.row == i + 1) own[4] = J.rtrans[(size_t)sc.row * nR + r1] * fR[r1];
+  if (i >= first && sc.kind == 3) own[4] = J.exit_trans[r1] * fR[r1];
   const bool rf = J.right_first_block != 0;
   const int pos = wave_draw(J.n_states, own, rf ? 5 : 0, nL, left_weight, own, rf ? 0 : 5, d);
   if (pos == kFirst) return 0;
@@ -187,9 +200,10 @@ __device__ int draw_left_region(const DevSampleJunction& J, int dense0, const do
       [&](int g) -> double {
         double t;
         if (sc.kind == 0) {
-          if (g != sc.gene) return 0.0;
+          if (g != sc.gene || sc.row != 0) return 0.0;
           t = J.left_trans[g];  // row 0 of left_trans: the transition out of the germline region
         } else {
+          if (sc.kind == 2 && sc.row != 0) return 0.0;
           const double x = sc.kind == 1 ? J.nli[(size_t)sc.gene * 4 + sc.base] : J.li[sc.gene];  // row 0 of li
           t = (J.enter_lo[g] * J.gp[sc.gene]) * x;
         }
@@ -205,7 +219,7 @@ __device__ int sample_junction(const DevSampleJunction& J, int right_gene, const
                                 Draw& d, int32_t* __restrict__ states) {
   const int W = J.n_rows;
   const size_t stride = (size_t)J.n_left + 5 * (size_t)J.n_right;
-  Succ sc{3, right_gene, 0};
+  Succ sc{3, right_gene, 0, -1};
   int row0 = 0;
   for (int i = W - 1; i >= 0; --i) {
     const int s = draw_row(J, i, sc, fwd_rows + (size_t)i * stride, d);

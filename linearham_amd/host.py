@@ -120,6 +120,18 @@ class PhyloHMM(_HMM):
     def set_extended_range(self, on=True):
         _check(self.lib.lhh_phylo_set_extended_range(self.h, int(on)))
 
+    def sample_states_with_words(self, words):
+        """(device states, host states) of one SampleNaiveSequence whose engine outputs are `words` (test entry)."""
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        d = np.zeros(4096, dtype=np.int32)
+        s = np.zeros(4096, dtype=np.int32)
+        n = C.c_int()
+        self.lib.lhh_phylo_sample_words.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                    C.POINTER(C.c_int)]
+        _check(self.lib.lhh_phylo_sample_words(self.h, w.ctypes.data, len(w), d.ctypes.data, s.ctypes.data, 4096,
+                                               C.byref(n)))
+        return d[:n.value].copy(), s[:n.value].copy()
+
     def run_pipeline(self, input_path, output_path, num_rates):
         _check(self.lib.lhh_run_pipeline(self.h, input_path.encode(), output_path.encode(), num_rates))
 

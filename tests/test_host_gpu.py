@@ -291,6 +291,35 @@ def test_device_sampler_matches_host_sampler(tmp_path, locus, seed):
     assert len(rows) == 5001 and len({r[c] for r in rows[1:]}) > 1   # the draws do vary over the rows
 
 
+@pytest.mark.parametrize("locus", ["igh", "igk"])
+def test_device_sampler_on_crafted_engine_outputs(tmp_path, locus):
+    """K4 against HMM::SampleRow draw by draw on engine outputs chosen to hit the corners of libstdc++'s
+    discrete_distribution (bits/random.tcc): a uniform of exactly 0 (lower_bound returns element 0 whatever it holds),
+    the largest uniform below 1 (the last partial sum is forced to 1), uniforms next to 0 and 1, and random words.
+    The host engine is a std::mt19937 whose state is set so that it returns exactly these words."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_samples=3, seed=23, locus=locus), out)
+    yaml_path, pdir = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params")
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    h = host.PhyloHMM(yaml_path, 0, pdir, 0)
+    rng = np.random.default_rng(5)
+    n_words = 600
+    patterns = [np.zeros(n_words, np.uint32), np.full(n_words, 0xFFFFFFFF, np.uint32)]
+    lo1 = np.zeros(n_words, np.uint32); lo1[0::2] = 1                    # smallest positive uniform
+    hi1 = np.full(n_words, 0xFFFFFFFF, np.uint32); hi1[0::2] = 0xFFFFF800  # rounds to just below 1
+    mix = np.where(rng.random(n_words) < 0.5, 0, 0xFFFFFFFF).astype(np.uint32)
+    patterns += [lo1, hi1, mix] + [rng.integers(0, 2 ** 32, n_words, dtype=np.uint64).astype(np.uint32) for _ in range(20)]
+    seen = set()
+    for r in rows:
+        h.initialize_phylo_parameters(r["tree"], r["er"], r["pi"], r["alpha"], 4, is_path=False)
+        for w in patterns:
+            dev, ref = h.sample_states_with_words(w)
+            np.testing.assert_array_equal(dev, ref)
+            seen.add(tuple(dev))
+    assert len(seen) > 10   # the patterns do lead to different paths
+
+
 def test_full_size_family_properties(tmp_path):
     """BASELINE.json configs[2] at full size (100 leaves x 400 sites, 200 V / 30 D / 12 J alleles) through the C++
     host and the C ABI -- properties that need no oracle run: rows repeated in a batch give identical bits wherever
