@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <deque>
 #include <exception>
 #include <functional>
 #include <mutex>
@@ -762,6 +763,31 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
     }
   };
   double t_words = 0;
+  // Stage 0: a parser thread turns the next batches of rows into device arrays (worker threads inside FlattenTable) and
+  // keeps at most two of them waiting, so that parsing batch k + 1 overlaps the device's work on batch k.
+  std::deque<TableBatch> parsed;
+  bool parser_done = false;
+  std::thread parser([&] {
+    try {
+      for (std::size_t off = 0; off < N; off += kBatch) {
+        const std::size_t m = std::min(kBatch, N - off);
+        const auto t0 = now();
+        TableBatch tb = FlattenTable(table, off, off + m, true, true, input_path);
+        t_flat += secs(t0, now());
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return parsed.size() < 2 || cancel; });
+        if (cancel) return;
+        parsed.push_back(std::move(tb));
+        cv.notify_all();
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lock(mu);
+      if (!producer_error) producer_error = std::current_exception();
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    parser_done = true;
+    cv.notify_all();
+  });
   std::thread producer([&] {
     try {
       int k = 0;
@@ -769,9 +795,15 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       for (std::size_t off = 0; off < N; off += kBatch, k ^= 1) {
         Slot& s = slots[k];
         const std::size_t m = std::min(kBatch, N - off);
-        const auto t0 = now();
-        TableBatch tb = FlattenTable(table, off, off + m, true, true, input_path);
-        const auto t1 = now();
+        TableBatch tb;
+        {
+          std::unique_lock<std::mutex> lock(mu);
+          cv.wait(lock, [&] { return !parsed.empty() || parser_done || cancel || producer_error; });
+          if (cancel || producer_error || parsed.empty()) return;  // (an empty queue with the parser gone: it failed)
+          tb = std::move(parsed.front());
+          parsed.pop_front();
+          cv.notify_all();
+        }
         {
           std::unique_lock<std::mutex> lock(mu);
           cv.wait(lock, [&] { return s.state == 0 || cancel; });
@@ -807,7 +839,6 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
                    "lh_eval_batch");
         }
         const auto t3 = now();
-        t_flat += secs(t0, t1);
         t_eval += secs(t2, t3);
         {
           std::lock_guard<std::mutex> lock(mu);
@@ -821,15 +852,16 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       cv.notify_all();
     }
   });
-  struct Joiner {  // the producer is stopped, joined and the slots are freed on every way out
-    std::thread& t;
+  struct Joiner {  // the two threads are stopped, joined and the slots are freed on every way out
+    std::thread &t, &t0;
     std::function<void()> before, after;
     ~Joiner() {
       before();
+      if (t0.joinable()) t0.join();
       if (t.joinable()) t.join();
       after();
     }
-  } joiner{producer,
+  } joiner{producer, parser,
            [&] {
              {
                std::lock_guard<std::mutex> lock(mu);
