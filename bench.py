@@ -192,6 +192,8 @@ def parse_args():
     ap.add_argument("--no-check", action="store_true", help="kernel timing experiments only")
     ap.add_argument("--no-forward-rate", action="store_true", help="skip the second timed loop (forward arrays on)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-samples", type=int, default=192,
+                    help="evaluations of the CPU baseline sample (also the rows the parity check covers)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (through host copies) only to rehearse the multi-rank path on "
                          "a box with fewer GPUs than ranks -- ranks then share devices (LOCAL_RANK modulo)")
@@ -417,7 +419,7 @@ def worker(args, rank, local_rank, world):
             check_ids = list(range(min(n_total, 2 * world if world > 1 else 2)))
             rows = [int(r) for r in sharding.table_rows(check_ids, flat["n_rows"], world, n_total)]
             if want_base or world > 1 or args.preset in ("small", "config3"):
-                ref_ll, base = cpu_oracle(fam_dir, rows, args.cpu_budget_s, 192 if want_base else 0)
+                ref_ll, base = cpu_oracle(fam_dir, rows, args.cpu_budget_s, args.cpu_samples if want_base else 0)
                 if base:
                     out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
                     out["speedup_vs_cpu_all_cores"] = value / base["value"]
