@@ -111,6 +111,12 @@ int lh_device_count(void);
  * thread while the caller parses its inputs); lh_host_alloc / lh_host_free hand out page-locked host memory,
  * which the host-pointer entry points copy to and from at full PCIe rate (any host pointer is accepted). */
 int lh_warmup(void);
+/* Makes `device` (0 .. lh_device_count() - 1) the calling thread's current device (hipSetDevice, for hosts that do
+ * not link the HIP runtime themselves).  A handle belongs to the device that is current when lh_family_create
+ * runs, and every entry point that takes a handle switches to that device for its duration: a host with several
+ * GPUs creates one handle per device and drives each from its own thread (tree samples dealt
+ * i mod N; reference loop src/PhyloHMM.cpp:414-442). */
+int lh_set_device(int32_t device);
 void* lh_host_alloc(size_t bytes);
 void lh_host_free(void* p);
 
@@ -218,11 +224,19 @@ int lh_eval_batch(lh_family* fam, int32_t n, int32_t n_tips, int32_t max_depth, 
                   int32_t num_rates, double* loglik, const lh_eval_outputs* outs);
 
 /* Same with every array already resident on the handle's device; enqueued on `hip_stream`
- * (a hipStream_t, NULL = default stream) without synchronising. */
+ * (a hipStream_t, NULL = default stream) without synchronising.  Device-resident schedules are not trusted: a
+ * kernel (K0c) checks every op on the device before anything is indexed with it; a malformed schedule leaves NaN
+ * in that sample's results and raises the handle's error word, which lh_family_status reports.  (The reference
+ * checks nothing here: src/PhyloHMM.cpp:421 uses the parsed tree unchecked.) */
 int lh_eval_batch_device(lh_family* fam, int32_t n, int32_t n_tips, int32_t max_depth,
                          const int32_t* ops, const double* brlen, const double* er, const double* pi,
                          const double* alpha, int32_t num_rates, double* loglik,
                          const lh_eval_outputs* outs, void* hip_stream);
+
+/* Synchronises the handle's device, then reports and clears its asynchronous error state: nonzero (message in
+ * lh_last_error) if a launch since the previous call met a malformed schedule.  The host-pointer entry points
+ * call it themselves before they return. */
+int lh_family_status(lh_family* fam);
 
 /* Forward pass only, on caller-supplied per-column emissions em[n][C] (host pointers). */
 int lh_forward_batch(lh_family* fam, int32_t n, const double* em, double* loglik,

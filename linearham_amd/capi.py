@@ -44,11 +44,13 @@ EXPORTS = ["lh_last_error", "lh_device_count", "lh_family_create", "lh_family_de
            "lh_forward_size", "lh_scaler_size", "lh_family_info", "lh_family_consensus_sets", "lh_schedule_tree", "lh_eval_batch",
            "lh_eval_batch_device", "lh_forward_batch", "lh_asr_batch", "lh_asr_batch_device",
            "lh_profile_enable", "lh_profile_read", "lh_asr_profile_read", "lh_family_set_extended_range", "lh_warmup", "lh_host_alloc", "lh_host_free", "lh_family_set_sampler",
-           "lh_sample_words", "lh_sample_states", "lh_eval_sample_batch"]
+           "lh_sample_words", "lh_sample_states", "lh_eval_sample_batch", "lh_set_device", "lh_family_status"]
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "liblinearham_hip.so")
+    # LH_LIB_DIR: timing experiments load a variant build from its own directory (tools/build_variant.sh) instead of
+    # overwriting the product library in place
+    return os.path.join(os.environ.get("LH_LIB_DIR") or os.path.join(_HERE, "lib"), "liblinearham_hip.so")
 
 
 class HipLibrary:
@@ -87,6 +89,8 @@ class HipLibrary:
         lib.lh_profile_enable.argtypes = [C.c_void_p, C.c_int]
         lib.lh_family_set_extended_range.argtypes = [C.c_void_p, C.c_int]
         lib.lh_profile_read.argtypes = [C.c_void_p, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_int64)]
+        lib.lh_set_device.argtypes = [C.c_int32]
+        lib.lh_family_status.argtypes = [C.c_void_p]
 
     def error(self):
         return self.lib.lh_last_error().decode()
@@ -261,6 +265,10 @@ class Family:
         self.hip.check(self.hip.lib.lh_eval_batch_device(
             self.handle, n, n_tips, max_depth, ops_ptr, brlen_ptr, er_ptr, pi_ptr, alpha_ptr, num_rates,
             loglik_ptr, None, stream))
+
+    def status(self):
+        """Synchronise the device and raise if a launch since the last call met a malformed (device-resident) schedule."""
+        self.hip.check(self.hip.lib.lh_family_status(self.handle))
 
     def forward_batch(self, em, want=()):
         em = _f64(em)

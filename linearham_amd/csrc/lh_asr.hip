@@ -172,8 +172,9 @@ __global__ void __launch_bounds__(256) asr_rate_kernel(int n, int R, int L, int 
 // K3s: per sample, the schedule in the form K3b walks it (one thread does the stack bookkeeping out of LDS,
 // then a thread per op writes its descriptor).
 __global__ void __launch_bounds__(64) asr_sched_kernel(int T, const int32_t* __restrict__ ops,
-                                                       AsrOp* __restrict__ desc) {
+                                                       const int4* __restrict__ hdr, AsrOp* __restrict__ desc) {
   extern __shared__ double2 sched_smem[];
+  if (hdr[blockIdx.x].w != 0) return;  // K0c (lh_prune.hip) rejected this sample's schedule; K3b skips it too
   const int n_ops = T - 2;
   int4* ops_s = reinterpret_cast<int4*>(sched_smem);               // [n_ops]
   int32_t* popped_op = reinterpret_cast<int32_t*>(ops_s + n_ops);  // [n_ops]
@@ -247,8 +248,10 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
                                                   const double* __restrict__ pi,
                                                   const uint8_t* __restrict__ choice_g,
                                                   const uint8_t* __restrict__ naive, uint64_t seed, uint64_t sample0,
-                                                  double2* clv, int Lp, uint8_t* __restrict__ anc, int dbg_mode) {
+                                                  double2* clv, int Lp, uint8_t* __restrict__ anc, int dbg_mode,
+                                                  const int4* __restrict__ hdr) {
   extern __shared__ double2 asr_smem[];
+  if (hdr[blockIdx.y].w != 0) return;  // malformed schedule (reported through lh_family_status)
   const int n_ops = T - 2;
   const int NP = n_prune + 1;  // patterns, the all-N one (id n_prune) included
   double* tiptab = reinterpret_cast<double*>(asr_smem);           // [T][4][4]
@@ -528,7 +531,7 @@ size_t asr_desc_bytes(int T) { return sizeof(AsrOp) * (size_t)(T - 2); }
 int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, const double* brlen, const double* rates,
                const double* eig, const double* pi, const double* site_lik, const int32_t* site_scal,
                const uint8_t* naive, uint64_t seed, uint64_t sample0, double* clv, void* desc, uint8_t* anc,
-               uint8_t* rate_choice, hipStream_t stream) {
+               uint8_t* rate_choice, const int4* hdr, hipStream_t stream) {
   const int L = fam.n_sites;
   const size_t lds = asr_lds_bytes(T, L, R, fam.n_prune);
   if (lds > 160 * 1024 || L < 1) return 1;
@@ -539,11 +542,11 @@ int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, co
   hipLaunchKernelGGL(asr_rate_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, n, R, L,
                      fam.n_prune, fam.site_pat, site_lik, site_scal, naive, seed, sample0, rate_choice);
   const size_t sched_lds = (size_t)(T - 2) * (sizeof(int4) + 2 * sizeof(int32_t));
-  hipLaunchKernelGGL(asr_sched_kernel, dim3(n), dim3(64), sched_lds, stream, T, ops, static_cast<AsrOp*>(desc));
+  hipLaunchKernelGGL(asr_sched_kernel, dim3(n), dim3(64), sched_lds, stream, T, ops, hdr, static_cast<AsrOp*>(desc));
   static const int dbg = getenv("LH_ASR_DBG") ? atoi(getenv("LH_ASR_DBG")) : 0;  // phase-timing hook
   hipLaunchKernelGGL(asr_kernel, dim3(R, n), dim3(256), lds, stream, R, T, L, fam.n_prune, fam.msa, fam.site_pat,
                      static_cast<const AsrOp*>(desc), brlen, rates, eig, pi, (const uint8_t*)rate_choice, naive, seed,
-                     sample0, reinterpret_cast<double2*>(clv), (int)asr_slots(L, R), anc, dbg);
+                     sample0, reinterpret_cast<double2*>(clv), (int)asr_slots(L, R), anc, dbg, hdr);
   return 0;
 }
 

@@ -30,8 +30,9 @@ int fail(const std::string& msg) {
 
 struct Workspace {
   int n_cap = 0, R = 0, T = 0;
-  double *rates = nullptr, *eig = nullptr, *pmat = nullptr, *site_lik = nullptr;
+  double *rates = nullptr, *eig = nullptr, *site_lik = nullptr;
   int32_t* site_scal = nullptr;
+  lh::PruneWs prune{};  // K0c's checked / rewritten schedules and K1's scratch area; err_flag is the family's
 };
 
 struct ForwardWs {  // K2a -> K2b hand-off, sized by the largest batch seen
@@ -96,12 +97,28 @@ struct lh_family {
     size_t pinned_cap = 0;
   } smp;
   int32_t n_ucol_used = 0;  // (naive base, pattern) pairs some xMSA column has (lh_family_info)
+  int32_t* err_flag = nullptr;  // device word (arena): K0c sets it when a schedule is malformed (lh_family_status)
   std::vector<EventSet> events;
   double ms[3] = {0, 0, 0};
   int64_t launches = 0;
 };
 
 namespace {
+
+// A handle belongs to the device that was current when lh_family_create ran; every entry point makes that device
+// current for its duration, so handles of different GPUs can be driven from any thread (one thread per handle).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(const lh_family* f) {
+    if (f && hipGetDevice(&prev) == hipSuccess && prev != f->device) switched = hipSetDevice(f->device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 // All family tables are sub-allocated from a few large device chunks: the forward kernel touches ~45
 // small tables per junction row, and one allocation (and page) per table costs TLB reach.
@@ -336,12 +353,20 @@ int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_
   return 0;
 }
 
-size_t scratch_doubles(int T) { return (size_t)std::max(T - 2, 1) * 32; }
+// bytes of K1 workspace per sample: scratch area (P-matrices, cherry tables) and K0c's schedule arrays
+size_t k1_bytes_per_sample(const lh_family* f, int T, int R) {
+  const lh::PruneWsSizes z = lh::prune_ws_sizes(T, f->host.msa_mixed_n != 0);
+  const size_t n_ops = (size_t)std::max(T - 2, 1);
+  return sizeof(double) * R * z.scratch_doubles_per_rate + n_ops * (2 * sizeof(int4) + sizeof(int32_t)) +
+         z.tabs_per_sample * sizeof(int4) + sizeof(int4);
+}
 
 int ensure_workspace(lh_family* f, int n, int R, int T) {
   Workspace& w = f->ws;
   if (n <= w.n_cap && R == w.R && T == w.T) return 0;
-  void** bufs[] = {(void**)&w.rates, (void**)&w.eig, (void**)&w.pmat, (void**)&w.site_lik, (void**)&w.site_scal};
+  void** bufs[] = {(void**)&w.rates,         (void**)&w.eig,        (void**)&w.site_lik,   (void**)&w.site_scal,
+                   (void**)&w.prune.scratch, (void**)&w.prune.wops, (void**)&w.prune.mats, (void**)&w.prune.tabs,
+                   (void**)&w.prune.hdr};
   for (void** b : bufs) {
     if (*b) LH_HIP(hipFree(*b));
     *b = nullptr;
@@ -351,8 +376,15 @@ int ensure_workspace(lh_family* f, int n, int R, int T) {
   const int cap = std::max(n, 1);
   LH_HIP(hipMalloc((void**)&w.rates, sizeof(double) * cap * R));
   LH_HIP(hipMalloc((void**)&w.eig, sizeof(double) * cap * 36));
-  // K1's scratch area per (sample, rate): the schedule's P-matrices
-  LH_HIP(hipMalloc((void**)&w.pmat, sizeof(double) * cap * R * scratch_doubles(T)));
+  // K1's scratch area per (sample, rate): the walk's P-matrices and cherry tables; K0c's per-sample schedule arrays
+  const lh::PruneWsSizes z = lh::prune_ws_sizes(T, f->host.msa_mixed_n != 0);
+  const size_t n_ops = (size_t)std::max(T - 2, 1);
+  LH_HIP(hipMalloc((void**)&w.prune.scratch, sizeof(double) * cap * R * z.scratch_doubles_per_rate));
+  LH_HIP(hipMalloc((void**)&w.prune.wops, 2 * sizeof(int4) * cap * n_ops));
+  LH_HIP(hipMalloc((void**)&w.prune.mats, sizeof(int32_t) * cap * n_ops));
+  LH_HIP(hipMalloc((void**)&w.prune.tabs, sizeof(int4) * cap * z.tabs_per_sample));
+  LH_HIP(hipMalloc((void**)&w.prune.hdr, sizeof(int4) * cap));
+  w.prune.err_flag = f->err_flag;
   LH_HIP(hipMalloc((void**)&w.site_lik, sizeof(double) * cap * R * 5 * std::max(L, (size_t)1)));
   LH_HIP(hipMalloc((void**)&w.site_scal, sizeof(int32_t) * cap * R * std::max(L, (size_t)1)));
   w.n_cap = cap;
@@ -421,6 +453,12 @@ int lh_device_count(void) {
   return n;
 }
 
+int lh_set_device(int32_t device) {
+  if (device < 0 || device >= lh_device_count()) return fail("lh_set_device: no such device");
+  LH_HIP(hipSetDevice(device));
+  return 0;
+}
+
 int lh_warmup(void) {
   if (lh_device_count() < 1) return fail("lh_warmup: no HIP device available");
   LH_HIP(hipFree(nullptr));  // creates the primary context of the current device
@@ -454,6 +492,14 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
   if (hipGetDevice(&f->device) != hipSuccess) {
     delete f;
     return fail("hipGetDevice failed");
+  }
+  {
+    void* p = nullptr;
+    if (arena_alloc(f, sizeof(int32_t), &p) || hipMemset(p, 0, sizeof(int32_t)) != hipSuccess) {
+      lh_family_destroy(f);
+      return fail("lh_family_create: device allocation failed");
+    }
+    f->err_flag = static_cast<int32_t*>(p);
   }
   lh::DevFamily& h = f->host;
   h.has_d = desc->has_d ? 1 : 0;
@@ -638,10 +684,12 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
 
 void lh_family_destroy(lh_family* f) {
   if (!f) return;
+  DeviceGuard guard(f);
   for (void* p : f->allocs) (void)hipFree(p);
   Workspace& w = f->ws;
-  void* bufs[] = {w.rates, w.eig,      w.pmat,     w.site_lik,  w.site_scal, f->fws.gem,
-                  f->fws.jem, f->fws.gcnt, f->fws.jrs, f->fws.dxf, f->fws.dxc};
+  void* bufs[] = {w.rates,    w.eig,       w.site_lik, w.site_scal, w.prune.scratch, w.prune.wops, w.prune.mats,
+                  w.prune.tabs, w.prune.hdr, f->fws.gem, f->fws.jem,  f->fws.gcnt,     f->fws.jrs,   f->fws.dxf,
+                  f->fws.dxc};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (void* p : f->st.ptr)
@@ -857,6 +905,7 @@ static int upload_sampler_junction(lh_family* f, const lh_sampler_junction& j, l
 
 int lh_family_set_sampler(lh_family* f, const lh_sampler_desc* desc) {
   if (!f || !desc) return fail("lh_family_set_sampler: null argument");
+  DeviceGuard guard(f);
   const lh::DevFamily& h = f->host;
   lh::DevSampler s{};
   s.has_d = h.has_d;
@@ -884,6 +933,24 @@ int lh_family_set_sampler(lh_family* f, const lh_sampler_desc* desc) {
 int32_t lh_sample_words(const lh_family* f) { return f && f->have_sampler ? f->sampler.words_per_sample : 0; }
 int32_t lh_sample_states(const lh_family* f) { return f && f->have_sampler ? f->sampler.states_per_sample : 0; }
 
+// Reads (and clears) the handle's asynchronous error word after synchronising its device.
+static int check_async_error(lh_family* f, const char* who) {
+  int32_t flag = 0;
+  LH_HIP(hipDeviceSynchronize());
+  LH_HIP(hipMemcpy(&flag, f->err_flag, sizeof(flag), hipMemcpyDeviceToHost));
+  if (flag) {
+    LH_HIP(hipMemset(f->err_flag, 0, sizeof(flag)));
+    return fail(std::string(who) + ": malformed schedule op (use lh_schedule_tree); the affected samples' results are NaN");
+  }
+  return 0;
+}
+
+int lh_family_status(lh_family* f) {
+  if (!f) return fail("lh_family_status: null family");
+  DeviceGuard guard(f);
+  return check_async_error(f, "lh_family_status");
+}
+
 int lh_profile_enable(lh_family* f, int enable) {
   if (!f) return fail("null family");
   f->profile = enable != 0;
@@ -892,6 +959,7 @@ int lh_profile_enable(lh_family* f, int enable) {
 
 int lh_profile_read(lh_family* f, double* ms_model, double* ms_prune, double* ms_forward, int64_t* n_launches) {
   if (!f) return fail("null family");
+  DeviceGuard guard(f);
   for (EventSet& es : f->events) {
     LH_HIP(hipEventSynchronize(es.e[3]));
     for (int k = 0; k < 3; ++k) {
@@ -914,6 +982,7 @@ int lh_profile_read(lh_family* f, double* ms_model, double* ms_prune, double* ms
 
 int lh_asr_profile_read(lh_family* f, double* ms_sampling, int64_t* n_launches) {
   if (!f) return fail("null family");
+  DeviceGuard guard(f);
   AsrWs& a = f->asr;
   for (auto& ev : a.events) {
     LH_HIP(hipEventSynchronize(ev.second));
@@ -936,6 +1005,7 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
                          const double* brlen, const double* er, const double* pi, const double* alpha,
                          int32_t R, double* loglik, const lh_eval_outputs* outs, void* hip_stream) {
   if (!f) return fail("lh_eval_batch: null family");
+  DeviceGuard guard(f);
   if (n < 0) return fail("lh_eval_batch: negative batch size");
   if (n == 0) return 0;
   if (f->host.n_seqs < 1) return fail("lh_eval_batch: family was created without an MSA (forward-only)");
@@ -947,7 +1017,7 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
   if (!ops || !brlen || !er || !pi || !alpha || !loglik) return fail("lh_eval_batch: null array");
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   // launch groups of at most kChunk samples and at most ~16 GB of per-sample workspace
-  const size_t per_sample = sizeof(double) * R * (scratch_doubles(T) + 6 * (size_t)std::max(f->host.n_prune, 1));
+  const size_t per_sample = k1_bytes_per_sample(f, T, R) + sizeof(double) * R * 6 * (size_t)std::max(f->host.n_prune, 1);
   const int by_memory = (int)std::max<size_t>(1024, ((size_t)16 << 30) / per_sample);
   const int chunk = std::min<int>(n, std::min(kChunk, by_memory));
   if (ensure_workspace(f, chunk, R, T)) return 1;
@@ -966,7 +1036,7 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
                            stream);
     if (f->profile) LH_HIP(hipEventRecord(es.e[1], stream));
     const int planes = lh::launch_prune(f->host, m, R, T, max_depth, ops + (size_t)off * n_ops * 4,
-                                        brlen + (size_t)off * nodes, rates, w.eig, w.pmat, pi + (size_t)off * 4,
+                                        brlen + (size_t)off * nodes, rates, w.eig, w.prune, pi + (size_t)off * 4,
                                         w.site_lik, w.site_scal, stream);
     if (f->profile) LH_HIP(hipEventRecord(es.e[2], stream));
     if (run_forward(f, m, planes, w.site_lik, w.site_scal, pi + (size_t)off * 4, nullptr, em_out, loglik + off, outs, off,
@@ -1001,6 +1071,7 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
                   const double* brlen, const double* er, const double* pi, const double* alpha, int32_t R,
                   double* loglik, const lh_eval_outputs* outs) {
   if (!f) return fail("lh_eval_batch: null family");
+  DeviceGuard guard(f);
   if (n <= 0) return n == 0 ? 0 : fail("lh_eval_batch: negative batch size");
   if (T < 3) return fail("lh_eval_batch: need at least 3 tips");
   if (!ops || !brlen || !er || !pi || !alpha || !loglik) return fail("lh_eval_batch: null array");
@@ -1104,6 +1175,7 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
                               (double*)d_ll + off, &o, hp.comp);
   }
   if (hipDeviceSynchronize() != hipSuccess && !rc) rc = fail("lh_eval_batch: device synchronisation failed");
+  if (!rc && check_async_error(f, "lh_eval_batch")) rc = 1;  // K0c's verdict on the schedules as the device saw them
   if (rc) return 1;
   LH_HIP(hipMemcpy(loglik, d_ll, sizeof(double) * n, hipMemcpyDeviceToHost));
   if (outs) {
@@ -1123,6 +1195,7 @@ int lh_eval_sample_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
                          const double* brlen, const double* er, const double* pi, const double* alpha, int32_t R,
                          const uint32_t* words, double* loglik, double* rates, int32_t* states) {
   if (!f) return fail("lh_eval_sample_batch: null family");
+  DeviceGuard guard(f);
   if (!f->have_sampler) return fail("lh_eval_sample_batch: lh_family_set_sampler has not been called");
   if (n <= 0) return n == 0 ? 0 : fail("lh_eval_sample_batch: negative batch size");
   if (T < 3) return fail("lh_eval_sample_batch: need at least 3 tips");
@@ -1190,6 +1263,7 @@ int lh_eval_sample_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
   LH_HIP(hipMemcpy(loglik, d[6], bytes[6], hipMemcpyDeviceToHost));
   if (rates) LH_HIP(hipMemcpy(rates, d[7], bytes[7], hipMemcpyDeviceToHost));
   LH_HIP(hipMemcpy(states, d[8], bytes[8], hipMemcpyDeviceToHost));
+  if (check_async_error(f, "lh_eval_sample_batch")) return 1;
   if (timing) {
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double, std::milli>(b - a).count();
@@ -1207,6 +1281,7 @@ int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, c
                         const uint8_t* naive, uint64_t seed, uint64_t first_sample, uint8_t* anc,
                         uint8_t* rate_choice, void* hip_stream) {
   if (!f) return fail("lh_asr_batch: null family");
+  DeviceGuard guard(f);
   if (n < 0) return fail("lh_asr_batch: negative batch size");
   if (n == 0) return 0;
   if (f->host.n_seqs < 1) return fail("lh_asr_batch: family was created without an MSA");
@@ -1222,7 +1297,7 @@ int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, c
   const size_t nodes = 2 * (size_t)T - 2, n_ops = (size_t)T - 2, L = f->host.n_sites;
   // launch groups: at most ~8 GB of CLV area (32 B per inner node and site) plus K1's workspace
   const size_t clv_per_sample = sizeof(double) * n_ops * 4 * lh::asr_slots((int)L, R);
-  const size_t k1_per_sample = sizeof(double) * R * (scratch_doubles(T) + 6 * (size_t)std::max(f->host.n_prune, 1));
+  const size_t k1_per_sample = k1_bytes_per_sample(f, T, R) + sizeof(double) * R * 6 * (size_t)std::max(f->host.n_prune, 1);
   const int by_memory = (int)std::max<size_t>(64, ((size_t)8 << 30) / (clv_per_sample + k1_per_sample));
   const int chunk = std::min<int>(n, std::min(8192, by_memory));
   if (ensure_workspace(f, chunk, R, T)) return 1;
@@ -1260,7 +1335,7 @@ int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, c
     const double* bl_m = brlen + (size_t)off * nodes;
     lh::launch_gtr_setup(m, er + (size_t)off * 6, pi_m, w.eig, stream);
     // per-rate planes: K1 must not mix the categories here
-    const int planes = lh::launch_prune(f->host, m, R, T, max_depth, ops_m, bl_m, r_m, w.eig, w.pmat, pi_m,
+    const int planes = lh::launch_prune(f->host, m, R, T, max_depth, ops_m, bl_m, r_m, w.eig, w.prune, pi_m,
                                         w.site_lik, w.site_scal, stream, false);
     if (planes != R && f->host.n_prune > 0) return fail("lh_asr_batch: internal error (rate planes were mixed)");
     std::pair<hipEvent_t, hipEvent_t> ev;
@@ -1272,7 +1347,7 @@ int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, c
     if (lh::launch_asr(f->host, m, R, T, ops_m, bl_m, r_m, w.eig, pi_m, w.site_lik, w.site_scal,
                        naive + (size_t)off * L, seed, first_sample + (uint64_t)off, aw.clv, aw.desc,
                        anc + (size_t)off * n_ops * L,
-                       rate_choice ? rate_choice + (size_t)off * L : aw.choice, stream))
+                       rate_choice ? rate_choice + (size_t)off * L : aw.choice, w.prune.hdr, stream))
       return fail("lh_asr_batch: launch failed");
     if (f->profile) {
       LH_HIP(hipEventRecord(ev.second, stream));
@@ -1300,6 +1375,7 @@ int lh_asr_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const in
                  const double* er, const double* pi, const double* rates, int32_t R, const uint8_t* naive,
                  uint64_t seed, uint64_t first_sample, uint8_t* anc, uint8_t* rate_choice) {
   if (!f) return fail("lh_asr_batch: null family");
+  DeviceGuard guard(f);
   if (n < 0) return fail("lh_asr_batch: negative batch size");
   if (n == 0) return 0;
   if (T < 3 || T != f->host.n_seqs + 1) return fail("lh_asr_batch: n_tips must equal n_seqs + 1 (naive)");
@@ -1331,7 +1407,7 @@ int lh_asr_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const in
                             (const double*)d[3], (const double*)d[4], R, (const uint8_t*)d[5], seed,
                             first_sample + (uint64_t)off, (uint8_t*)d[6], (uint8_t*)d[7], nullptr))
       return 1;
-    LH_HIP(hipDeviceSynchronize());
+    if (check_async_error(f, "lh_asr_batch")) return 1;
     LH_HIP(hipMemcpy(anc + (size_t)off * n_ops * L, d[6], bytes[6], hipMemcpyDeviceToHost));
     if (rate_choice) LH_HIP(hipMemcpy(rate_choice + (size_t)off * L, d[7], L * m, hipMemcpyDeviceToHost));
   }
@@ -1340,6 +1416,7 @@ int lh_asr_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const in
 
 int lh_forward_batch(lh_family* f, int32_t n, const double* em, double* loglik, const lh_eval_outputs* outs) {
   if (!f) return fail("lh_forward_batch: null family");
+  DeviceGuard guard(f);
   if (n <= 0) return n == 0 ? 0 : fail("lh_forward_batch: negative batch size");
   if (!em || !loglik) return fail("lh_forward_batch: null array");
   const size_t C = f->host.n_xmsa, FS = f->host.forward_size, SS = f->host.scaler_size;

@@ -16,6 +16,32 @@ constexpr double kLogScaleFactor = 177.445678223345993274;  // log(2^256)
 // one or two follow): K1's prologue packs its matrix work by it
 enum : int { OP_CHERRY = 0, OP_TIP_ACC = 1, OP_POP_ACC = 2, OP_PUSH_FLAG = 16, OP_RANK_SHIFT = 8 };
 
+// Walk ops: what K1 executes.  K0c (schedule_check_kernel, lh_prune.hip) validates a sample's schedule ON THE
+// DEVICE and rewrites it with every cherry that can be folded into its consumer replaced by a table look-up: for
+// a cherry (y, z) under branch c the vector P_c (P_y[:, s_y] o P_z[:, s_z]) takes 16 values per (sample, rate)
+// (25 with N tips), which K1's prologue tabulates; then
+//   cherry + tip-into-accumulator      ->  W_CTIP      a = table[s_y][s_z] o tipcol_w         (no mat-vec)
+//   pushed cherry + pop                ->  W_CTAB_ACC  a = table[s_y][s_z] o (P_first a)      (one mat-vec, no push / pop)
+// A walk op is a 32-byte descriptor (struct WalkOp in lh_prune.hip: byte offsets ready for the instructions that
+// use them).
+enum : int { W_CHERRY = 0, W_TIP_ACC = 1, W_POP = 2, W_CTIP = 3, W_CTAB_ACC = 4 };
+
+// K0c's output and K1's scratch area (all device memory, sized by prune_ws_sizes)
+struct PruneWs {
+  double* scratch;    // per (sample, rate): [n_mat + n_tab][16] P-matrices (walk order, then the cherry branches'),
+                      // then [n_tab][E][4] cherry tables, E = 16 or 25
+  int4* wops;         // [n][T-2][2] walk-op descriptors
+  int32_t* mats;      // [n][T-2] node whose branch matrix i of the list is
+  int4* tabs;         // [n][(T-1)/2] cherry tables: tip y, tip z, the cherry's node
+  int4* hdr;          // [n] walk ops, matrices, tables, error (malformed schedule: the sample's results are NaN)
+  int32_t* err_flag;  // set when any sample of any launch had a malformed schedule (lh_family_status reads and clears it)
+};
+struct PruneWsSizes {
+  size_t scratch_doubles_per_rate;  // per (sample, rate)
+  size_t tabs_per_sample;
+};
+PruneWsSizes prune_ws_sizes(int T, bool mixed_n);
+
 // Device copy of lh_segments / lh_junction / family constants (all pointers are device pointers).
 struct DevSegments {
   int32_t n_genes;
@@ -172,7 +198,7 @@ void launch_model_setup(int n, int R, const double* er, const double* pi, const 
 // Returns the number of rate planes left in site_lik / site_scal: R, or 1 if the rates were mixed in K1
 // (site_lik[n][1][5][n_prune], site_scal[n][1][n_prune]); K2a is to be run with that count.
 int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
-                 const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
+                 const double* brlen, const double* rates, const double* eig, const PruneWs& ws, const double* pi,
                  double* site_lik, int32_t* site_scal, hipStream_t stream, bool allow_fused = true);
 
 // GTR eigendecomposition only (K0a's last role): eig[n][36]
@@ -185,7 +211,7 @@ void launch_gtr_setup(int n, const double* er, const double* pi, double* eig, hi
 int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, const double* brlen, const double* rates,
                const double* eig, const double* pi, const double* site_lik, const int32_t* site_scal,
                const uint8_t* naive, uint64_t seed, uint64_t sample0, double* clv, void* desc, uint8_t* anc,
-               uint8_t* rate_choice, hipStream_t stream);
+               uint8_t* rate_choice, const int4* hdr /* K0c's verdicts, PruneWs::hdr */, hipStream_t stream);
 size_t asr_desc_bytes(int T);  // per sample, of the schedule descriptors `desc` (scratch, K3s -> K3b)
 size_t asr_lds_bytes(int T, int L, int R, int n_prune);
 size_t asr_slots(int L, int R);  // slots per sample in K3's CLV area: clv[n][T-2][2][asr_slots] double2

@@ -84,6 +84,13 @@ typedef const double __attribute__((address_space(4))) * pmat_ptr;
 
 // -DLH_EXP_K1_STAMPS: latency of the first P-matrix load of every non-cherry op and the length of the walk, per wave,
 // for 128 workgroups in the middle of the grid (an instrument; it perturbs the schedule it measures)
+#ifdef LH_EXP_CT_STAMPS
+__device__ unsigned long long ct_stamps[1024][10];
+__device__ unsigned long long ct_phase[128][8];
+#define LH_CT_PHASE(i) if (threadIdx.x == 0 && blockIdx.z >= 20000 && blockIdx.z < 20128) ct_phase[blockIdx.z - 20000][i] = __builtin_readcyclecounter();
+#else
+#define LH_CT_PHASE(i)
+#endif
 #ifdef LH_EXP_K1_STAMPS
 __device__ unsigned long long k1_stamps[1024][4];
 __device__ unsigned long long k1_phase[128][8];
@@ -365,6 +372,269 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
   }
 }
 
+
+// ---- cherry tables (round 3) ------------------------------------------------------------------------------------
+// A cherry (y, z) under branch c reaches the rest of the tree only through P_c (P_y[:, s_y] o P_z[:, s_z]): 16
+// vectors per (sample, rate), 25 when tips can be N.  The prologue tabulates them (ctab[table][s_y * SY + s_z][4],
+// global memory: 13 KB per (sample, rate) do not fit beside the tip tables in LDS at three workgroups per CU), and the
+// walk executes the schedule K0c rewrote (lh_device.h, W_*): a quarter fewer ops, a fifth fewer vector instructions.
+
+// One table entry: two 16-byte loads per lane (the prologue of THIS workgroup wrote the table; ordered by the barrier)
+template <bool kN>
+__device__ __forceinline__ void table_entry(const double* ctab, int table, int sy, int sz, double (&c)[4]) {
+  constexpr int SY = kN ? 5 : 4;
+  // 32-bit byte offset from a wave-uniform base: scalar base + vector offset addressing, no 64-bit vector arithmetic
+  const unsigned off = ((unsigned)table * (SY * SY) + (unsigned)(sy * SY + sz)) * 32u;
+  const double2* q = reinterpret_cast<const double2*>(reinterpret_cast<const char*>(ctab) + off);
+  const double2 q0 = q[0], q1 = q[1];
+  c[0] = q0.x, c[1] = q0.y, c[2] = q1.x, c[3] = q1.y;
+}
+
+// The walk descriptors (two int4 per op, written by K0c, fetched with one scalar load) hold everything an op needs
+// in the form the instructions take it, because the walk is bound by SCALAR issue as much as by vector issue (a SIMD
+// issues one scalar instruction per four cycles, like one vector instruction: r03 PMC):
+//   a.x  kind (bits 0-2) | tip-state count (bits 4-5) | push mask (one-hot slot, bits 8-23) | pop slot (bits 24-27)
+//   a.y  byte offset of the op's first P-matrix in the scratch area      a.z  byte offset of its cherry table
+//   a.w  MSA byte offset of tip A's row      b.x  of tip B's row      b.y  of tip C's row
+//   b.z  LDS byte offset of tip A's table entry      b.w  of tip B's (W_CHERRY) or tip C's (W_CTIP)
+struct WalkOp {
+  int4 a, b;
+};
+// timing experiments (results wrong by construction): every table look-up goes to table 0 / every walk matrix comes
+// from one of two hot lines
+#ifdef LH_EXP_CT_TABHIT
+#define LH_CT_TOFF(x) ((x) & 0)
+#else
+#define LH_CT_TOFF(x) (x)
+#endif
+#ifdef LH_EXP_CT_PHIT
+#define LH_CT_POFF(x) ((x) & 128)
+#else
+#define LH_CT_POFF(x) (x)
+#endif
+
+template <bool kN>
+__device__ __forceinline__ void tip_column_at(const char* tiptab_bytes, int entry_off, int st, double (&c)[4]) {
+  const double* t = reinterpret_cast<const double*>(tiptab_bytes + entry_off);
+  const double2* q = reinterpret_cast<const double2*>(t + (kN ? (st & 3) : st) * 4);
+  const double2 q0 = q[0], q1 = q[1];
+  c[0] = q0.x, c[1] = q0.y, c[2] = q1.x, c[3] = q1.y;
+  if constexpr (kN) {
+    if (st == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c[i] = ((t[i] + t[4 + i]) + t[8 + i]) + t[12 + i];
+    }
+  }
+}
+
+template <bool kN>
+__device__ __forceinline__ void table_entry_at(const char* ctab_bytes, int table_off, int sy, int sz, double (&c)[4]) {
+  constexpr int SY = kN ? 5 : 4;
+  // 32-bit byte offset from a wave-uniform base: scalar base + vector offset addressing, no 64-bit vector arithmetic
+  const unsigned off = (unsigned)table_off + (unsigned)(sy * SY + sz) * 32u;
+  const double2* q = reinterpret_cast<const double2*>(ctab_bytes + off);
+  const double2 q0 = q[0], q1 = q[1];
+  c[0] = q0.x, c[1] = q0.y, c[2] = q1.x, c[3] = q1.y;
+}
+
+template <int kDepth, int S, bool kN>
+__device__ __forceinline__ void prune_wave_ct(int site0, int site_end, const uint8_t* __restrict__ msa, int n_w,
+                                              const WalkOp* __restrict__ op_ptr, pmat_ptr pm, const double* tiptab,
+                                              const double* ctab, const double* naive_tab,
+                                              const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
+  unsigned usite[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int site = site0 + 64 * s;
+    usite[s] = (unsigned)(site < site_end ? site : site_end - 1);
+  }
+  double a[S][4];
+  int scal[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    a[s][0] = a[s][1] = a[s][2] = a[s][3] = 1.0;
+    scal[s] = 0;
+  }
+  // Pending siblings: slot 0 in registers, deeper slots in a private array (scratch memory).  After K0c's rewrite
+  // a directly popped cherry never reaches the stack and K0c numbers the slots by depth: the configs[2] trees push
+  // slot 0 ten times and slot 1 twice per tree, nothing deeper (a 500-tip tree: four slots).  One register slot
+  // instead of three is what lets the walk run at six waves per SIMD without spilling its working set.
+  double st0[S][4];
+  double deep[kDepth > 1 ? kDepth - 1 : 1][S][4];
+  const char* tipb = reinterpret_cast<const char*>(tiptab);
+  const char* ctabb = reinterpret_cast<const char*>(ctab);
+
+#ifdef LH_EXP_CT_STAMPS
+  int ct_prev_kind = 0;
+#endif
+  // op k's descriptor and tip states were requested during iteration k - 1
+  WalkOp op = op_ptr[0];
+  int sa[S], sb[S], sc[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) sa[s] = sb[s] = sc[s] = 0;
+  if (n_w > 0) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      sa[s] = msa[(unsigned)op.a.w + usite[s]];
+      sb[s] = msa[(unsigned)op.b.x + usite[s]];
+      sc[s] = msa[(unsigned)op.b.y + usite[s]];
+    }
+  }
+#ifdef LH_EXP_CT_STAMPS
+  unsigned long long kt[5] = {0, 0, 0, 0, 0};
+  unsigned kn[5] = {0, 0, 0, 0, 0};
+  unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
+  for (int k = 0; k < n_w; ++k) {
+    const WalkOp nx = op_ptr[k + 1 < n_w ? k + 1 : k];
+    const int kind = op.a.x & 7;
+#ifdef LH_EXP_CT_STAMPS
+    {
+      const unsigned long long t_now = __builtin_readcyclecounter();
+      if (k > 0) {
+        const int pk = __builtin_amdgcn_readfirstlane(ct_prev_kind);
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+          if (pk == q) kt[q] += t_now - t_prev, kn[q] += 1;
+      }
+      t_prev = t_now;
+    }
+    const int ct_prev_kind_next = kind;
+#endif
+    if (op.a.x & 0xffff00) {  // push the accumulator first: bits 8-23 = slot + 1
+      const int slot = (((unsigned)op.a.x >> 8) & 0xffffu) - 1;
+      if (slot == 0) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          st0[s][0] = a[s][0], st0[s][1] = a[s][1], st0[s][2] = a[s][2], st0[s][3] = a[s][3];
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          deep[slot - 1][s][0] = a[s][0], deep[slot - 1][s][1] = a[s][1];
+          deep[slot - 1][s][2] = a[s][2], deep[slot - 1][s][3] = a[s][3];
+        }
+      }
+    }
+    // every op ends in a = u * v (see prune_wave): u a tip column, a table entry or P_a sibling; v a tip column or P_b a
+    double u[S][4], v[S][4];
+    if (kind == W_TIP_ACC) {
+      const pmat_ptr pb = reinterpret_cast<pmat_ptr>(reinterpret_cast<const char __attribute__((address_space(4)))*>(pm) + (unsigned)LH_CT_POFF(op.a.y));
+#pragma unroll
+      for (int s = 0; s < S; ++s) matvec(pb, a[s], v[s]);
+#pragma unroll
+      for (int s = 0; s < S; ++s) tip_column_at<kN>(tipb, op.b.z, sa[s], u[s]);
+    } else if (kind == W_CTAB_ACC) {
+      const pmat_ptr pb = reinterpret_cast<pmat_ptr>(reinterpret_cast<const char __attribute__((address_space(4)))*>(pm) + (unsigned)LH_CT_POFF(op.a.y));
+#pragma unroll
+      for (int s = 0; s < S; ++s) matvec(pb, a[s], v[s]);
+#pragma unroll
+      for (int s = 0; s < S; ++s) table_entry_at<kN>(ctabb, LH_CT_TOFF(op.a.z), sa[s], sb[s], u[s]);
+    } else if (kind == W_POP) {
+      const pmat_ptr pb = reinterpret_cast<pmat_ptr>(reinterpret_cast<const char __attribute__((address_space(4)))*>(pm) + (unsigned)LH_CT_POFF(op.a.y));
+#pragma unroll
+      for (int s = 0; s < S; ++s) matvec(pb, a[s], v[s]);
+      const pmat_ptr pa = pb + 16;
+      const int slot = (op.a.x >> 24) & 15;
+      if (slot == 0) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) matvec(pa, st0[s], u[s]);
+      } else {
+        double y[S][4];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          y[s][0] = deep[slot - 1][s][0], y[s][1] = deep[slot - 1][s][1];
+          y[s][2] = deep[slot - 1][s][2], y[s][3] = deep[slot - 1][s][3];
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) matvec(pa, y[s], u[s]);
+      }
+    } else if (kind == W_CTIP) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        table_entry_at<kN>(ctabb, LH_CT_TOFF(op.a.z), sa[s], sb[s], u[s]);
+        tip_column_at<kN>(tipb, op.b.w, sc[s], v[s]);
+      }
+    } else {  // W_CHERRY
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        tip_column_at<kN>(tipb, op.b.z, sa[s], u[s]);
+        tip_column_at<kN>(tipb, op.b.w, sb[s], v[s]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      a[s][0] = u[s][0] * v[s][0];
+      a[s][1] = u[s][1] * v[s][1];
+      a[s][2] = u[s][2] * v[s][2];
+      a[s][3] = u[s][3] * v[s][3];
+    }
+#ifdef LH_EXP_CT_STAMPS
+    ct_prev_kind = ct_prev_kind_next;
+#endif
+    op = nx;
+    // the next op's tip states: tip A unconditionally (an op without tips has offset 0), B and C on a count test
+#pragma unroll
+    for (int s = 0; s < S; ++s) sa[s] = msa[(unsigned)op.a.w + usite[s]];
+    if (op.a.x & 0x20) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) sb[s] = msa[(unsigned)op.b.x + usite[s]];
+      if (op.a.x & 0x10) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) sc[s] = msa[(unsigned)op.b.y + usite[s]];
+      }
+    }
+    // per-site, per-rate 2^256 rescaling, as in prune_wave
+    unsigned hw[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      hw[s] = max(max((unsigned)__double2hiint(a[s][0]), (unsigned)__double2hiint(a[s][1])),
+                  max((unsigned)__double2hiint(a[s][2]), (unsigned)__double2hiint(a[s][3])));
+    unsigned hmin = hw[0];
+#pragma unroll
+    for (int s = 1; s < S; ++s) hmin = min(hmin, hw[s]);
+    if (__builtin_expect(__ballot(hmin < 0x2FF00000u) != 0, 0)) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        if (hw[s] < 0x2FF00000u) {
+          a[s][0] *= kScaleFactor;
+          a[s][1] *= kScaleFactor;
+          a[s][2] *= kScaleFactor;
+          a[s][3] *= kScaleFactor;
+          ++scal[s];
+        }
+      }
+    }
+  }
+#ifdef LH_EXP_CT_STAMPS
+  if (S == 2 && blockIdx.z >= 20000 && blockIdx.z < 20128 && (threadIdx.x & 63) == 0) {
+    const int w = (blockIdx.z - 20000) * 8 + (threadIdx.x >> 6);
+    for (int q = 0; q < 5; ++q) {
+      ct_stamps[w][q] = kt[q];
+      ct_stamps[w][5 + q] = kn[q];
+    }
+  }
+#endif
+  // epilogue: close the naive branch for each possible naive state (as prune_wave)
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const double w0 = p4[0] * a[s][0], w1 = p4[1] * a[s][1], w2 = p4[2] * a[s][2], w3 = p4[3] * a[s][3];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      double tv[4];
+      if (b < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tv[i] = naive_tab[b * 4 + i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tv[i] = ((naive_tab[i] + naive_tab[4 + i]) + naive_tab[8 + i]) + naive_tab[12 + i];
+      }
+      lik[s][b] = fma(w3, tv[3], fma(w2, tv[2], fma(w1, tv[1], w0 * tv[0])));
+    }
+    scl[s] = scal[s];
+  }
+}
+
 #undef LH_SLOT_COPY
 #undef LH_PUSH_IF
 #undef LH_POP_CASE
@@ -373,45 +643,51 @@ __device__ __forceinline__ void prune_wave(int site0, int site_end, const uint8_
 
 }  // namespace
 
-// Block = n2 two-site waves followed by n1 one-site waves per rate; the tile's sites are
-// blockIdx.x * tile .. +tile-1 (clipped to L).
-//
-// kFused: the workgroup carries ALL rate categories of its sample (waves [r * wpr, (r + 1) * wpr) walk
-// rate r with their own LDS tip table) and, when the walks are done, mixes them itself:
-// site_lik[n][1][5][L] then holds the rate mixture (equal weights, scalers aligned to the smallest, the
-// arithmetic K2a would do) and K2a runs with a single "rate".  A quarter of the output traffic, and K2a's
-// bandwidth-bound assembly shrinks to a quarter.  Used when R * wpr <= 8 waves and the R tip tables fit.
-template <int kDepth, bool kTwo, bool kN, bool kFused, bool kSeg = false>
+// The older form of the workgroup, kept for what the cherry-table form does not cover: large trees (kSeg: tip table
+// built a schedule segment at a time) and deep stacks (one site per lane).  One workgroup per (site tile, rate,
+// sample); block = n2 two-site waves followed by n1 one-site waves; the tile's sites are blockIdx.x * tile ..
+// +tile-1 (clipped to L).  It walks the schedule as lh_schedule_tree wrote it (K0c has checked it: hdr.w).
+template <int kDepth, bool kTwo, bool kN, bool kSeg = false>
 __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, const uint8_t* __restrict__ msa, int L,
                                            int T, int n_ops, const int32_t* __restrict__ ops,
+                                           const int4* __restrict__ hdr,
                                            const double* __restrict__ brlen, const double* __restrict__ rates,
-                                           const double* __restrict__ eig, double* pmat_w,
+                                           const double* __restrict__ eig, double* pmat_w, size_t rate_stride,
                                            const double* __restrict__ pi,
                                            double* __restrict__ site_lik, int32_t* __restrict__ site_scal) {
   extern __shared__ double2 smem2[];
   LH_K1_PHASE(0)
   const int tid = threadIdx.x;
-  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rate = kFused ? wave_all / wpr : (int)blockIdx.y;
-  const int wave = kFused ? wave_all - rate * wpr : wave_all;  // within the rate
-  const int nthr = kFused ? wpr * 64 : (int)blockDim.x;       // threads working on this rate
-  const int rtid = kFused ? tid - rate * nthr : tid;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rate = (int)blockIdx.y;
+  const int nthr = (int)blockDim.x;
+  const int rtid = tid;
   const int sample = blockIdx.z;
+  const int lane = tid & 63;
+  const int tile0 = blockIdx.x * tile;
+  const int site_end = min(tile0 + tile, L);
+  double* lik_out = site_lik + (((size_t)sample * R + rate) * 5) * (size_t)L;
+  int32_t* scal_out = site_scal + ((size_t)sample * R + rate) * (size_t)L;
+  if (hdr[sample].w != 0) {  // K0c rejected the schedule (uniform per workgroup): no number may look like a result
+    for (int site = tile0 + tid; site < site_end; site += nthr) {
+      for (int b = 0; b < 5; ++b) lik_out[(size_t)b * L + site] = __builtin_nan("");
+      scal_out[site] = 0;
+    }
+    return;
+  }
   // scratch area of one (sample, rate): the schedule's P-matrices
-  const size_t pm_stride = (size_t)(T - 2) * 32;
-  const size_t pm_off = ((size_t)sample * R + rate) * pm_stride;
-  // LDS tip table [T][4][4] (per rate when fused); large trees (kSeg): the segment slots [2 kSegOps][4][4]
-  // followed by the naive tip's entry
-  double* tiptab = reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);
+  const size_t pm_off = ((size_t)sample * R + rate) * rate_stride;
+  // LDS tip table [T][4][4]; large trees (kSeg): the segment slots [2 kSegOps][4][4] followed by the naive tip's entry
+  double* tiptab = reinterpret_cast<double*>(smem2);
   const double* naive_tab = kSeg ? tiptab + 2 * kSegOps * 16 : tiptab;
   const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
 
-  // Prologue (formerly a kernel of its own): the P-matrices of this (sample, rate).
+  // Prologue: the P-matrices of this (sample, rate).
   //   P = I + U expm1(lambda t r) U^-1   (pll_update_prob_matrices [3P])
-  // One thread per matrix.  The first half of the rate's threads takes the schedule's ops: op k's
+  // One thread per matrix.  The first half of the threads takes the schedule's ops: op k's
   // accumulator-child matrix goes to pmat[k][0], its popped-child matrix to pmat[k][1] -- global memory,
   // because the walk below wants them as SCALAR operands and scalar loads only read memory; the lines
-  // are written and, a barrier later, read back on the same CU, so they are served by its L2.  The
+  // are written and, a barrier later, read back on the same CU.  The
   // second half takes the tip branches: a tip child needs no mat-vec, P * onehot(state) is a column of
   // P, and those columns go straight into the LDS table tiptab[tip][state][4] (states A,C,G,T).
   {
@@ -420,46 +696,6 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
     const double* __restrict__ bl = brlen + (size_t)sample * (2 * (size_t)T - 2);
     double* pw = pmat_w + pm_off;
     double P[4][4];
-    if constexpr (kFused) {
-      // Packed form: the T - 3 inner-branch matrices are numbered by the schedule (lh_schedule_tree leaves each
-      // op's running count in its descriptor); every op thread notes where its one or two matrices go in a
-      // list in LDS (the same for every rate: one copy per workgroup, behind the tip tables), and after a
-      // barrier thread t of a rate takes items t, t + nthr, ... of [inner matrices | tips]: no lane idles on a
-      // cherry, none computes two matrices while its neighbours compute one.
-      uint16_t* mat_list = reinterpret_cast<uint16_t*>(reinterpret_cast<double*>(smem2) + (size_t)R * T * 16);
-      if (rate == 0) {
-        for (int k = rtid; k < n_ops; k += nthr) {
-          const int4 op = op_ptr[k];
-          const int kind = op.x & 15, rank = op.x >> OP_RANK_SHIFT;
-          if (kind == OP_CHERRY) continue;
-          mat_list[rank] = (uint16_t)(2 * k);          // the accumulator child's matrix: node op.z, slot [k][0]
-          if (kind == OP_POP_ACC) mat_list[rank + 1] = (uint16_t)(2 * k + 1);  // the popped child's: node op.y, slot [k][1]
-        }
-      }
-      __syncthreads();
-      LH_K1_PHASE(1)
-      const int n_inner = T - 3;
-      for (int it = rtid; it < n_inner + T; it += nthr) {
-        if (it < n_inner) {
-          const int code = mat_list[it], k = code >> 1;
-          const int4 op = op_ptr[k];
-          compute_pmatrix(e, bl[(code & 1) ? op.y : op.z] * rt, P);
-          double* o = pw + (size_t)k * 32 + (code & 1) * 16;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[i * 4 + q] = P[i][q];
-        } else {
-          const int j = it - n_inner;
-          compute_pmatrix(e, bl[j] * rt, P);
-          double* o = tiptab + j * 16;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
-        }
-      }
-    } else {
     const int half = nthr >= 128 ? (nthr / 128) * 64 : 0;  // whole waves on either side
     const bool do_ops = half == 0 || rtid < half;
     const bool do_tips = half == 0 || rtid >= half;
@@ -496,7 +732,6 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
           for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
       }
     }
-    }
   }
   SegCtx seg{eig + (size_t)sample * 36, brlen + (size_t)sample * (2 * (size_t)T - 2),
              rates[(size_t)sample * R + rate], tiptab, rtid, nthr};
@@ -511,9 +746,6 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
 
   // P-matrices in schedule order (addresses depend on the op number only), readable from here on
   const pmat_ptr pm = pmat_after_barrier(pmat_w + pm_off);
-  const int lane = tid & 63;
-  const int tile0 = blockIdx.x * tile;
-  const int site_end = min(tile0 + tile, L);
   const double* __restrict__ p4 = pi + (size_t)sample * 4;
   // results of this wave's walk: five naive-state likelihoods and a scaler count per site
   double lik[2][5];
@@ -536,6 +768,257 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
     for (int b = 0; b < 5; ++b) lik[0][b] = lik1[0][b];
     scl[0] = scl1[0];
   }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int site = site0 + 64 * s;
+    if (s < n_own && site < site_end) {
+#pragma unroll
+      for (int b = 0; b < 5; ++b) lik_out[(size_t)b * L + site] = lik[s][b];
+      scal_out[site] = scl[s];
+    }
+  }
+}
+
+// x = P * a with P row-major in vector registers (the prologue's table building)
+__device__ __forceinline__ void matvec_v(const double (&p)[16], const double (&a)[4], double (&x)[4]) {
+  x[0] = fma(p[3], a[3], fma(p[2], a[2], fma(p[1], a[1], p[0] * a[0])));
+  x[1] = fma(p[7], a[3], fma(p[6], a[2], fma(p[5], a[1], p[4] * a[0])));
+  x[2] = fma(p[11], a[3], fma(p[10], a[2], fma(p[9], a[1], p[8] * a[0])));
+  x[3] = fma(p[15], a[3], fma(p[14], a[2], fma(p[13], a[1], p[12] * a[0])));
+}
+
+// K0c: one thread per sample checks the schedule (kinds, node ranges, stack discipline: everything K1 indexes with)
+// and writes the walk descriptors (WalkOp above; lh_device.h).  A malformed schedule gets an empty walk, hdr.w = 1 (K1
+// then leaves NaN) and sets *err_flag, which lh_family_status reports: device-resident schedules are not trusted.
+// L = K1's site dimension (MSA row stride); E = entries per cherry table (16, or 25 when tips can be N).
+__global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int max_depth, int tabs_stride, int L, int E,
+                                                            const int32_t* __restrict__ ops, int4* __restrict__ wops,
+                                                            int32_t* __restrict__ mats, int4* __restrict__ tabs,
+                                                            int4* __restrict__ hdr, int32_t* err_flag) {
+  const int smp = blockIdx.x * 64 + threadIdx.x;
+  if (smp >= n) return;
+  const int n_ops = T - 2, nodes = 2 * T - 2;
+  const int4* __restrict__ o = reinterpret_cast<const int4*>(ops) + (size_t)smp * n_ops;
+  int4* wo = wops + (size_t)smp * n_ops * 2;
+  int32_t* ml = mats + (size_t)smp * n_ops;
+  int4* tl = tabs + (size_t)smp * tabs_stride;
+  int depth = 0, n_w = 0, n_mat = 0, n_tab = 0;
+  int bdepth = 0;  // stack depth of the schedule as written (depth: of the rewritten walk, which pushes less)
+  bool bad = false;
+  auto tip_ok = [&](int v) { return v >= 1 && v < T; };
+  auto inner_ok = [&](int v) { return v >= T && v < nodes; };
+  auto row = [&](int tip) { return (tip - 1) * L; };  // MSA byte offset of a tip's row
+  int k = 0;
+  int4 op = o[0];
+  while (k < n_ops && !bad) {
+    const bool has_next = k + 1 < n_ops;
+    const int4 nx = has_next ? o[k + 1] : make_int4(15, 0, 0, 0);
+    const int kind = op.x & 15;
+    const bool push = (op.x & OP_PUSH_FLAG) != 0;
+    if (op.x < 0 || (op.x & 0xe0)) bad = true;
+    int4 wa = make_int4(0, 0, 0, 0), wb = make_int4(0, 0, 0, 0);
+    int step = 1;
+    if (kind == OP_CHERRY) {
+      if (!tip_ok(op.y) || !tip_ok(op.z)) bad = true;
+      if (push && (op.w != bdepth || bdepth >= max_depth)) bad = true;
+      if (!push && k != 0) bad = true;  // a cherry that does not push would overwrite a live accumulator
+      const int nk = nx.x & 15;
+      const bool nx_plain = nx.x >= 0 && (nx.x & 0xf0) == 0;
+      const int pushbits = (push && !bad) ? ((depth + 1) << 8) : 0;  // slots numbered by the depth the rewritten walk has here
+      if (bad) {
+      } else if (has_next && nk == OP_TIP_ACC && nx_plain && tip_ok(nx.y) && inner_ok(nx.z) && n_tab < tabs_stride) {
+        wa = make_int4(W_CTIP | 0x30 | pushbits, 0, n_tab * E * 32, row(op.y));
+        wb = make_int4(row(op.z), row(nx.y), 0, nx.y * 128);
+        tl[n_tab++] = make_int4(op.y, op.z, nx.z, 0);
+        if (push) ++depth, ++bdepth;
+        step = 2;
+      } else if (has_next && nk == OP_POP_ACC && push && nx_plain && nx.w == op.w && inner_ok(nx.y) && inner_ok(nx.z) &&
+                 n_tab < tabs_stride && n_mat < n_ops) {
+        // the cherry is the whole second subtree: the first one stays in the accumulator, nothing is pushed
+        wa = make_int4(W_CTAB_ACC | 0x20, n_mat * 128, n_tab * E * 32, row(op.y));
+        wb = make_int4(row(op.z), 0, 0, 0);
+        ml[n_mat++] = nx.y;
+        tl[n_tab++] = make_int4(op.y, op.z, nx.z, 0);
+        step = 2;
+      } else {
+        wa = make_int4(W_CHERRY | 0x20 | pushbits, 0, 0, row(op.y));
+        wb = make_int4(row(op.z), 0, op.y * 128, op.z * 128);
+        if (push) ++depth, ++bdepth;
+      }
+    } else if (kind == OP_TIP_ACC) {
+      if (push || k == 0 || !tip_ok(op.y) || !inner_ok(op.z) || n_mat >= n_ops) {
+        bad = true;
+      } else {
+        wa = make_int4(W_TIP_ACC, n_mat * 128, 0, row(op.y));
+        wb = make_int4(0, 0, op.y * 128, 0);
+        ml[n_mat++] = op.z;
+      }
+    } else if (kind == OP_POP_ACC) {
+      if (push || bdepth < 1 || depth < 1 || op.w != bdepth - 1 || !inner_ok(op.y) || !inner_ok(op.z) || n_mat + 1 >= n_ops) {
+        bad = true;
+      } else {
+        wa = make_int4(W_POP | ((depth - 1) << 24), n_mat * 128, 0, 0);
+        ml[n_mat] = op.z;      // the child whose CLV is in the accumulator
+        ml[n_mat + 1] = op.y;  // the popped child
+        n_mat += 2;
+        --depth, --bdepth;
+      }
+    } else {
+      bad = true;
+    }
+    if (!bad) {
+      wo[2 * n_w] = wa;
+      wo[2 * n_w + 1] = wb;
+      ++n_w;
+    }
+    k += step;
+    if (k < n_ops) op = step == 2 ? o[k] : nx;
+  }
+  if (depth != 0 || bdepth != 0 || n_mat + n_tab > T - 3) bad = true;  // (the scratch area holds T - 3 matrices per rate)
+  if (bad) {
+    hdr[smp] = make_int4(0, 0, 0, 1);
+    atomicOr(err_flag, 1);
+  } else {
+    hdr[smp] = make_int4(n_w, n_mat, n_tab, 0);
+  }
+}
+
+// The workgroup of the cherry-table form.  Block layout as prune_body (n2 two-site waves + n1 one-site waves per rate;
+// kFused: all R rates of the sample in one workgroup, mixed at the end).  scratch: this (sample, rate)'s region of
+// rate_stride doubles: [n_mat + n_tab][16] P-matrices | [n_tab][E][4] tables.
+template <int kDepth, bool kN, bool kFused>
+__device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, const uint8_t* __restrict__ msa, int L,
+                                              int T, const int4* __restrict__ wops, const int32_t* __restrict__ mats,
+                                              const int4* __restrict__ tabs, int tabs_stride,
+                                              const int4* __restrict__ hdr, const double* __restrict__ brlen,
+                                              const double* __restrict__ rates, const double* __restrict__ eig,
+                                              double* pmat_w, size_t rate_stride, const double* __restrict__ pi,
+                                              double* __restrict__ site_lik, int32_t* __restrict__ site_scal) {
+  extern __shared__ double2 smem2[];
+  constexpr int SY = kN ? 5 : 4, E = SY * SY;
+  const int tid = threadIdx.x;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rate = kFused ? wave_all / wpr : (int)blockIdx.y;
+  const int wave = kFused ? wave_all - rate * wpr : wave_all;
+  const int nthr = kFused ? wpr * 64 : (int)blockDim.x;
+  const int rtid = kFused ? tid - rate * nthr : tid;
+  const int sample = blockIdx.z;
+  const int n_ops = T - 2;
+  const int4 h = hdr[sample];
+  const int n_w = __builtin_amdgcn_readfirstlane(h.x), n_mat = __builtin_amdgcn_readfirstlane(h.y),
+            n_tab = __builtin_amdgcn_readfirstlane(h.z);
+  const bool malformed = h.w != 0;
+  double* pw = pmat_w + ((size_t)sample * R + rate) * rate_stride;
+  double* ctab = pw + (size_t)(T - 3 > 0 ? T - 3 : 0) * 16;
+  double* tiptab = reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);
+  const double* naive_tab = tiptab;
+  const WalkOp* __restrict__ op_ptr = reinterpret_cast<const WalkOp*>(wops) + (size_t)sample * n_ops;
+  const int4* __restrict__ tl = tabs + (size_t)sample * tabs_stride;
+  LH_CT_PHASE(0)
+
+  // Prologue, first half: the P-matrices of this (sample, rate), one thread per matrix: the walk's inner-branch
+  // matrices in walk order and the cherry branches' (for the tables) to the scratch area, the tip branches' into
+  // the LDS tip table (column by column, as the walk gathers them).
+  {
+    const double* __restrict__ e = eig + (size_t)sample * 36;
+    const double rt = rates[(size_t)sample * R + rate];
+    const double* __restrict__ bl = brlen + (size_t)sample * (2 * (size_t)T - 2);
+    const int32_t* __restrict__ ml = mats + (size_t)sample * n_ops;
+    double P[4][4];
+    const int n_inner = n_mat + n_tab;
+    for (int it = rtid; it < n_inner + T; it += nthr) {
+      if (it < n_inner) {
+        const int node = it < n_mat ? ml[it] : tl[it - n_mat].z;
+        compute_pmatrix(e, bl[node] * rt, P);
+        double* o = pw + (size_t)it * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[i * 4 + q] = P[i][q];
+      } else {
+        const int j = it - n_inner;
+        compute_pmatrix(e, bl[j] * rt, P);
+        double* o = tiptab + j * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
+      }
+    }
+  }
+  LH_CT_PHASE(1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __threadfence_block();
+  __syncthreads();
+  LH_CT_PHASE(2)
+  // Second half: the cherry tables, one thread per (table, state of the first tip): P_c (tipcol_y o tipcol_z) for
+  // every state of the second tip -- the very operations the unfused walk performs per lane, done once per state pair.
+#ifdef LH_EXP_CT_NOPHASEC  // timing experiment: no tables are built (results wrong)
+  for (int it = rtid; it < 0; it += nthr) {
+#else
+  for (int it = rtid; it < n_tab * SY; it += nthr) {
+#endif
+    const int c = it / SY, sy = it - c * SY;
+    const int4 t = tl[c];
+    double pc[16];
+    {
+      const double2* q = reinterpret_cast<const double2*>(pw + (size_t)(n_mat + c) * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double2 v = q[j];
+        pc[2 * j] = v.x;
+        pc[2 * j + 1] = v.y;
+      }
+    }
+    double py[4];
+    tip_column<kN>(tiptab, t.x, sy, py);
+    double2* o = reinterpret_cast<double2*>(ctab) + ((size_t)c * E + (size_t)sy * SY) * 2;
+#pragma unroll
+    for (int sz = 0; sz < SY; ++sz) {
+      double pz[4], pr[4], x[4];
+      tip_column<kN>(tiptab, t.y, sz, pz);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pr[i] = py[i] * pz[i];
+      matvec_v(pc, pr, x);
+      o[2 * sz] = make_double2(x[0], x[1]);
+      o[2 * sz + 1] = make_double2(x[2], x[3]);
+    }
+  }
+  LH_CT_PHASE(3)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __threadfence_block();
+  __syncthreads();
+  LH_CT_PHASE(4)
+
+  const pmat_ptr pm = pmat_after_barrier(pw);
+  const int lane = tid & 63;
+  const int tile0 = blockIdx.x * tile;
+  const int site_end = min(tile0 + tile, L);
+  const double* __restrict__ p4 = pi + (size_t)sample * 4;
+  double lik[2][5];
+  int scl[2] = {0, 0};
+  int site0, n_own;
+  const bool two_sites = wave < n2;
+  if (two_sites) {
+    site0 = tile0 + wave * 128 + lane;
+    n_own = 2;
+    prune_wave_ct<kDepth, 2, kN>(site0, site_end, msa, n_w, op_ptr, pm, tiptab, ctab, naive_tab, p4, lik, scl);
+  } else {
+    site0 = tile0 + n2 * 128 + (wave - n2) * 64 + lane;
+    n_own = 1;
+    double lik1[1][5];
+    int scl1[1];
+    prune_wave_ct<kDepth, 1, kN>(site0, site_end, msa, n_w, op_ptr, pm, tiptab, ctab, naive_tab, p4, lik1, scl1);
+#pragma unroll
+    for (int b = 0; b < 5; ++b) lik[0][b] = lik1[0][b];
+    scl[0] = scl1[0];
+  }
+  if (malformed) {  // K0c rejected the schedule: no number may look like a result
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int b = 0; b < 5; ++b) lik[s][b] = __builtin_nan("");
+  }
 
   if constexpr (!kFused) {
     double* lik_out = site_lik + (((size_t)sample * R + rate) * 5) * (size_t)L;
@@ -550,13 +1033,13 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
       }
     }
   } else {
-    // exchange through LDS (over the tip tables, which no wave needs any more), then mix the rates
-    const int pad = n2 * 128 + (wpr - n2) * 64;  // sites a rate's waves cover
-    LH_K1_PHASE(4)
+    // exchange through LDS (over the tip tables, which no wave needs any more), then mix the rates (as prune_body)
+    const int pad = n2 * 128 + (wpr - n2) * 64;
+    LH_CT_PHASE(5)
     __syncthreads();
-    LH_K1_PHASE(5)
-    double* X = reinterpret_cast<double*>(smem2);                 // [R][5][pad]
-    int* SC = reinterpret_cast<int*>(X + (size_t)R * 5 * pad);    // [R][pad]
+    LH_CT_PHASE(6)
+    double* X = reinterpret_cast<double*>(smem2);
+    int* SC = reinterpret_cast<int*>(X + (size_t)R * 5 * pad);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int idx = site0 + 64 * s - tile0;
@@ -567,8 +1050,6 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
       }
     }
     __syncthreads();
-    // PhyloHMM::FillXmsaEmission's rate mixture (src/PhyloHMM.cpp:226-237): equal weights, scalers aligned
-    // to the smallest one -- the same operations in the same order as K2a performs on unmixed input
     const int n_tile = site_end - tile0;
     const double w = 1.0 / R;
     double* lik_out = site_lik + ((size_t)sample * 5) * (size_t)L;
@@ -587,60 +1068,78 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
       lik_out[(size_t)b * L + tile0 + p] = acc;
       if (b == 0) scal_out[tile0 + p] = smin;
     }
-    LH_K1_PHASE(6)
+    LH_CT_PHASE(7)
   }
 }
+
+#define LH_PRUNE_CT_PARAMS                                                                                          \
+  int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, const int4 *__restrict__ wops,   \
+      const int32_t *__restrict__ mats, const int4 *__restrict__ tabs, int tabs_stride,                             \
+      const int4 *__restrict__ hdr, const double *__restrict__ brlen, const double *__restrict__ rates,            \
+      const double *__restrict__ eig, double *pmat_w, size_t rate_stride, const double *__restrict__ pi,           \
+      double *__restrict__ site_lik, int32_t *__restrict__ site_scal
+#define LH_PRUNE_CT_ARGS \
+  n2, tile, R, wpr, msa, L, T, wops, mats, tabs, tabs_stride, hdr, brlen, rates, eig, pmat_w, rate_stride, pi, site_lik, site_scal
+#define LH_PRUNE_CT_KERNEL(NAME, WAVES)                                                              \
+  template <int kDepth, bool kN, bool kFused>                                                        \
+  __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) NAME(    \
+      LH_PRUNE_CT_PARAMS) {                                                                          \
+    prune_body_ct<kDepth, kN, kFused>(LH_PRUNE_CT_ARGS);                                             \
+  }
+LH_PRUNE_CT_KERNEL(prune_kernel_ct6, 6)
+LH_PRUNE_CT_KERNEL(prune_kernel_ct5, 5)
+LH_PRUNE_CT_KERNEL(prune_kernel_ct4, 4)
+#undef LH_PRUNE_CT_KERNEL
 
 // pmat_w: the scratch area (see prune_body); written in the prologue, read back after the barrier.
 #define LH_PRUNE_PARAMS                                                                                     \
   int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, int n_ops,               \
-      const int32_t *__restrict__ ops,                                                                      \
+      const int32_t *__restrict__ ops, const int4 *__restrict__ hdr,                                        \
       const double *__restrict__ brlen, const double *__restrict__ rates, const double *__restrict__ eig,  \
-      double *pmat_w, const double *__restrict__ pi,                                                       \
+      double *pmat_w, size_t rate_stride, const double *__restrict__ pi,                                   \
       double *__restrict__ site_lik, int32_t *__restrict__ site_scal
-#define LH_PRUNE_ARGS n2, tile, R, wpr, msa, L, T, n_ops, ops, brlen, rates, eig, pmat_w, pi, site_lik, site_scal
-
-// Shallow stacks (depth <= 4, any tree up to a few hundred tips): two sites per lane.  The walk needs
-// ~100 VGPRs; resident waves matter more to it than a few spilled registers, as long as the LDS tip
-// tables of that many workgroups fit a CU.  Three register budgets are therefore built -- 6 waves per
-// SIMD (80 VGPRs), 5 (96) and 4 (128, no spills) -- and the launcher takes the tightest one whose
-// occupancy the tip tables allow: configs[2] (13 KB of LDS per two-wave workgroup) runs 6 waves per SIMD,
-// 5 % faster than 5 and 19 % faster than 4; a 500-tip tree (64 KB) could not use them and keeps its registers.
-#define LH_PRUNE_KERNEL(NAME, WAVES)                                                                 \
-  template <int kDepth, bool kN, bool kFused>                                                        \
-  __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) NAME(    \
-      LH_PRUNE_PARAMS) {                                                                             \
-    prune_body<kDepth, true, kN, kFused>(LH_PRUNE_ARGS);                                             \
-  }
-LH_PRUNE_KERNEL(prune_kernel_w6, 6)
-LH_PRUNE_KERNEL(prune_kernel_w5, 5)
-LH_PRUNE_KERNEL(prune_kernel_w4, 4)
-#undef LH_PRUNE_KERNEL
+#define LH_PRUNE_ARGS n2, tile, R, wpr, msa, L, T, n_ops, ops, hdr, brlen, rates, eig, pmat_w, rate_stride, pi, site_lik, site_scal
 
 // Large trees: tip table built a schedule segment at a time (see SegCtx); register budgets for five and four
 // waves per SIMD.
 template <int kDepth, bool kN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) prune_kernel_seg(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, true, kN, false, true>(LH_PRUNE_ARGS);
+  prune_body<kDepth, true, kN, true>(LH_PRUNE_ARGS);
 }
 template <int kDepth, bool kN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) prune_kernel_seg4(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, true, kN, false, true>(LH_PRUNE_ARGS);
+  prune_body<kDepth, true, kN, true>(LH_PRUNE_ARGS);
 }
 
 // Deep stacks leave no room for two sites per lane.
 template <int kDepth>
 __global__ void __launch_bounds__(512) prune_kernel_deep(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, false, true, false>(LH_PRUNE_ARGS);
+  prune_body<kDepth, false, true>(LH_PRUNE_ARGS);
+}
+
+PruneWsSizes prune_ws_sizes(int T, bool mixed_n) {
+  PruneWsSizes z;
+  z.tabs_per_sample = (size_t)std::max((T - 1) / 2, 1);
+  const size_t e = mixed_n ? 25 : 16;
+  // the cherry-table form, and never less than the older kernels' [T-2][2][16]
+  z.scratch_doubles_per_rate = std::max((size_t)std::max(T - 3, 0) * 16 + z.tabs_per_sample * e * 4, (size_t)std::max(T - 2, 1) * 32);
+  return z;
 }
 
 // Returns the number of rate planes it left in site_lik / site_scal: R, or 1 when the workgroups mixed
 // the rate categories themselves (the count K2a must then be run with).
 int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
-                 const double* brlen, const double* rates, const double* eig, double* pmat, const double* pi,
+                 const double* brlen, const double* rates, const double* eig, const PruneWs& ws, const double* pi,
                  double* site_lik, int32_t* site_scal, hipStream_t stream, bool allow_fused) {
   const int L = fam.n_prune;  // distinct alignment columns; identical ones are pruned once
+  const PruneWsSizes sizes = prune_ws_sizes(T, fam.msa_mixed_n != 0);
+  // K0c: every schedule is checked on the device (and rewritten into walk ops) before K1 indexes anything with it
+  hipLaunchKernelGGL(schedule_check_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, T, max_depth,
+                     (int)sizes.tabs_per_sample, L, fam.msa_mixed_n ? 25 : 16, ops, ws.wops, ws.mats, ws.tabs, ws.hdr,
+                     ws.err_flag);
   if (L == 0) return R;       // nothing but all-N padding (K2a reads no plane at all)
+  double* pmat = ws.scratch;
+  const size_t rate_stride = sizes.scratch_doubles_per_rate;
   const bool two = max_depth <= 4;
   // tile: up to 1024 sites as two-site waves plus at most one one-site wave for a remainder below 64
   // (deep variant: up to 8 one-site waves = 512 sites); tiles rebalanced so that they are equally full.
@@ -669,8 +1168,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   // all rates of a sample in one workgroup, mixed there: at most 8 waves, and R tip tables (later reused
   // as the exchange area [R][5][pad] doubles + [R][pad] ints) within a third of a CU's LDS
   const size_t pad = (size_t)n2 * 128 + (size_t)n1 * 64;
-  const size_t fused_lds = std::max((size_t)R * tip_bytes + (((size_t)T * sizeof(uint16_t) + 15) & ~(size_t)15),
-                                    (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
+  const size_t fused_lds = std::max((size_t)R * tip_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
   static const bool seg_env = getenv("LH_K1_SEGMENTS") != nullptr;  // test hook: segments on small trees too
   static const int seg_waves = getenv("LH_K1_SEG_WAVES") ? atoi(getenv("LH_K1_SEG_WAVES")) : 4;  // measured: 4 (128 VGPRs, few spills) beats 5 by 9 %
   static const bool no_fuse = getenv("LH_K1_NO_FUSE") != nullptr;  // test hook: one workgroup per (sample, rate)
@@ -686,20 +1184,33 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
     if (lds > 64 * 1024)                                                                                      \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                    \
-    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, R, wpr, fam.msa, L, T, n_ops, ops, brlen, rates, \
-                       eig, pmat, pi, site_lik, site_scal);                                                   \
+    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, R, wpr, fam.msa, L, T, n_ops, ops, ws.hdr, brlen, rates, \
+                       eig, pmat, rate_stride, pi, site_lik, site_scal);                                      \
+  }
+#define LH_LAUNCH_CT(K)                                                                                       \
+  {                                                                                                           \
+    if (lds > 64 * 1024)                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                    \
+    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, R, wpr, fam.msa, L, T, ws.wops, ws.mats, ws.tabs, \
+                       (int)sizes.tabs_per_sample, ws.hdr, brlen, rates, eig, pmat, rate_stride, pi, site_lik,  \
+                       site_scal);                                                                            \
   }
   // waves per SIMD that the LDS of the resident workgroups allows (160 KB per CU, 4 SIMDs)
   const int lds_waves = lds == 0 ? 8 : (int)((160 * 1024 / lds) * wg_waves / 4);
-  // alignments that never mix N with bases take the instantiation without N handling in the look-ups
+  // the cherry-table form (two sites per lane, whole tip table in LDS); three register budgets, the launcher takes
+  // the tightest one whose occupancy the tip tables allow
+#ifndef LH_EXP_CT_BUDGET
+#define LH_EXP_CT_BUDGET 6
+#endif
 #define LH_LAUNCH_BUDGET(D, N, F)                                                 \
   {                                                                               \
-    if (lds_waves >= 6 && D == 3) /* a fourth slot spills too much at 80 VGPRs */ \
-      LH_LAUNCH_K((prune_kernel_w6<D, N, F>))                                     \
-    else if (lds_waves >= 5)                                                      \
-      LH_LAUNCH_K((prune_kernel_w5<D, N, F>))                                     \
+    if (lds_waves >= 6 && D == 3 && LH_EXP_CT_BUDGET >= 6) /* a fourth slot spills too much at 80 VGPRs */ \
+      LH_LAUNCH_CT((prune_kernel_ct6<D, N, F>))                                   \
+    else if (lds_waves >= 5 && LH_EXP_CT_BUDGET >= 5)                             \
+      LH_LAUNCH_CT((prune_kernel_ct5<D, N, F>))                                   \
     else                                                                          \
-      LH_LAUNCH_K((prune_kernel_w4<D, N, F>))                                     \
+      LH_LAUNCH_CT((prune_kernel_ct4<D, N, F>))                                   \
   }
 #define LH_LAUNCH_SHALLOW(D, N)             \
   {                                         \
@@ -727,6 +1238,31 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
 #undef LH_LAUNCH_SHALLOW
 #undef LH_LAUNCH_BUDGET
 #undef LH_LAUNCH_K
+#undef LH_LAUNCH_CT
+#ifdef LH_EXP_CT_STAMPS
+  {
+    static int calls = 0;
+    if (++calls == 3) {
+      (void)hipDeviceSynchronize();
+      static unsigned long long h[1024][10];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(ct_stamps), sizeof(h));
+      const char* names[5] = {"cherry", "tip_acc", "pop", "ctip", "ctab_acc"};
+      for (int q = 0; q < 5; ++q) {
+        double t = 0, c = 0;
+        for (int w = 0; w < 1024; ++w) t += (double)h[w][q], c += (double)h[w][5 + q];
+        fprintf(stderr, "[CT stamps] %-9s %.1f ops per wave, %.0f cycles per op\n", names[q], c / 1024, t / (c > 0 ? c : 1));
+      }
+      static unsigned long long ph[128][8];
+      (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(ct_phase), sizeof(ph));
+      double acc[8] = {0};
+      for (int b = 0; b < 128; ++b)
+        for (int i = 1; i < 8; ++i) acc[i] += (double)(ph[b][i] - ph[b][0]);
+      fprintf(stderr, "[CT phases, wave 0 of 128 workgroups, cycles since its start] matrices computed %.0f; drained + barrier %.0f; tables "
+              "computed %.0f; drained + barrier %.0f; walk done %.0f; all waves done %.0f; mixed and written %.0f\n", acc[1] / 128,
+              acc[2] / 128, acc[3] / 128, acc[4] / 128, acc[5] / 128, acc[6] / 128, acc[7] / 128);
+    }
+  }
+#endif
 #ifdef LH_EXP_K1_STAMPS
   {
     static int calls = 0;

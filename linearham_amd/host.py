@@ -11,7 +11,9 @@ _LIB = None
 
 
 def host_library_path():
-    return os.path.join(_HERE, "lib", "liblinearham_host.so")
+    # LH_LIB_DIR: timing experiments load a variant build from its own directory (tools/build_variant.sh) instead of
+    # overwriting the product library in place
+    return os.path.join(os.environ.get("LH_LIB_DIR") or os.path.join(_HERE, "lib"), "liblinearham_host.so")
 
 
 def load_host():
