@@ -357,7 +357,7 @@ int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_
 size_t k1_bytes_per_sample(const lh_family* f, int T, int R) {
   const lh::PruneWsSizes z = lh::prune_ws_sizes(T, f->host.msa_mixed_n != 0);
   const size_t n_ops = (size_t)std::max(T - 2, 1);
-  return sizeof(double) * R * z.scratch_doubles_per_rate + n_ops * (2 * sizeof(int4) + sizeof(int32_t)) +
+  return sizeof(double) * R * z.scratch_doubles_per_rate + n_ops * (sizeof(int2) + sizeof(int32_t)) +
          z.tabs_per_sample * sizeof(int4) + sizeof(int4);
 }
 
@@ -380,7 +380,7 @@ int ensure_workspace(lh_family* f, int n, int R, int T) {
   const lh::PruneWsSizes z = lh::prune_ws_sizes(T, f->host.msa_mixed_n != 0);
   const size_t n_ops = (size_t)std::max(T - 2, 1);
   LH_HIP(hipMalloc((void**)&w.prune.scratch, sizeof(double) * cap * R * z.scratch_doubles_per_rate));
-  LH_HIP(hipMalloc((void**)&w.prune.wops, 2 * sizeof(int4) * cap * n_ops));
+  LH_HIP(hipMalloc((void**)&w.prune.wops, sizeof(int2) * cap * n_ops));
   LH_HIP(hipMalloc((void**)&w.prune.mats, sizeof(int32_t) * cap * n_ops));
   LH_HIP(hipMalloc((void**)&w.prune.tabs, sizeof(int4) * cap * z.tabs_per_sample));
   LH_HIP(hipMalloc((void**)&w.prune.hdr, sizeof(int4) * cap));

@@ -22,15 +22,14 @@ enum : int { OP_CHERRY = 0, OP_TIP_ACC = 1, OP_POP_ACC = 2, OP_PUSH_FLAG = 16, O
 // (25 with N tips), which K1's prologue tabulates; then
 //   cherry + tip-into-accumulator      ->  W_CTIP      a = table[s_y][s_z] o tipcol_w         (no mat-vec)
 //   pushed cherry + pop                ->  W_CTAB_ACC  a = table[s_y][s_z] o (P_first a)      (one mat-vec, no push / pop)
-// A walk op is a 32-byte descriptor (struct WalkOp in lh_prune.hip: byte offsets ready for the instructions that
-// use them).
+// A walk op is an 8-byte descriptor (WalkOp in lh_prune.hip).
 enum : int { W_CHERRY = 0, W_TIP_ACC = 1, W_POP = 2, W_CTIP = 3, W_CTAB_ACC = 4 };
 
 // K0c's output and K1's scratch area (all device memory, sized by prune_ws_sizes)
 struct PruneWs {
   double* scratch;    // per (sample, rate): [n_mat + n_tab][16] P-matrices (walk order, then the cherry branches'),
                       // then [n_tab][E][4] cherry tables, E = 16 or 25
-  int4* wops;         // [n][T-2][2] walk-op descriptors
+  int2* wops;         // [n][T-2] walk-op descriptors
   int32_t* mats;      // [n][T-2] node whose branch matrix i of the list is
   int4* tabs;         // [n][(T-1)/2] cherry tables: tip y, tip z, the cherry's node
   int4* hdr;          // [n] walk ops, matrices, tables, error (malformed schedule: the sample's results are NaN)

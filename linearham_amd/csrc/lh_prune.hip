@@ -84,6 +84,9 @@ typedef const double __attribute__((address_space(4))) * pmat_ptr;
 
 // -DLH_EXP_K1_STAMPS: latency of the first P-matrix load of every non-cherry op and the length of the walk, per wave,
 // for 128 workgroups in the middle of the grid (an instrument; it perturbs the schedule it measures)
+#ifdef LH_DEBUG_WALK
+__device__ int lh_dbg_max_ops = 1 << 30;
+#endif
 #ifdef LH_EXP_CT_STAMPS
 __device__ unsigned long long ct_stamps[1024][10];
 __device__ unsigned long long ct_phase[128][8];
@@ -390,16 +393,19 @@ __device__ __forceinline__ void table_entry(const double* ctab, int table, int s
   c[0] = q0.x, c[1] = q0.y, c[2] = q1.x, c[3] = q1.y;
 }
 
-// The walk descriptors (two int4 per op, written by K0c, fetched with one scalar load) hold everything an op needs
-// in the form the instructions take it, because the walk is bound by SCALAR issue as much as by vector issue (a SIMD
-// issues one scalar instruction per four cycles, like one vector instruction: r03 PMC):
-//   a.x  kind (bits 0-2) | tip-state count (bits 4-5) | push mask (one-hot slot, bits 8-23) | pop slot (bits 24-27)
-//   a.y  byte offset of the op's first P-matrix in the scratch area      a.z  byte offset of its cherry table
-//   a.w  MSA byte offset of tip A's row      b.x  of tip B's row      b.y  of tip C's row
-//   b.z  LDS byte offset of tip A's table entry      b.w  of tip B's (W_CHERRY) or tip C's (W_CTIP)
-struct WalkOp {
-  int4 a, b;
-};
+// Walk descriptors: 8 bytes per op, written by K0c, copied into LDS by the workgroup's prologue and read from there
+// two ops ahead (a descriptor fetched from global memory sat in the same scalar-memory wait as the op's P-matrix and
+// cost a trip to HBM per op: r03 stamps):
+//   x  kind [2:0] | the op uses a P-matrix [3] | push slot + 1 [8:4] (0: no push) | pop slot [12:9] |
+//      tip B / tip C states are read [13] / [14] | tip A [31:16] (1 when the op has none: its state is loaded anyway)
+//   y  tip B [15:0] | tip C [31:16]
+// P-matrices and cherry tables are consumed strictly in sequence (K0c lists them in walk order; a pushed subtree's
+// branch matrix is applied AT THE PUSH, st = P_first a, so that every op uses at most one matrix), so the walk keeps
+// two running offsets instead of per-op addresses, and "the next matrix" / "the next table" are known without
+// looking ahead.
+typedef int2 WalkOp;
+enum : int { WOP_MATRIX = 8, WOP_PUSH_SHIFT = 4, WOP_POP_SHIFT = 9, WOP_HAS_B = 1 << 13, WOP_HAS_C = 1 << 14 };
+
 // timing experiments (results wrong by construction): every table look-up goes to table 0 / every walk matrix comes
 // from one of two hot lines
 #ifdef LH_EXP_CT_TABHIT
@@ -428,20 +434,89 @@ __device__ __forceinline__ void tip_column_at(const char* tiptab_bytes, int entr
 }
 
 template <bool kN>
-__device__ __forceinline__ void table_entry_at(const char* ctab_bytes, int table_off, int sy, int sz, double (&c)[4]) {
+__device__ __forceinline__ void table_entry_at(const char* ctab_bytes, unsigned table_off, int sy, int sz, double (&c)[4]) {
   constexpr int SY = kN ? 5 : 4;
   // 32-bit byte offset from a wave-uniform base: scalar base + vector offset addressing, no 64-bit vector arithmetic
-  const unsigned off = (unsigned)table_off + (unsigned)(sy * SY + sz) * 32u;
+  const unsigned off = table_off + (unsigned)(sy * SY + sz) * 32u;
   const double2* q = reinterpret_cast<const double2*>(ctab_bytes + off);
   const double2 q0 = q[0], q1 = q[1];
   c[0] = q0.x, c[1] = q0.y, c[2] = q1.x, c[3] = q1.y;
 }
 
+// The naive branch closed for each possible naive state b (A,C,G,T,N): L_b = sum_i pi_i clv_root[i] P_naive[i][b]
+// (N: row sums of P_naive); naive_tab = the naive tip's entry of the tip table.
+template <int S>
+__device__ __forceinline__ void close_naive_branch(const double (&a)[S][4], const int (&scal)[S], const double* naive_tab,
+                                                   const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const double w0 = p4[0] * a[s][0], w1 = p4[1] * a[s][1], w2 = p4[2] * a[s][2], w3 = p4[3] * a[s][3];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      double tv[4];
+      if (b < 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tv[i] = naive_tab[b * 4 + i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tv[i] = ((naive_tab[i] + naive_tab[4 + i]) + naive_tab[8 + i]) + naive_tab[12 + i];
+      }
+      lik[s][b] = fma(w3, tv[3], fma(w2, tv[2], fma(w1, tv[1], w0 * tv[0])));
+    }
+    scl[s] = scal[s];
+  }
+}
+
+typedef __attribute__((address_space(5))) char* private_ptr;
+typedef __attribute__((address_space(3))) const char* lds_ptr;
+
+// The walk in assembly (two sites per lane, alignments without N; text and register map: tools/gen_walk_asm.py ->
+// lh_prune_walk_asm.inc).  Same operations in the same order as the C++ walk below, which stays as the form for
+// everything else and as its reference (LH_K1_CXX_WALK=1 selects it; tests compare the two).
+// wops: the sample's descriptors in global memory; site_base: the wave's first site (lane l carries site_base + l and
+// site_base + l + 64); ctoff: byte offset of the cherry tables in the scratch region pm points to.
+template <int kDepth>
+__device__ __forceinline__ void prune_wave_asm(int site_base, int site_end, const uint8_t* __restrict__ msa, int L, int n_w,
+                                               const WalkOp* __restrict__ wops, pmat_ptr pm, unsigned ctoff,
+                                               const double* tiptab, const double* naive_tab,
+                                               const double* __restrict__ p4, double (&lik)[2][5], int (&scl)[2]) {
+  __attribute__((aligned(16))) double out_mem[10];                                      // a[2][4], then the packed scaler counts
+  __attribute__((aligned(16))) double deep_mem[(kDepth > 1 ? kDepth - 1 : 1) * 8];     // stack slots 1.. : [slot][site][4]
+  const uint8_t* msa_m = msa - L;
+  const unsigned tip_lds = (unsigned)(size_t)(lds_ptr)tiptab;
+  const int last_site = site_end - 1;
+  asm volatile(
+#include "lh_prune_walk_asm.inc"
+      :
+      : [nw] "s"(n_w), [wops] "s"(wops), [pm] "s"(pm), [ctoff] "s"(ctoff), [msa] "s"(msa_m), [L] "s"(L), [tip] "s"(tip_lds),
+        [site0] "s"(site_base), [last] "s"(last_site), [out] "v"((private_ptr)out_mem), [deep] "v"((private_ptr)deep_mem)
+      : "memory", "vcc", "scc", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
+        "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36",
+        "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
+        "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70",
+        "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43",
+        "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60",
+        "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77",
+        "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
+        "s95", "s96", "s97", "s98", "s99");
+  double a[2][4];
+  int scal[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[s][i] = out_mem[s * 4 + i];
+  const unsigned packed = reinterpret_cast<const unsigned*>(out_mem)[16];
+  scal[0] = (int)(packed & 0xffffu);
+  scal[1] = (int)(packed >> 16);
+  close_naive_branch<2>(a, scal, naive_tab, p4, lik, scl);
+}
+
 template <int kDepth, int S, bool kN>
-__device__ __forceinline__ void prune_wave_ct(int site0, int site_end, const uint8_t* __restrict__ msa, int n_w,
-                                              const WalkOp* __restrict__ op_ptr, pmat_ptr pm, const double* tiptab,
+__device__ __forceinline__ void prune_wave_ct(int site0, int site_end, const uint8_t* __restrict__ msa, int L, int n_w,
+                                              const WalkOp* desc /* LDS */, pmat_ptr pm, const double* tiptab,
                                               const double* ctab, const double* naive_tab,
                                               const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
+  constexpr unsigned kTabBytes = (kN ? 25 : 16) * 32;
   unsigned usite[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -455,39 +530,46 @@ __device__ __forceinline__ void prune_wave_ct(int site0, int site_end, const uin
     a[s][0] = a[s][1] = a[s][2] = a[s][3] = 1.0;
     scal[s] = 0;
   }
-  // Pending siblings: slot 0 in registers, deeper slots in a private array (scratch memory).  After K0c's rewrite
-  // a directly popped cherry never reaches the stack and K0c numbers the slots by depth: the configs[2] trees push
-  // slot 0 ten times and slot 1 twice per tree, nothing deeper (a 500-tip tree: four slots).  One register slot
-  // instead of three is what lets the walk run at six waves per SIMD without spilling its working set.
+  // Pending siblings (each already multiplied by its branch matrix): slot 0 in registers, deeper slots in a private
+  // array (scratch memory).  After K0c's rewrite a directly popped cherry never reaches the stack and K0c numbers the
+  // slots by depth: the configs[2] trees push slot 0 ten times and slot 1 twice per tree, nothing deeper.  One
+  // register slot instead of three is what lets the walk run at six waves per SIMD without spilling its working set.
   double st0[S][4];
   double deep[kDepth > 1 ? kDepth - 1 : 1][S][4];
+#pragma unroll
+  for (int s = 0; s < S; ++s) st0[s][0] = st0[s][1] = st0[s][2] = st0[s][3] = 0.0;
   const char* tipb = reinterpret_cast<const char*>(tiptab);
   const char* ctabb = reinterpret_cast<const char*>(ctab);
-
-#ifdef LH_EXP_CT_STAMPS
-  int ct_prev_kind = 0;
-#endif
-  // op k's descriptor and tip states were requested during iteration k - 1
-  WalkOp op = op_ptr[0];
+  const uint8_t* msa_m = msa - L;  // row of tip t (MSA row t - 1) at msa_m + t * L
+  const int last = n_w > 0 ? n_w - 1 : 0;
+  // descriptor pipeline: d0 = this op, d1 = the next one (both in scalar registers), dv = the one after (LDS read in flight)
+  WalkOp d0, d1, dv;
+  {
+    const WalkOp t0 = desc[0], t1 = desc[last < 1 ? last : 1];
+    d0.x = __builtin_amdgcn_readfirstlane(t0.x), d0.y = __builtin_amdgcn_readfirstlane(t0.y);
+    d1.x = __builtin_amdgcn_readfirstlane(t1.x), d1.y = __builtin_amdgcn_readfirstlane(t1.y);
+    dv = desc[last < 2 ? last : 2];
+  }
   int sa[S], sb[S], sc[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) sa[s] = sb[s] = sc[s] = 0;
   if (n_w > 0) {
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      sa[s] = msa[(unsigned)op.a.w + usite[s]];
-      sb[s] = msa[(unsigned)op.b.x + usite[s]];
-      sc[s] = msa[(unsigned)op.b.y + usite[s]];
+      sa[s] = msa_m[(unsigned)(((unsigned)d0.x >> 16) * L) + usite[s]];
+      sb[s] = msa_m[(unsigned)((d0.y & 0xffff) * L) + usite[s]];
+      sc[s] = msa_m[(unsigned)(((unsigned)d0.y >> 16) * L) + usite[s]];
     }
   }
+  unsigned pm_off = 0, tab_off = 0;  // byte offsets of the next unused P-matrix / cherry table
 #ifdef LH_EXP_CT_STAMPS
+  int ct_prev_kind = 0;
   unsigned long long kt[5] = {0, 0, 0, 0, 0};
   unsigned kn[5] = {0, 0, 0, 0, 0};
   unsigned long long t_prev = __builtin_readcyclecounter();
 #endif
   for (int k = 0; k < n_w; ++k) {
-    const WalkOp nx = op_ptr[k + 1 < n_w ? k + 1 : k];
-    const int kind = op.a.x & 7;
+    const int kind = d0.x & 7;
 #ifdef LH_EXP_CT_STAMPS
     {
       const unsigned long long t_now = __builtin_readcyclecounter();
@@ -498,92 +580,109 @@ __device__ __forceinline__ void prune_wave_ct(int site0, int site_end, const uin
           if (pk == q) kt[q] += t_now - t_prev, kn[q] += 1;
       }
       t_prev = t_now;
+      ct_prev_kind = kind;
     }
-    const int ct_prev_kind_next = kind;
 #endif
-    if (op.a.x & 0xffff00) {  // push the accumulator first: bits 8-23 = slot + 1
-      const int slot = (((unsigned)op.a.x >> 8) & 0xffffu) - 1;
-      if (slot == 0) {
+    const int tip_a = (unsigned)d0.x >> 16, tip_b = d0.y & 0xffff, tip_c = (unsigned)d0.y >> 16;
+    // the op's matrix, if it has one, is the next in sequence: x = P a -- its own mat-vec (tip-into-accumulator,
+    // table-into-accumulator, pop) or the one a push applies to the subtree it sets aside
+    double x[S][4];
+    if (d0.x & WOP_MATRIX) {
+      const pmat_ptr pb = reinterpret_cast<pmat_ptr>(reinterpret_cast<const char __attribute__((address_space(4)))*>(pm) + LH_CT_POFF(pm_off));
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-          st0[s][0] = a[s][0], st0[s][1] = a[s][1], st0[s][2] = a[s][2], st0[s][3] = a[s][3];
-        }
+      for (int s = 0; s < S; ++s) matvec(pb, a[s], x[s]);
+      pm_off += 128;
+    }
+    const int push = (d0.x >> WOP_PUSH_SHIFT) & 31;
+    if (push != 0) {
+      if (push == 1) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) st0[s][0] = x[s][0], st0[s][1] = x[s][1], st0[s][2] = x[s][2], st0[s][3] = x[s][3];
       } else {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          deep[slot - 1][s][0] = a[s][0], deep[slot - 1][s][1] = a[s][1];
-          deep[slot - 1][s][2] = a[s][2], deep[slot - 1][s][3] = a[s][3];
+          deep[push - 2][s][0] = x[s][0], deep[push - 2][s][1] = x[s][1];
+          deep[push - 2][s][2] = x[s][2], deep[push - 2][s][3] = x[s][3];
         }
       }
     }
-    // every op ends in a = u * v (see prune_wave): u a tip column, a table entry or P_a sibling; v a tip column or P_b a
-    double u[S][4], v[S][4];
-    if (kind == W_TIP_ACC) {
-      const pmat_ptr pb = reinterpret_cast<pmat_ptr>(reinterpret_cast<const char __attribute__((address_space(4)))*>(pm) + (unsigned)LH_CT_POFF(op.a.y));
+    // every op ends in an element-wise product: (tip column | table entry | pending sibling) x (x | tip column)
+    double u[S][4];
+    if (kind == W_TIP_ACC || kind == W_CTAB_ACC || kind == W_POP) {
+      if (kind == W_TIP_ACC) {
 #pragma unroll
-      for (int s = 0; s < S; ++s) matvec(pb, a[s], v[s]);
+        for (int s = 0; s < S; ++s) tip_column_at<kN>(tipb, tip_a * 128, sa[s], u[s]);
+      } else if (kind == W_CTAB_ACC) {
 #pragma unroll
-      for (int s = 0; s < S; ++s) tip_column_at<kN>(tipb, op.b.z, sa[s], u[s]);
-    } else if (kind == W_CTAB_ACC) {
-      const pmat_ptr pb = reinterpret_cast<pmat_ptr>(reinterpret_cast<const char __attribute__((address_space(4)))*>(pm) + (unsigned)LH_CT_POFF(op.a.y));
-#pragma unroll
-      for (int s = 0; s < S; ++s) matvec(pb, a[s], v[s]);
-#pragma unroll
-      for (int s = 0; s < S; ++s) table_entry_at<kN>(ctabb, LH_CT_TOFF(op.a.z), sa[s], sb[s], u[s]);
-    } else if (kind == W_POP) {
-      const pmat_ptr pb = reinterpret_cast<pmat_ptr>(reinterpret_cast<const char __attribute__((address_space(4)))*>(pm) + (unsigned)LH_CT_POFF(op.a.y));
-#pragma unroll
-      for (int s = 0; s < S; ++s) matvec(pb, a[s], v[s]);
-      const pmat_ptr pa = pb + 16;
-      const int slot = (op.a.x >> 24) & 15;
-      if (slot == 0) {
-#pragma unroll
-        for (int s = 0; s < S; ++s) matvec(pa, st0[s], u[s]);
+        for (int s = 0; s < S; ++s) table_entry_at<kN>(ctabb, LH_CT_TOFF(tab_off), sa[s], sb[s], u[s]);
+        tab_off += kTabBytes;
       } else {
-        double y[S][4];
+        const int slot = (d0.x >> WOP_POP_SHIFT) & 15;
+        if (slot == 0) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) u[s][0] = st0[s][0], u[s][1] = st0[s][1], u[s][2] = st0[s][2], u[s][3] = st0[s][3];
+        } else {
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            u[s][0] = deep[slot - 1][s][0], u[s][1] = deep[slot - 1][s][1];
+            u[s][2] = deep[slot - 1][s][2], u[s][3] = deep[slot - 1][s][3];
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        a[s][0] = u[s][0] * x[s][0];
+        a[s][1] = u[s][1] * x[s][1];
+        a[s][2] = u[s][2] * x[s][2];
+        a[s][3] = u[s][3] * x[s][3];
+      }
+    } else {
+      double v[S][4];
+      if (kind == W_CTIP) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          y[s][0] = deep[slot - 1][s][0], y[s][1] = deep[slot - 1][s][1];
-          y[s][2] = deep[slot - 1][s][2], y[s][3] = deep[slot - 1][s][3];
+          table_entry_at<kN>(ctabb, LH_CT_TOFF(tab_off), sa[s], sb[s], u[s]);
+          tip_column_at<kN>(tipb, tip_c * 128, sc[s], v[s]);
         }
+        tab_off += kTabBytes;
+      } else {  // W_CHERRY
 #pragma unroll
-        for (int s = 0; s < S; ++s) matvec(pa, y[s], u[s]);
+        for (int s = 0; s < S; ++s) {
+          tip_column_at<kN>(tipb, tip_a * 128, sa[s], u[s]);
+          tip_column_at<kN>(tipb, tip_b * 128, sb[s], v[s]);
+        }
       }
-    } else if (kind == W_CTIP) {
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        table_entry_at<kN>(ctabb, LH_CT_TOFF(op.a.z), sa[s], sb[s], u[s]);
-        tip_column_at<kN>(tipb, op.b.w, sc[s], v[s]);
-      }
-    } else {  // W_CHERRY
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        tip_column_at<kN>(tipb, op.b.z, sa[s], u[s]);
-        tip_column_at<kN>(tipb, op.b.w, sb[s], v[s]);
+        a[s][0] = u[s][0] * v[s][0];
+        a[s][1] = u[s][1] * v[s][1];
+        a[s][2] = u[s][2] * v[s][2];
+        a[s][3] = u[s][3] * v[s][3];
       }
     }
+    // rotate the descriptors and request the next op's tip states (tip A always; B and C on their flags)
+    d0 = d1;
+    d1.x = __builtin_amdgcn_readfirstlane(dv.x), d1.y = __builtin_amdgcn_readfirstlane(dv.y);
+    dv = desc[k + 3 < n_w ? k + 3 : last];
+#ifdef LH_EXP_CT_NOSTATE  // timing experiment: tip states from arithmetic, no memory (results wrong)
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      a[s][0] = u[s][0] * v[s][0];
-      a[s][1] = u[s][1] * v[s][1];
-      a[s][2] = u[s][2] * v[s][2];
-      a[s][3] = u[s][3] * v[s][3];
+      sa[s] = (usite[s] + ((unsigned)d0.x >> 16)) & 3;
+      sb[s] = (usite[s] + (d0.y & 0xffff)) & 3;
+      sc[s] = (usite[s] + ((unsigned)d0.y >> 16)) & 3;
     }
-#ifdef LH_EXP_CT_STAMPS
-    ct_prev_kind = ct_prev_kind_next;
+#else
+#pragma unroll
+    for (int s = 0; s < S; ++s) sa[s] = msa_m[(unsigned)(((unsigned)d0.x >> 16) * L) + usite[s]];
+    if (d0.x & WOP_HAS_B) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) sb[s] = msa_m[(unsigned)((d0.y & 0xffff) * L) + usite[s]];
+    }
+    if (d0.x & WOP_HAS_C) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) sc[s] = msa_m[(unsigned)(((unsigned)d0.y >> 16) * L) + usite[s]];
+    }
 #endif
-    op = nx;
-    // the next op's tip states: tip A unconditionally (an op without tips has offset 0), B and C on a count test
-#pragma unroll
-    for (int s = 0; s < S; ++s) sa[s] = msa[(unsigned)op.a.w + usite[s]];
-    if (op.a.x & 0x20) {
-#pragma unroll
-      for (int s = 0; s < S; ++s) sb[s] = msa[(unsigned)op.b.x + usite[s]];
-      if (op.a.x & 0x10) {
-#pragma unroll
-        for (int s = 0; s < S; ++s) sc[s] = msa[(unsigned)op.b.y + usite[s]];
-      }
-    }
     // per-site, per-rate 2^256 rescaling, as in prune_wave
     unsigned hw[S];
 #pragma unroll
@@ -615,24 +714,7 @@ __device__ __forceinline__ void prune_wave_ct(int site0, int site_end, const uin
     }
   }
 #endif
-  // epilogue: close the naive branch for each possible naive state (as prune_wave)
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    const double w0 = p4[0] * a[s][0], w1 = p4[1] * a[s][1], w2 = p4[2] * a[s][2], w3 = p4[3] * a[s][3];
-#pragma unroll
-    for (int b = 0; b < 5; ++b) {
-      double tv[4];
-      if (b < 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tv[i] = naive_tab[b * 4 + i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tv[i] = ((naive_tab[i] + naive_tab[4 + i]) + naive_tab[8 + i]) + naive_tab[12 + i];
-      }
-      lik[s][b] = fma(w3, tv[3], fma(w2, tv[2], fma(w1, tv[1], w0 * tv[0])));
-    }
-    scl[s] = scal[s];
-  }
+  close_naive_branch<S>(a, scal, naive_tab, p4, lik, scl);
 }
 
 #undef LH_SLOT_COPY
@@ -788,26 +870,26 @@ __device__ __forceinline__ void matvec_v(const double (&p)[16], const double (&a
 }
 
 // K0c: one thread per sample checks the schedule (kinds, node ranges, stack discipline: everything K1 indexes with)
-// and writes the walk descriptors (WalkOp above; lh_device.h).  A malformed schedule gets an empty walk, hdr.w = 1 (K1
+// and writes the walk descriptors (WalkOp above; lh_device.h), the list of branch nodes whose P-matrices the walk
+// consumes (in that order) and the list of cherry tables.  A malformed schedule gets an empty walk, hdr.w = 1 (K1
 // then leaves NaN) and sets *err_flag, which lh_family_status reports: device-resident schedules are not trusted.
-// L = K1's site dimension (MSA row stride); E = entries per cherry table (16, or 25 when tips can be N).
-__global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int max_depth, int tabs_stride, int L, int E,
-                                                            const int32_t* __restrict__ ops, int4* __restrict__ wops,
+__global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int max_depth, int tabs_stride, int use_tables,
+                                                            const int32_t* __restrict__ ops, int2* __restrict__ wops,
                                                             int32_t* __restrict__ mats, int4* __restrict__ tabs,
                                                             int4* __restrict__ hdr, int32_t* err_flag) {
   const int smp = blockIdx.x * 64 + threadIdx.x;
   if (smp >= n) return;
   const int n_ops = T - 2, nodes = 2 * T - 2;
   const int4* __restrict__ o = reinterpret_cast<const int4*>(ops) + (size_t)smp * n_ops;
-  int4* wo = wops + (size_t)smp * n_ops * 2;
+  int2* wo = wops + (size_t)smp * n_ops;
   int32_t* ml = mats + (size_t)smp * n_ops;
   int4* tl = tabs + (size_t)smp * tabs_stride;
   int depth = 0, n_w = 0, n_mat = 0, n_tab = 0;
   int bdepth = 0;  // stack depth of the schedule as written (depth: of the rewritten walk, which pushes less)
+  int pend[16];    // per stack slot of the rewritten walk: where the pushed subtree's branch node goes in `mats`
   bool bad = false;
   auto tip_ok = [&](int v) { return v >= 1 && v < T; };
   auto inner_ok = [&](int v) { return v >= T && v < nodes; };
-  auto row = [&](int tip) { return (tip - 1) * L; };  // MSA byte offset of a tip's row
   int k = 0;
   int4 op = o[0];
   while (k < n_ops && !bad) {
@@ -816,61 +898,57 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
     const int kind = op.x & 15;
     const bool push = (op.x & OP_PUSH_FLAG) != 0;
     if (op.x < 0 || (op.x & 0xe0)) bad = true;
-    int4 wa = make_int4(0, 0, 0, 0), wb = make_int4(0, 0, 0, 0);
+    int2 w = make_int2(0, 0);
     int step = 1;
     if (kind == OP_CHERRY) {
       if (!tip_ok(op.y) || !tip_ok(op.z)) bad = true;
-      if (push && (op.w != bdepth || bdepth >= max_depth)) bad = true;
+      if (push && (op.w != bdepth || bdepth >= max_depth || depth >= 16 || n_mat >= n_ops)) bad = true;
       if (!push && k != 0) bad = true;  // a cherry that does not push would overwrite a live accumulator
       const int nk = nx.x & 15;
       const bool nx_plain = nx.x >= 0 && (nx.x & 0xf0) == 0;
-      const int pushbits = (push && !bad) ? ((depth + 1) << 8) : 0;  // slots numbered by the depth the rewritten walk has here
       if (bad) {
-      } else if (has_next && nk == OP_TIP_ACC && nx_plain && tip_ok(nx.y) && inner_ok(nx.z) && n_tab < tabs_stride) {
-        wa = make_int4(W_CTIP | 0x30 | pushbits, 0, n_tab * E * 32, row(op.y));
-        wb = make_int4(row(op.z), row(nx.y), 0, nx.y * 128);
-        tl[n_tab++] = make_int4(op.y, op.z, nx.z, 0);
-        if (push) ++depth, ++bdepth;
-        step = 2;
-      } else if (has_next && nk == OP_POP_ACC && push && nx_plain && nx.w == op.w && inner_ok(nx.y) && inner_ok(nx.z) &&
-                 n_tab < tabs_stride && n_mat < n_ops) {
+      } else if (use_tables && has_next && nk == OP_POP_ACC && push && nx_plain && nx.w == op.w && inner_ok(nx.y) &&
+                 inner_ok(nx.z) && n_tab < tabs_stride) {
         // the cherry is the whole second subtree: the first one stays in the accumulator, nothing is pushed
-        wa = make_int4(W_CTAB_ACC | 0x20, n_mat * 128, n_tab * E * 32, row(op.y));
-        wb = make_int4(row(op.z), 0, 0, 0);
+        w = make_int2(W_CTAB_ACC | WOP_MATRIX | WOP_HAS_B | (op.y << 16), op.z | (1 << 16));
         ml[n_mat++] = nx.y;
         tl[n_tab++] = make_int4(op.y, op.z, nx.z, 0);
         step = 2;
       } else {
-        wa = make_int4(W_CHERRY | 0x20 | pushbits, 0, 0, row(op.y));
-        wb = make_int4(row(op.z), 0, op.y * 128, op.z * 128);
-        if (push) ++depth, ++bdepth;
+        int pushbits = 0;
+        if (push) {  // the accumulator is set aside as P_first a: the matrix's node is named by the matching pop
+          pushbits = WOP_MATRIX | ((depth + 1) << WOP_PUSH_SHIFT);
+          pend[depth] = n_mat++;
+          ++depth, ++bdepth;
+        }
+        if (use_tables && has_next && nk == OP_TIP_ACC && nx_plain && tip_ok(nx.y) && inner_ok(nx.z) && n_tab < tabs_stride) {
+          w = make_int2(W_CTIP | pushbits | WOP_HAS_B | WOP_HAS_C | (op.y << 16), op.z | (nx.y << 16));
+          tl[n_tab++] = make_int4(op.y, op.z, nx.z, 0);
+          step = 2;
+        } else {
+          w = make_int2(W_CHERRY | pushbits | WOP_HAS_B | (op.y << 16), op.z | (1 << 16));
+        }
       }
     } else if (kind == OP_TIP_ACC) {
       if (push || k == 0 || !tip_ok(op.y) || !inner_ok(op.z) || n_mat >= n_ops) {
         bad = true;
       } else {
-        wa = make_int4(W_TIP_ACC, n_mat * 128, 0, row(op.y));
-        wb = make_int4(0, 0, op.y * 128, 0);
+        w = make_int2(W_TIP_ACC | WOP_MATRIX | (op.y << 16), 1 | (1 << 16));
         ml[n_mat++] = op.z;
       }
     } else if (kind == OP_POP_ACC) {
-      if (push || bdepth < 1 || depth < 1 || op.w != bdepth - 1 || !inner_ok(op.y) || !inner_ok(op.z) || n_mat + 1 >= n_ops) {
+      if (push || bdepth < 1 || depth < 1 || op.w != bdepth - 1 || !inner_ok(op.y) || !inner_ok(op.z) || n_mat >= n_ops) {
         bad = true;
       } else {
-        wa = make_int4(W_POP | ((depth - 1) << 24), n_mat * 128, 0, 0);
-        ml[n_mat] = op.z;      // the child whose CLV is in the accumulator
-        ml[n_mat + 1] = op.y;  // the popped child
-        n_mat += 2;
         --depth, --bdepth;
+        w = make_int2(W_POP | WOP_MATRIX | (depth << WOP_POP_SHIFT) | (1 << 16), 1 | (1 << 16));
+        ml[pend[depth]] = op.y;  // the popped child: its matrix was applied at the push
+        ml[n_mat++] = op.z;      // the child whose CLV is in the accumulator
       }
     } else {
       bad = true;
     }
-    if (!bad) {
-      wo[2 * n_w] = wa;
-      wo[2 * n_w + 1] = wb;
-      ++n_w;
-    }
+    if (!bad) wo[n_w++] = w;
     k += step;
     if (k < n_ops) op = step == 2 ? o[k] : nx;
   }
@@ -886,9 +964,9 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
 // The workgroup of the cherry-table form.  Block layout as prune_body (n2 two-site waves + n1 one-site waves per rate;
 // kFused: all R rates of the sample in one workgroup, mixed at the end).  scratch: this (sample, rate)'s region of
 // rate_stride doubles: [n_mat + n_tab][16] P-matrices | [n_tab][E][4] tables.
-template <int kDepth, bool kN, bool kFused>
+template <int kDepth, bool kN, bool kFused, int kS = 2, bool kAsm = false>
 __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, const uint8_t* __restrict__ msa, int L,
-                                              int T, const int4* __restrict__ wops, const int32_t* __restrict__ mats,
+                                              int T, const int2* __restrict__ wops, const int32_t* __restrict__ mats,
                                               const int4* __restrict__ tabs, int tabs_stride,
                                               const int4* __restrict__ hdr, const double* __restrict__ brlen,
                                               const double* __restrict__ rates, const double* __restrict__ eig,
@@ -905,15 +983,21 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
   const int sample = blockIdx.z;
   const int n_ops = T - 2;
   const int4 h = hdr[sample];
-  const int n_w = __builtin_amdgcn_readfirstlane(h.x), n_mat = __builtin_amdgcn_readfirstlane(h.y),
-            n_tab = __builtin_amdgcn_readfirstlane(h.z);
+#ifdef LH_DEBUG_WALK  // debugging aid: stop every walk after lh_dbg_max_ops ops (LH_DBG_MAXOPS), to bisect a walk against another
+  const int n_w = min(__builtin_amdgcn_readfirstlane(h.x), lh_dbg_max_ops);
+#else
+  const int n_w = __builtin_amdgcn_readfirstlane(h.x);
+#endif
+  const int n_mat = __builtin_amdgcn_readfirstlane(h.y), n_tab = __builtin_amdgcn_readfirstlane(h.z);
   const bool malformed = h.w != 0;
   double* pw = pmat_w + ((size_t)sample * R + rate) * rate_stride;
   double* ctab = pw + (size_t)(T - 3 > 0 ? T - 3 : 0) * 16;
   double* tiptab = reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);
   const double* naive_tab = tiptab;
-  const WalkOp* __restrict__ op_ptr = reinterpret_cast<const WalkOp*>(wops) + (size_t)sample * n_ops;
   const int4* __restrict__ tl = tabs + (size_t)sample * tabs_stride;
+  // the walk descriptors go to LDS behind the tip tables (one copy per workgroup)
+  WalkOp* desc = reinterpret_cast<WalkOp*>(reinterpret_cast<double*>(smem2) + (size_t)(kFused ? R : 1) * T * 16);
+  for (int i = tid; i < n_w; i += blockDim.x) desc[i] = wops[(size_t)sample * n_ops + i];
   LH_CT_PHASE(0)
 
   // Prologue, first half: the P-matrices of this (sample, rate), one thread per matrix: the walk's inner-branch
@@ -995,27 +1079,34 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
   const int tile0 = blockIdx.x * tile;
   const int site_end = min(tile0 + tile, L);
   const double* __restrict__ p4 = pi + (size_t)sample * 4;
-  double lik[2][5];
-  int scl[2] = {0, 0};
+  // n2 waves carry kS sites per lane (64 apart), the others one site per lane
+  double lik[kS][5];
+  int scl[kS];
+#pragma unroll
+  for (int s = 0; s < kS; ++s) scl[s] = 0;
   int site0, n_own;
   const bool two_sites = wave < n2;
   if (two_sites) {
-    site0 = tile0 + wave * 128 + lane;
-    n_own = 2;
-    prune_wave_ct<kDepth, 2, kN>(site0, site_end, msa, n_w, op_ptr, pm, tiptab, ctab, naive_tab, p4, lik, scl);
+    site0 = tile0 + wave * (64 * kS) + lane;
+    n_own = kS;
+    if constexpr (kAsm && kS == 2 && !kN)
+      prune_wave_asm<kDepth>(tile0 + wave * 128, site_end, msa, L, n_w, wops + (size_t)sample * n_ops, pm,
+                             (unsigned)((T - 3 > 0 ? T - 3 : 0) * 128), tiptab, naive_tab, p4, lik, scl);
+    else
+      prune_wave_ct<kDepth, kS, kN>(site0, site_end, msa, L, n_w, desc, pm, tiptab, ctab, naive_tab, p4, lik, scl);
   } else {
-    site0 = tile0 + n2 * 128 + (wave - n2) * 64 + lane;
+    site0 = tile0 + n2 * (64 * kS) + (wave - n2) * 64 + lane;
     n_own = 1;
     double lik1[1][5];
     int scl1[1];
-    prune_wave_ct<kDepth, 1, kN>(site0, site_end, msa, n_w, op_ptr, pm, tiptab, ctab, naive_tab, p4, lik1, scl1);
+    prune_wave_ct<kDepth, 1, kN>(site0, site_end, msa, L, n_w, desc, pm, tiptab, ctab, naive_tab, p4, lik1, scl1);
 #pragma unroll
     for (int b = 0; b < 5; ++b) lik[0][b] = lik1[0][b];
     scl[0] = scl1[0];
   }
   if (malformed) {  // K0c rejected the schedule: no number may look like a result
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < kS; ++s)
 #pragma unroll
       for (int b = 0; b < 5; ++b) lik[s][b] = __builtin_nan("");
   }
@@ -1024,7 +1115,7 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
     double* lik_out = site_lik + (((size_t)sample * R + rate) * 5) * (size_t)L;
     int32_t* scal_out = site_scal + ((size_t)sample * R + rate) * (size_t)L;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < kS; ++s) {
       const int site = site0 + 64 * s;
       if (s < n_own && site < site_end) {
 #pragma unroll
@@ -1034,14 +1125,14 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
     }
   } else {
     // exchange through LDS (over the tip tables, which no wave needs any more), then mix the rates (as prune_body)
-    const int pad = n2 * 128 + (wpr - n2) * 64;
+    const int pad = n2 * (64 * kS) + (wpr - n2) * 64;
     LH_CT_PHASE(5)
     __syncthreads();
     LH_CT_PHASE(6)
     double* X = reinterpret_cast<double*>(smem2);
     int* SC = reinterpret_cast<int*>(X + (size_t)R * 5 * pad);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < kS; ++s) {
       const int idx = site0 + 64 * s - tile0;
       if (s < n_own && idx < pad) {
 #pragma unroll
@@ -1073,7 +1164,7 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
 }
 
 #define LH_PRUNE_CT_PARAMS                                                                                          \
-  int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, const int4 *__restrict__ wops,   \
+  int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, const int2 *__restrict__ wops,   \
       const int32_t *__restrict__ mats, const int4 *__restrict__ tabs, int tabs_stride,                             \
       const int4 *__restrict__ hdr, const double *__restrict__ brlen, const double *__restrict__ rates,            \
       const double *__restrict__ eig, double *pmat_w, size_t rate_stride, const double *__restrict__ pi,           \
@@ -1081,16 +1172,15 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
 #define LH_PRUNE_CT_ARGS \
   n2, tile, R, wpr, msa, L, T, wops, mats, tabs, tabs_stride, hdr, brlen, rates, eig, pmat_w, rate_stride, pi, site_lik, site_scal
 #define LH_PRUNE_CT_KERNEL(NAME, WAVES)                                                              \
-  template <int kDepth, bool kN, bool kFused>                                                        \
+  template <int kDepth, bool kN, bool kFused, bool kAsm>                                             \
   __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) NAME(    \
       LH_PRUNE_CT_PARAMS) {                                                                          \
-    prune_body_ct<kDepth, kN, kFused>(LH_PRUNE_CT_ARGS);                                             \
+    prune_body_ct<kDepth, kN, kFused, 2, kAsm>(LH_PRUNE_CT_ARGS);                                    \
   }
 LH_PRUNE_CT_KERNEL(prune_kernel_ct6, 6)
 LH_PRUNE_CT_KERNEL(prune_kernel_ct5, 5)
 LH_PRUNE_CT_KERNEL(prune_kernel_ct4, 4)
 #undef LH_PRUNE_CT_KERNEL
-
 // pmat_w: the scratch area (see prune_body); written in the prologue, read back after the barrier.
 #define LH_PRUNE_PARAMS                                                                                     \
   int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, int n_ops,               \
@@ -1111,12 +1201,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   prune_body<kDepth, true, kN, true>(LH_PRUNE_ARGS);
 }
 
-// Deep stacks leave no room for two sites per lane.
-template <int kDepth>
-__global__ void __launch_bounds__(512) prune_kernel_deep(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, false, true>(LH_PRUNE_ARGS);
-}
-
 PruneWsSizes prune_ws_sizes(int T, bool mixed_n) {
   PruneWsSizes z;
   z.tabs_per_sample = (size_t)std::max((T - 1) / 2, 1);
@@ -1133,14 +1217,20 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
                  double* site_lik, int32_t* site_scal, hipStream_t stream, bool allow_fused) {
   const int L = fam.n_prune;  // distinct alignment columns; identical ones are pruned once
   const PruneWsSizes sizes = prune_ws_sizes(T, fam.msa_mixed_n != 0);
+#ifdef LH_DEBUG_WALK
+  {
+    const int m = getenv("LH_DBG_MAXOPS") ? atoi(getenv("LH_DBG_MAXOPS")) : 1 << 30;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(lh_dbg_max_ops), &m, sizeof(m));
+  }
+#endif
   // K0c: every schedule is checked on the device (and rewritten into walk ops) before K1 indexes anything with it
+  static const bool no_tables = getenv("LH_K1_NO_TABLES") != nullptr;  // experiment: no cherry tables (every cherry walked)
   hipLaunchKernelGGL(schedule_check_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, T, max_depth,
-                     (int)sizes.tabs_per_sample, L, fam.msa_mixed_n ? 25 : 16, ops, ws.wops, ws.mats, ws.tabs, ws.hdr,
-                     ws.err_flag);
+                     (int)sizes.tabs_per_sample, no_tables ? 0 : 1, ops, ws.wops, ws.mats, ws.tabs, ws.hdr, ws.err_flag);
   if (L == 0) return R;       // nothing but all-N padding (K2a reads no plane at all)
   double* pmat = ws.scratch;
   const size_t rate_stride = sizes.scratch_doubles_per_rate;
-  const bool two = max_depth <= 4;
+  const bool two = true;  // (the one-site-per-lane form for deep stacks is gone: deep slots live in scratch memory)
   // tile: up to 1024 sites as two-site waves plus at most one one-site wave for a remainder below 64
   // (deep variant: up to 8 one-site waves = 512 sites); tiles rebalanced so that they are equally full.
   // Large tiles matter for large trees: every workgroup of a (sample, rate) repeats the P-matrix
@@ -1150,10 +1240,11 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   const int cap = cap_env >= 64 ? std::min(cap_env, two ? 1024 : 512) : two ? 1024 : 512;
   const int tiles = (L + cap - 1) / cap;
   const int tile = (L + tiles - 1) / tiles;
+  const int spl = 128;  // sites per two-site wave
   int n2 = 0, n1;
   if (two) {
-    n2 = tile / 128;
-    const int rem = tile - 128 * n2;
+    n2 = tile / spl;
+    const int rem = tile - spl * n2;
     if (rem > 64) {
       ++n2;
       n1 = 0;
@@ -1167,15 +1258,16 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   const size_t tip_bytes = (size_t)T * 16 * sizeof(double);
   // all rates of a sample in one workgroup, mixed there: at most 8 waves, and R tip tables (later reused
   // as the exchange area [R][5][pad] doubles + [R][pad] ints) within a third of a CU's LDS
-  const size_t pad = (size_t)n2 * 128 + (size_t)n1 * 64;
-  const size_t fused_lds = std::max((size_t)R * tip_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
+  const size_t pad = (size_t)n2 * spl + (size_t)n1 * 64;
+  const size_t desc_bytes = (((size_t)std::max(T - 2, 1) * sizeof(int2)) + 15) & ~(size_t)15;  // the walk descriptors' copy
+  const size_t fused_lds = std::max((size_t)R * tip_bytes + desc_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
   static const bool seg_env = getenv("LH_K1_SEGMENTS") != nullptr;  // test hook: segments on small trees too
   static const int seg_waves = getenv("LH_K1_SEG_WAVES") ? atoi(getenv("LH_K1_SEG_WAVES")) : 4;  // measured: 4 (128 VGPRs, few spills) beats 5 by 9 %
   static const bool no_fuse = getenv("LH_K1_NO_FUSE") != nullptr;  // test hook: one workgroup per (sample, rate)
   const bool fused = allow_fused && !no_fuse && two && R * wpr <= 8 && fused_lds <= 53 * 1024 && !seg_env;
   // large trees: with the whole tip table in LDS fewer than five waves per SIMD would be resident
-  const bool seg = two && !fused && ((160 * 1024 / tip_bytes) * wpr / 4 < 5 || seg_env);
-  const size_t lds = fused ? fused_lds : seg ? (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) : tip_bytes;
+  const bool seg = max_depth <= 4 && !fused && ((160 * 1024 / tip_bytes) * wpr / 4 < 5 || seg_env);
+  const size_t lds = fused ? fused_lds : seg ? (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) : tip_bytes + desc_bytes;
   const int wg_waves = fused ? R * wpr : wpr;
   dim3 grid(tiles, fused ? 1 : R, n), block(64 * wg_waves);
   const int n_ops = T - 2;
@@ -1198,43 +1290,49 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   }
   // waves per SIMD that the LDS of the resident workgroups allows (160 KB per CU, 4 SIMDs)
   const int lds_waves = lds == 0 ? 8 : (int)((160 * 1024 / lds) * wg_waves / 4);
-  // the cherry-table form (two sites per lane, whole tip table in LDS); three register budgets, the launcher takes
-  // the tightest one whose occupancy the tip tables allow
+  // The cherry-table form (two sites per lane, whole tip table in LDS; one stack slot in registers, deeper ones in
+  // scratch memory, so any depth up to 16 runs it).  Three register budgets -- the launcher takes the tightest one whose
+  // occupancy the tip tables allow -- and, for alignments without N, the walk in assembly (LH_K1_CXX_WALK: test hook
+  // that keeps the C++ walk).
+  static const bool cxx_walk = getenv("LH_K1_CXX_WALK") != nullptr;
+  const bool use_asm = !cxx_walk && !fam.msa_mixed_n;
 #ifndef LH_EXP_CT_BUDGET
 #define LH_EXP_CT_BUDGET 6
 #endif
-#define LH_LAUNCH_BUDGET(D, N, F)                                                 \
-  {                                                                               \
-    if (lds_waves >= 6 && D == 3 && LH_EXP_CT_BUDGET >= 6) /* a fourth slot spills too much at 80 VGPRs */ \
-      LH_LAUNCH_CT((prune_kernel_ct6<D, N, F>))                                   \
-    else if (lds_waves >= 5 && LH_EXP_CT_BUDGET >= 5)                             \
-      LH_LAUNCH_CT((prune_kernel_ct5<D, N, F>))                                   \
-    else                                                                          \
-      LH_LAUNCH_CT((prune_kernel_ct4<D, N, F>))                                   \
+#define LH_LAUNCH_BUDGET(D, N, F, A)                          \
+  {                                                           \
+    if (lds_waves >= 6 && LH_EXP_CT_BUDGET >= 6)              \
+      LH_LAUNCH_CT((prune_kernel_ct6<D, N, F, A>))            \
+    else if (lds_waves >= 5 && LH_EXP_CT_BUDGET >= 5)         \
+      LH_LAUNCH_CT((prune_kernel_ct5<D, N, F, A>))            \
+    else                                                      \
+      LH_LAUNCH_CT((prune_kernel_ct4<D, N, F, A>))            \
   }
-#define LH_LAUNCH_SHALLOW(D, N)             \
-  {                                         \
-    if (fused)                              \
-      LH_LAUNCH_BUDGET(D, N, true)          \
-    else if (seg && seg_waves == 4)         \
-      LH_LAUNCH_K((prune_kernel_seg4<D, N>)) \
-    else if (seg)                           \
-      LH_LAUNCH_K((prune_kernel_seg<D, N>)) \
-    else                                    \
-      LH_LAUNCH_BUDGET(D, N, false)         \
+#define LH_LAUNCH_FORM(D, N, A)              \
+  {                                          \
+    if (fused)                               \
+      LH_LAUNCH_BUDGET(D, N, true, A)        \
+    else if (seg && seg_waves == 4)          \
+      LH_LAUNCH_K((prune_kernel_seg4<4, N>)) \
+    else if (seg)                            \
+      LH_LAUNCH_K((prune_kernel_seg<4, N>))  \
+    else                                     \
+      LH_LAUNCH_BUDGET(D, N, false, A)       \
   }
-  if (max_depth <= 3 && !fam.msa_mixed_n)
-    LH_LAUNCH_SHALLOW(3, false)
-  else if (max_depth <= 3)
-    LH_LAUNCH_SHALLOW(3, true)
-  else if (max_depth <= 4 && !fam.msa_mixed_n)
-    LH_LAUNCH_SHALLOW(4, false)
-  else if (max_depth <= 4)
-    LH_LAUNCH_SHALLOW(4, true)
-  else if (max_depth <= 8)
-    LH_LAUNCH_K(prune_kernel_deep<8>)
+#define LH_LAUNCH_SHALLOW(D)        \
+  {                                 \
+    if (fam.msa_mixed_n)            \
+      LH_LAUNCH_FORM(D, true, false) \
+    else if (use_asm)               \
+      LH_LAUNCH_FORM(D, false, true) \
+    else                            \
+      LH_LAUNCH_FORM(D, false, false) \
+  }
+  if (max_depth <= 4)
+    LH_LAUNCH_SHALLOW(4)
   else
-    LH_LAUNCH_K(prune_kernel_deep<16>)
+    LH_LAUNCH_SHALLOW(16)
+#undef LH_LAUNCH_FORM
 #undef LH_LAUNCH_SHALLOW
 #undef LH_LAUNCH_BUDGET
 #undef LH_LAUNCH_K
