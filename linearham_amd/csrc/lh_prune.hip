@@ -470,46 +470,54 @@ __device__ __forceinline__ void close_naive_branch(const double (&a)[S][4], cons
 typedef __attribute__((address_space(5))) char* private_ptr;
 typedef __attribute__((address_space(3))) const char* lds_ptr;
 
-// The walk in assembly (two sites per lane, alignments without N; text and register map: tools/gen_walk_asm.py ->
-// lh_prune_walk_asm.inc).  Same operations in the same order as the C++ walk below, which stays as the form for
-// everything else and as its reference (LH_K1_CXX_WALK=1 selects it; tests compare the two).
-// wops: the sample's descriptors in global memory; site_base: the wave's first site (lane l carries site_base + l and
-// site_base + l + 64); ctoff: byte offset of the cherry tables in the scratch region pm points to.
-template <int kDepth>
+// The walk in assembly (two or four sites per lane, alignments without N; text and register map: tools/gen_walk_asm.py
+// -> lh_prune_walk_asm_s<S>.inc).  Same operations in the same order as the C++ walk below, which stays as the form
+// for everything else and as its reference (LH_K1_CXX_WALK=1 selects it; the results are bit-identical).
+// wops: the sample's descriptors in global memory; site_base: the wave's first site (lane l carries site_base + l +
+// 64 s); ctoff: byte offset of the cherry tables in the scratch region pm points to.
+#define LH_WALK_ASM_OPERANDS                                                                                             \
+  [nw] "s"(n_w), [wops] "s"(wops), [pm] "s"(pm), [ctoff] "s"(ctoff), [msa] "s"(msa_m), [L] "s"(L), [tip] "s"(tip_lds),  \
+      [site0] "s"(site_base), [last] "s"(last_site), [out] "v"((private_ptr)out_mem), [deep] "v"((private_ptr)deep_mem)
+template <int kDepth, int S>
 __device__ __forceinline__ void prune_wave_asm(int site_base, int site_end, const uint8_t* __restrict__ msa, int L, int n_w,
                                                const WalkOp* __restrict__ wops, pmat_ptr pm, unsigned ctoff,
                                                const double* tiptab, const double* naive_tab,
-                                               const double* __restrict__ p4, double (&lik)[2][5], int (&scl)[2]) {
-  __attribute__((aligned(16))) double out_mem[10];                                      // a[2][4], then the packed scaler counts
-  __attribute__((aligned(16))) double deep_mem[(kDepth > 1 ? kDepth - 1 : 1) * 8];     // stack slots 1.. : [slot][site][4]
+                                               const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
+  static_assert(S == 2 || S == 4, "the assembly walk exists for two and four sites per lane");
+  __attribute__((aligned(16))) double out_mem[4 * S + 2];                                   // a[S][4], then the packed scaler counts
+  __attribute__((aligned(16))) double deep_mem[(kDepth > 1 ? kDepth - 1 : 1) * 4 * S];     // stack slots 1.. : [slot][site][4]
   const uint8_t* msa_m = msa - L;
   const unsigned tip_lds = (unsigned)(size_t)(lds_ptr)tiptab;
   const int last_site = site_end - 1;
-  asm volatile(
-#include "lh_prune_walk_asm.inc"
-      :
-      : [nw] "s"(n_w), [wops] "s"(wops), [pm] "s"(pm), [ctoff] "s"(ctoff), [msa] "s"(msa_m), [L] "s"(L), [tip] "s"(tip_lds),
-        [site0] "s"(site_base), [last] "s"(last_site), [out] "v"((private_ptr)out_mem), [deep] "v"((private_ptr)deep_mem)
-      : "memory", "vcc", "scc", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19",
-        "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36",
-        "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
-        "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70",
-        "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43",
-        "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60",
-        "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77",
-        "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
-        "s95", "s96", "s97", "s98", "s99");
-  double a[2][4];
-  int scal[2];
+  if constexpr (S == 2) {
+    asm volatile(
+#include "lh_prune_walk_asm_s2.inc"
+        :
+        : LH_WALK_ASM_OPERANDS
+        : "memory", "vcc", "scc",
+#include "lh_prune_walk_clobbers_s2.inc"
+    );
+  } else {
+    asm volatile(
+#include "lh_prune_walk_asm_s4.inc"
+        :
+        : LH_WALK_ASM_OPERANDS
+        : "memory", "vcc", "scc",
+#include "lh_prune_walk_clobbers_s4.inc"
+    );
+  }
+  double a[S][4];
+  int scal[S];
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < S; ++s)
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[s][i] = out_mem[s * 4 + i];
-  const unsigned packed = reinterpret_cast<const unsigned*>(out_mem)[16];
-  scal[0] = (int)(packed & 0xffffu);
-  scal[1] = (int)(packed >> 16);
-  close_naive_branch<2>(a, scal, naive_tab, p4, lik, scl);
+  const unsigned* packed = reinterpret_cast<const unsigned*>(out_mem + 4 * S);
+#pragma unroll
+  for (int s = 0; s < S; ++s) scal[s] = (int)((packed[s / 2] >> (16 * (s & 1))) & 0xffffu);
+  close_naive_branch<S>(a, scal, naive_tab, p4, lik, scl);
 }
+#undef LH_WALK_ASM_OPERANDS
 
 template <int kDepth, int S, bool kN>
 __device__ __forceinline__ void prune_wave_ct(int site0, int site_end, const uint8_t* __restrict__ msa, int L, int n_w,
@@ -1089,9 +1097,9 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
   if (two_sites) {
     site0 = tile0 + wave * (64 * kS) + lane;
     n_own = kS;
-    if constexpr (kAsm && kS == 2 && !kN)
-      prune_wave_asm<kDepth>(tile0 + wave * 128, site_end, msa, L, n_w, wops + (size_t)sample * n_ops, pm,
-                             (unsigned)((T - 3 > 0 ? T - 3 : 0) * 128), tiptab, naive_tab, p4, lik, scl);
+    if constexpr (kAsm && !kN)
+      prune_wave_asm<kDepth, kS>(tile0 + wave * (64 * kS), site_end, msa, L, n_w, wops + (size_t)sample * n_ops, pm,
+                                 (unsigned)((T - 3 > 0 ? T - 3 : 0) * 128), tiptab, naive_tab, p4, lik, scl);
     else
       prune_wave_ct<kDepth, kS, kN>(site0, site_end, msa, L, n_w, desc, pm, tiptab, ctab, naive_tab, p4, lik, scl);
   } else {
@@ -1181,6 +1189,12 @@ LH_PRUNE_CT_KERNEL(prune_kernel_ct6, 6)
 LH_PRUNE_CT_KERNEL(prune_kernel_ct5, 5)
 LH_PRUNE_CT_KERNEL(prune_kernel_ct4, 4)
 #undef LH_PRUNE_CT_KERNEL
+// Four sites per lane (assembly walk only): the per-op instructions that do not depend on the site count -- loads of
+// the matrix, descriptor, branches, waits -- are paid once for twice the sites; 156 VGPRs, three waves per SIMD.
+template <int kDepth, bool kFused>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))) prune_kernel_ct_s4(LH_PRUNE_CT_PARAMS) {
+  prune_body_ct<kDepth, false, kFused, 4, true>(LH_PRUNE_CT_ARGS);
+}
 // pmat_w: the scratch area (see prune_body); written in the prologue, read back after the barrier.
 #define LH_PRUNE_PARAMS                                                                                     \
   int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, int n_ops,               \
@@ -1240,7 +1254,15 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   const int cap = cap_env >= 64 ? std::min(cap_env, two ? 1024 : 512) : two ? 1024 : 512;
   const int tiles = (L + cap - 1) / cap;
   const int tile = (L + tiles - 1) / tiles;
-  const int spl = 128;  // sites per two-site wave
+  // Four sites per lane when the assembly walk runs and a tile is (nearly) whole multiples of 256 sites -- configs[2]:
+  // 253 patterns = one four-site wave per rate; LH_K1_S2: test hook that keeps two sites per lane.
+  static const bool cxx_walk = getenv("LH_K1_CXX_WALK") != nullptr;
+  static const bool s2_env = getenv("LH_K1_S2") != nullptr;
+  const bool use_asm = !cxx_walk && !fam.msa_mixed_n;
+  // (not for large trees: 160 KB / tip table < 3 workgroups means the segmented form below, which has two-site waves)
+  const bool s4 = use_asm && !s2_env && (tile % 256 == 0 || tile % 256 > 192) && (size_t)T * 128 * 3 <= 160 * 1024 &&
+                  getenv("LH_K1_SEGMENTS") == nullptr;
+  const int spl = s4 ? 256 : 128;  // sites per multi-site wave
   int n2 = 0, n1;
   if (two) {
     n2 = tile / spl;
@@ -1294,14 +1316,14 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   // scratch memory, so any depth up to 16 runs it).  Three register budgets -- the launcher takes the tightest one whose
   // occupancy the tip tables allow -- and, for alignments without N, the walk in assembly (LH_K1_CXX_WALK: test hook
   // that keeps the C++ walk).
-  static const bool cxx_walk = getenv("LH_K1_CXX_WALK") != nullptr;
-  const bool use_asm = !cxx_walk && !fam.msa_mixed_n;
 #ifndef LH_EXP_CT_BUDGET
 #define LH_EXP_CT_BUDGET 6
 #endif
 #define LH_LAUNCH_BUDGET(D, N, F, A)                          \
   {                                                           \
-    if (lds_waves >= 6 && LH_EXP_CT_BUDGET >= 6)              \
+    if (s4 && A)                                              \
+      LH_LAUNCH_CT((prune_kernel_ct_s4<D, F>))                \
+    else if (lds_waves >= 6 && LH_EXP_CT_BUDGET >= 6)         \
       LH_LAUNCH_CT((prune_kernel_ct6<D, N, F, A>))            \
     else if (lds_waves >= 5 && LH_EXP_CT_BUDGET >= 5)         \
       LH_LAUNCH_CT((prune_kernel_ct5<D, N, F, A>))            \
