@@ -89,8 +89,9 @@ class HipLibrary:
         lib.lh_profile_enable.argtypes = [C.c_void_p, C.c_int]
         lib.lh_family_set_extended_range.argtypes = [C.c_void_p, C.c_int]
         lib.lh_profile_read.argtypes = [C.c_void_p, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_int64)]
-        lib.lh_set_device.argtypes = [C.c_int32]
-        lib.lh_family_status.argtypes = [C.c_void_p]
+        if hasattr(lib, "lh_set_device"):      # (absent from round-2 builds loaded through LH_LIB_DIR for comparisons)
+            lib.lh_set_device.argtypes = [C.c_int32]
+            lib.lh_family_status.argtypes = [C.c_void_p]
 
     def error(self):
         return self.lib.lh_last_error().decode()

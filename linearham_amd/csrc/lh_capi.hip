@@ -357,7 +357,7 @@ int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_
 size_t k1_bytes_per_sample(const lh_family* f, int T, int R) {
   const lh::PruneWsSizes z = lh::prune_ws_sizes(T, f->host.msa_mixed_n != 0);
   const size_t n_ops = (size_t)std::max(T - 2, 1);
-  return sizeof(double) * R * z.scratch_doubles_per_rate + n_ops * (sizeof(int2) + sizeof(int32_t)) +
+  return sizeof(double) * R * z.scratch_doubles_per_rate + n_ops * (sizeof(int2) + sizeof(double)) +
          z.tabs_per_sample * sizeof(int4) + sizeof(int4);
 }
 
@@ -365,7 +365,7 @@ int ensure_workspace(lh_family* f, int n, int R, int T) {
   Workspace& w = f->ws;
   if (n <= w.n_cap && R == w.R && T == w.T) return 0;
   void** bufs[] = {(void**)&w.rates,         (void**)&w.eig,        (void**)&w.site_lik,   (void**)&w.site_scal,
-                   (void**)&w.prune.scratch, (void**)&w.prune.wops, (void**)&w.prune.mats, (void**)&w.prune.tabs,
+                   (void**)&w.prune.scratch, (void**)&w.prune.wops, (void**)&w.prune.wlen, (void**)&w.prune.tabs,
                    (void**)&w.prune.hdr};
   for (void** b : bufs) {
     if (*b) LH_HIP(hipFree(*b));
@@ -381,7 +381,7 @@ int ensure_workspace(lh_family* f, int n, int R, int T) {
   const size_t n_ops = (size_t)std::max(T - 2, 1);
   LH_HIP(hipMalloc((void**)&w.prune.scratch, sizeof(double) * cap * R * z.scratch_doubles_per_rate));
   LH_HIP(hipMalloc((void**)&w.prune.wops, sizeof(int2) * cap * n_ops));
-  LH_HIP(hipMalloc((void**)&w.prune.mats, sizeof(int32_t) * cap * n_ops));
+  LH_HIP(hipMalloc((void**)&w.prune.wlen, sizeof(double) * cap * n_ops));
   LH_HIP(hipMalloc((void**)&w.prune.tabs, sizeof(int4) * cap * z.tabs_per_sample));
   LH_HIP(hipMalloc((void**)&w.prune.hdr, sizeof(int4) * cap));
   w.prune.err_flag = f->err_flag;
@@ -687,7 +687,7 @@ void lh_family_destroy(lh_family* f) {
   DeviceGuard guard(f);
   for (void* p : f->allocs) (void)hipFree(p);
   Workspace& w = f->ws;
-  void* bufs[] = {w.rates,    w.eig,       w.site_lik, w.site_scal, w.prune.scratch, w.prune.wops, w.prune.mats,
+  void* bufs[] = {w.rates,    w.eig,       w.site_lik, w.site_scal, w.prune.scratch, w.prune.wops, w.prune.wlen,
                   w.prune.tabs, w.prune.hdr, f->fws.gem, f->fws.jem,  f->fws.gcnt,     f->fws.jrs,   f->fws.dxf,
                   f->fws.dxc};
   for (void* b : bufs)

@@ -30,7 +30,7 @@ struct PruneWs {
   double* scratch;    // per (sample, rate): [n_mat + n_tab][16] P-matrices (walk order, then the cherry branches'),
                       // then [n_tab][E][4] cherry tables, E = 16 or 25
   int2* wops;         // [n][T-2] walk-op descriptors
-  int32_t* mats;      // [n][T-2] node whose branch matrix i of the list is
+  double* wlen;       // [n][T-2] branch length of inner-branch matrix i of the prologue's list (walk order, then the tables')
   int4* tabs;         // [n][(T-1)/2] cherry tables: tip y, tip z, the cherry's node
   int4* hdr;          // [n] walk ops, matrices, tables, error (malformed schedule: the sample's results are NaN)
   int32_t* err_flag;  // set when any sample of any launch had a malformed schedule (lh_family_status reads and clears it)

@@ -882,19 +882,23 @@ __device__ __forceinline__ void matvec_v(const double (&p)[16], const double (&a
 // consumes (in that order) and the list of cherry tables.  A malformed schedule gets an empty walk, hdr.w = 1 (K1
 // then leaves NaN) and sets *err_flag, which lh_family_status reports: device-resident schedules are not trusted.
 __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int max_depth, int tabs_stride, int use_tables,
-                                                            const int32_t* __restrict__ ops, int2* __restrict__ wops,
-                                                            int32_t* __restrict__ mats, int4* __restrict__ tabs,
+                                                            const int32_t* __restrict__ ops,
+                                                            const double* __restrict__ brlen, int2* __restrict__ wops,
+                                                            double* __restrict__ wlen, int4* __restrict__ tabs,
                                                             int4* __restrict__ hdr, int32_t* err_flag) {
   const int smp = blockIdx.x * 64 + threadIdx.x;
   if (smp >= n) return;
   const int n_ops = T - 2, nodes = 2 * T - 2;
   const int4* __restrict__ o = reinterpret_cast<const int4*>(ops) + (size_t)smp * n_ops;
   int2* wo = wops + (size_t)smp * n_ops;
-  int32_t* ml = mats + (size_t)smp * n_ops;
+  // branch length of every inner-branch matrix K1's prologue computes, in the order it stores them: the walk's
+  // matrices in walk order, then the cherry branches' (table c at n_mat + c, written below once n_mat is known)
+  double* ml = wlen + (size_t)smp * n_ops;
+  const double* __restrict__ bl = brlen + (size_t)smp * nodes;
   int4* tl = tabs + (size_t)smp * tabs_stride;
   int depth = 0, n_w = 0, n_mat = 0, n_tab = 0;
   int bdepth = 0;  // stack depth of the schedule as written (depth: of the rewritten walk, which pushes less)
-  int pend[16];    // per stack slot of the rewritten walk: where the pushed subtree's branch node goes in `mats`
+  int pend[16];    // per stack slot of the rewritten walk: where the pushed subtree's branch length goes in `wlen`
   bool bad = false;
   auto tip_ok = [&](int v) { return v >= 1 && v < T; };
   auto inner_ok = [&](int v) { return v >= T && v < nodes; };
@@ -919,7 +923,7 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
                  inner_ok(nx.z) && n_tab < tabs_stride) {
         // the cherry is the whole second subtree: the first one stays in the accumulator, nothing is pushed
         w = make_int2(W_CTAB_ACC | WOP_MATRIX | WOP_HAS_B | (op.y << 16), op.z | (1 << 16));
-        ml[n_mat++] = nx.y;
+        ml[n_mat++] = bl[nx.y];
         tl[n_tab++] = make_int4(op.y, op.z, nx.z, 0);
         step = 2;
       } else {
@@ -942,7 +946,7 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
         bad = true;
       } else {
         w = make_int2(W_TIP_ACC | WOP_MATRIX | (op.y << 16), 1 | (1 << 16));
-        ml[n_mat++] = op.z;
+        ml[n_mat++] = bl[op.z];
       }
     } else if (kind == OP_POP_ACC) {
       if (push || bdepth < 1 || depth < 1 || op.w != bdepth - 1 || !inner_ok(op.y) || !inner_ok(op.z) || n_mat >= n_ops) {
@@ -950,8 +954,8 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
       } else {
         --depth, --bdepth;
         w = make_int2(W_POP | WOP_MATRIX | (depth << WOP_POP_SHIFT) | (1 << 16), 1 | (1 << 16));
-        ml[pend[depth]] = op.y;  // the popped child: its matrix was applied at the push
-        ml[n_mat++] = op.z;      // the child whose CLV is in the accumulator
+        ml[pend[depth]] = bl[op.y];  // the popped child: its matrix was applied at the push
+        ml[n_mat++] = bl[op.z];      // the child whose CLV is in the accumulator
       }
     } else {
       bad = true;
@@ -965,6 +969,7 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
     hdr[smp] = make_int4(0, 0, 0, 1);
     atomicOr(err_flag, 1);
   } else {
+    for (int c = 0; c < n_tab; ++c) ml[n_mat + c] = bl[tl[c].z];
     hdr[smp] = make_int4(n_w, n_mat, n_tab, 0);
   }
 }
@@ -974,7 +979,7 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
 // rate_stride doubles: [n_mat + n_tab][16] P-matrices | [n_tab][E][4] tables.
 template <int kDepth, bool kN, bool kFused, int kS = 2, bool kAsm = false>
 __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, const uint8_t* __restrict__ msa, int L,
-                                              int T, const int2* __restrict__ wops, const int32_t* __restrict__ mats,
+                                              int T, const int2* __restrict__ wops, const double* __restrict__ wlen,
                                               const int4* __restrict__ tabs, int tabs_stride,
                                               const int4* __restrict__ hdr, const double* __restrict__ brlen,
                                               const double* __restrict__ rates, const double* __restrict__ eig,
@@ -1003,33 +1008,65 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
   double* tiptab = reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);
   const double* naive_tab = tiptab;
   const int4* __restrict__ tl = tabs + (size_t)sample * tabs_stride;
-  // the walk descriptors go to LDS behind the tip tables (one copy per workgroup)
+  // the walk descriptors go to LDS behind the tip tables (one copy per workgroup) for the waves that run the C++ walk
   WalkOp* desc = reinterpret_cast<WalkOp*>(reinterpret_cast<double*>(smem2) + (size_t)(kFused ? R : 1) * T * 16);
+  // (the assembly walk fetches its descriptors from global memory with scalar loads: this copy also brings their
+  // lines into L2 before the walk asks for them -- without it every eighth op waited for HBM)
   for (int i = tid; i < n_w; i += blockDim.x) desc[i] = wops[(size_t)sample * n_ops + i];
   LH_CT_PHASE(0)
 
-  // Prologue, first half: the P-matrices of this (sample, rate), one thread per matrix: the walk's inner-branch
-  // matrices in walk order and the cherry branches' (for the tables) to the scratch area, the tip branches' into
-  // the LDS tip table (column by column, as the walk gathers them).
+  // Prologue, first half: the P-matrices of this (sample, rate), one thread per matrix (K0c left every matrix's
+  // branch length in the order they are stored): the walk's inner-branch matrices to the scratch area, the tip
+  // branches' into the LDS tip table (column by column, as the walk gathers them), the cherry branches' for the
+  // tables.  Without N a table's four state rows are built by the four lanes of a QUAD, and the quad's first lane
+  // computes the cherry branch's matrix here and keeps it in registers: it reaches the other three through DPP in the
+  // second half, not through memory (tables beyond nthr / 4, and all tables of alignments with N, take the path
+  // through the scratch area).
+  constexpr bool kQuad = !kN;
+  const int n_q = kQuad ? min(n_tab, nthr >> 2) : 0;
+  const bool pc_lane = kQuad && (rtid & 3) == 0 && (rtid >> 2) < n_q;
+  int4 tcell = make_int4(1, 1, 0, 0);
+  if (kQuad && (rtid >> 2) < n_q) tcell = tl[rtid >> 2];  // the quad's table: requested now, used after the barrier
+  double pcq[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) pcq[i] = 0.0;
   {
     const double* __restrict__ e = eig + (size_t)sample * 36;
     const double rt = rates[(size_t)sample * R + rate];
     const double* __restrict__ bl = brlen + (size_t)sample * (2 * (size_t)T - 2);
-    const int32_t* __restrict__ ml = mats + (size_t)sample * n_ops;
+    const double* __restrict__ wl = wlen + (size_t)sample * n_ops;
     double P[4][4];
-    const int n_inner = n_mat + n_tab;
-    for (int it = rtid; it < n_inner + T; it += nthr) {
-      if (it < n_inner) {
-        const int node = it < n_mat ? ml[it] : tl[it - n_mat].z;
-        compute_pmatrix(e, bl[node] * rt, P);
-        double* o = pw + (size_t)it * 16;
+    // One matrix per thread and round.  Round 0: a quad's first lane takes its cherry matrix, every other thread the
+    // item of its rank in the common list (walk matrices | cherry matrices n_q.. (scratch path) | tips); later rounds:
+    // the rest of the list, nthr items at a time.  A single compute_pmatrix per round, whatever the item's kind.
+    const int n_rest = n_tab - n_q;
+    const int n_list = n_mat + n_rest + T;
+    const int round1 = nthr - n_q;  // list items taken in round 0
+    const int n_rounds = 1 + (n_list > round1 ? (n_list - round1 + nthr - 1) / nthr : 0);
+    for (int round = 0; round < n_rounds; ++round) {
+      const bool is_pc = round == 0 && pc_lane;
+      const int it = round == 0 ? rtid - min(n_q, (rtid + 3) >> 2) : round1 + rtid + (round - 1) * nthr;
+      const bool in_list = !is_pc && it < n_list;
+      const bool inner = in_list && it < n_mat + n_rest;
+      const int slot = it < n_mat ? it : it + n_q;  // matrix slot in the scratch area ([n_mat + c] for table c)
+      const int j = it - (n_mat + n_rest);          // tip
+      double t = 0.0;
+      if (is_pc) t = wl[n_mat + (rtid >> 2)];
+      else if (inner) t = wl[slot];
+      else if (in_list) t = bl[j];
+      compute_pmatrix(e, t * rt, P);
+      if (is_pc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pcq[i * 4 + q] = P[i][q];
+      } else if (inner) {
+        double* o = pw + (size_t)slot * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) o[i * 4 + q] = P[i][q];
-      } else {
-        const int j = it - n_inner;
-        compute_pmatrix(e, bl[j] * rt, P);
+      } else if (in_list) {
         double* o = tiptab + j * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1039,43 +1076,53 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
     }
   }
   LH_CT_PHASE(1)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __threadfence_block();
-  __syncthreads();
+  // the tip tables are complete (LDS); the scratch-area stores need to have landed only if a table goes that way
+  if (n_tab > n_q) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   LH_CT_PHASE(2)
   // Second half: the cherry tables, one thread per (table, state of the first tip): P_c (tipcol_y o tipcol_z) for
   // every state of the second tip -- the very operations the unfused walk performs per lane, done once per state pair.
-#ifdef LH_EXP_CT_NOPHASEC  // timing experiment: no tables are built (results wrong)
-  for (int it = rtid; it < 0; it += nthr) {
-#else
-  for (int it = rtid; it < n_tab * SY; it += nthr) {
-#endif
-    const int c = it / SY, sy = it - c * SY;
-    const int4 t = tl[c];
-    double pc[16];
-    {
-      const double2* q = reinterpret_cast<const double2*>(pw + (size_t)(n_mat + c) * 16);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const double2 v = q[j];
-        pc[2 * j] = v.x;
-        pc[2 * j + 1] = v.y;
-      }
-    }
+  auto build_rows = [&](const double (&pc)[16], int c, int sy, int ty, int tz) {
     double py[4];
-    tip_column<kN>(tiptab, t.x, sy, py);
+    tip_column<kN>(tiptab, ty, sy, py);
     double2* o = reinterpret_cast<double2*>(ctab) + ((size_t)c * E + (size_t)sy * SY) * 2;
 #pragma unroll
     for (int sz = 0; sz < SY; ++sz) {
       double pz[4], pr[4], x[4];
-      tip_column<kN>(tiptab, t.y, sz, pz);
+      tip_column<kN>(tiptab, tz, sz, pz);
 #pragma unroll
       for (int i = 0; i < 4; ++i) pr[i] = py[i] * pz[i];
       matvec_v(pc, pr, x);
       o[2 * sz] = make_double2(x[0], x[1]);
       o[2 * sz + 1] = make_double2(x[2], x[3]);
     }
+  };
+#ifndef LH_EXP_CT_NOPHASEC
+  if constexpr (kQuad) {
+    // every lane of the wave takes part in the DPP moves (quad_perm [0,0,0,0]: the quad's first lane to all four)
+    double pc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int lo = __builtin_amdgcn_mov_dpp(__double2loint(pcq[i]), 0, 0xf, 0xf, true);
+      const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(pcq[i]), 0, 0xf, 0xf, true);
+      pc[i] = __hiloint2double(hi, lo);
+    }
+    if ((rtid >> 2) < n_q) build_rows(pc, rtid >> 2, rtid & 3, tcell.x, tcell.y);
   }
+  for (int it = rtid; it < (n_tab - n_q) * SY; it += nthr) {
+    const int c = n_q + it / SY, sy = it - (it / SY) * SY;
+    const int4 t = tl[c];
+    double pc[16];
+    const double2* q = reinterpret_cast<const double2*>(pw + (size_t)(n_mat + c) * 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double2 v = q[j];
+      pc[2 * j] = v.x;
+      pc[2 * j + 1] = v.y;
+    }
+    build_rows(pc, c, sy, t.x, t.y);
+  }
+#endif
   LH_CT_PHASE(3)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __threadfence_block();
@@ -1173,12 +1220,12 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
 
 #define LH_PRUNE_CT_PARAMS                                                                                          \
   int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, const int2 *__restrict__ wops,   \
-      const int32_t *__restrict__ mats, const int4 *__restrict__ tabs, int tabs_stride,                             \
+      const double *__restrict__ wlen, const int4 *__restrict__ tabs, int tabs_stride,                              \
       const int4 *__restrict__ hdr, const double *__restrict__ brlen, const double *__restrict__ rates,            \
       const double *__restrict__ eig, double *pmat_w, size_t rate_stride, const double *__restrict__ pi,           \
       double *__restrict__ site_lik, int32_t *__restrict__ site_scal
 #define LH_PRUNE_CT_ARGS \
-  n2, tile, R, wpr, msa, L, T, wops, mats, tabs, tabs_stride, hdr, brlen, rates, eig, pmat_w, rate_stride, pi, site_lik, site_scal
+  n2, tile, R, wpr, msa, L, T, wops, wlen, tabs, tabs_stride, hdr, brlen, rates, eig, pmat_w, rate_stride, pi, site_lik, site_scal
 #define LH_PRUNE_CT_KERNEL(NAME, WAVES)                                                              \
   template <int kDepth, bool kN, bool kFused, bool kAsm>                                             \
   __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) NAME(    \
@@ -1240,7 +1287,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   // K0c: every schedule is checked on the device (and rewritten into walk ops) before K1 indexes anything with it
   static const bool no_tables = getenv("LH_K1_NO_TABLES") != nullptr;  // experiment: no cherry tables (every cherry walked)
   hipLaunchKernelGGL(schedule_check_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, T, max_depth,
-                     (int)sizes.tabs_per_sample, no_tables ? 0 : 1, ops, ws.wops, ws.mats, ws.tabs, ws.hdr, ws.err_flag);
+                     (int)sizes.tabs_per_sample, no_tables ? 0 : 1, ops, brlen, ws.wops, ws.wlen, ws.tabs, ws.hdr, ws.err_flag);
   if (L == 0) return R;       // nothing but all-N padding (K2a reads no plane at all)
   double* pmat = ws.scratch;
   const size_t rate_stride = sizes.scratch_doubles_per_rate;
@@ -1254,13 +1301,14 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   const int cap = cap_env >= 64 ? std::min(cap_env, two ? 1024 : 512) : two ? 1024 : 512;
   const int tiles = (L + cap - 1) / cap;
   const int tile = (L + tiles - 1) / tiles;
-  // Four sites per lane when the assembly walk runs and a tile is (nearly) whole multiples of 256 sites -- configs[2]:
-  // 253 patterns = one four-site wave per rate; LH_K1_S2: test hook that keeps two sites per lane.
+  // LH_K1_S4: the assembly walk with FOUR sites per lane (three waves per SIMD) where a tile is (nearly) whole
+  // multiples of 256 sites -- measured on configs[2] (253 patterns = one four-site wave per rate): the same time per op
+  // as two sites per lane at six waves per SIMD, so it is not the default; kept, tested, behind the switch.
   static const bool cxx_walk = getenv("LH_K1_CXX_WALK") != nullptr;
-  static const bool s2_env = getenv("LH_K1_S2") != nullptr;
+  static const bool s4_env = getenv("LH_K1_S4") != nullptr;
   const bool use_asm = !cxx_walk && !fam.msa_mixed_n;
   // (not for large trees: 160 KB / tip table < 3 workgroups means the segmented form below, which has two-site waves)
-  const bool s4 = use_asm && !s2_env && (tile % 256 == 0 || tile % 256 > 192) && (size_t)T * 128 * 3 <= 160 * 1024 &&
+  const bool s4 = use_asm && s4_env && (tile % 256 == 0 || tile % 256 > 192) && (size_t)T * 128 * 3 <= 160 * 1024 &&
                   getenv("LH_K1_SEGMENTS") == nullptr;
   const int spl = s4 ? 256 : 128;  // sites per multi-site wave
   int n2 = 0, n1;
@@ -1306,7 +1354,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
     if (lds > 64 * 1024)                                                                                      \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                    \
-    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, R, wpr, fam.msa, L, T, ws.wops, ws.mats, ws.tabs, \
+    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, R, wpr, fam.msa, L, T, ws.wops, ws.wlen, ws.tabs, \
                        (int)sizes.tabs_per_sample, ws.hdr, brlen, rates, eig, pmat, rate_stride, pi, site_lik,  \
                        site_scal);                                                                            \
   }

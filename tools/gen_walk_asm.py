@@ -54,6 +54,21 @@ def pair(r):
     return "v[%d:%d]" % (r, r + 1)
 
 
+def weave(valu, other, ratio=2):
+    """The two independent instruction lists as one stream, `ratio` vector instructions per other one: a wave whose
+    scalar / memory instructions sit between its vector ones keeps feeding the vector unit while they issue."""
+    if "noweave" in OPTS:
+        return other + valu
+    out, i, j = [], 0, 0
+    while i < len(valu) or j < len(other):
+        out += valu[i:i + ratio]
+        i += ratio
+        if j < len(other):
+            out.append(other[j])
+            j += 1
+    return out
+
+
 def spair(r):
     return "s[%d:%d]" % (r, r + 1)
 
@@ -112,7 +127,7 @@ class Gen:
                     "global_load_dwordx4 v[%d:%d], v%d, s[74:75] offset:16" % (dst + 8 * s + 4, dst + 8 * s + 7, r.tmp + s)]
         return out + ["s_add_i32 s76, s76, 0x200"]
 
-    def states(self, dx, dy):
+    def states(self, dx, dy, split=False):
         """Tip states of the op whose descriptor is s<dx>, s<dy>: tip A always, B and C on their flags."""
         r, S = self.r, self.S
         if "nostate" in OPTS:   # states from arithmetic, no memory (results wrong)
@@ -120,16 +135,19 @@ class Gen:
             for s in range(S):
                 out += ["v_add_u32_e32 v%d, s87, v%d" % (r.sa + s, r.usite + s), "v_and_b32_e32 v%d, 3, v%d" % (r.sa + s, r.sa + s),
                         "v_mov_b32_e32 v%d, v%d" % (r.sb + s, r.sa + s), "v_mov_b32_e32 v%d, v%d" % (r.sc + s, r.sa + s)]
-            return out
+            return (out, []) if split else out
 
         def loads(dst):
             o = ["s_mul_i32 s87, s87, s80"]
             o += ["v_add_u32_e32 v%d, s87, v%d" % (r.tmp + s, r.usite + s) for s in range(S)]
             o += ["global_load_ubyte v%d, v%d, s[78:79]" % (dst + s, r.tmp + s) for s in range(S)]
             return o
-        return (["s_lshr_b32 s87, s%d, 16" % dx] + loads(r.sa) +
-                ["s_bitcmp1_b32 s%d, 13" % dx, "s_cbranch_scc0 1f", "s_and_b32 s87, s%d, 0xffff" % dy] + loads(r.sb) +
-                ["1:", "s_bitcmp1_b32 s%d, 14" % dx, "s_cbranch_scc0 2f", "s_lshr_b32 s87, s%d, 16" % dy] + loads(r.sc) + ["2:"])
+        part_a = ["s_lshr_b32 s87, s%d, 16" % dx] + loads(r.sa)
+        part_bc = (["s_bitcmp1_b32 s%d, 13" % dx, "s_cbranch_scc0 1f", "s_and_b32 s87, s%d, 0xffff" % dy] + loads(r.sb) +
+                   ["1:", "s_bitcmp1_b32 s%d, 14" % dx, "s_cbranch_scc0 2f", "s_lshr_b32 s87, s%d, 16" % dy] + loads(r.sc) + ["2:"])
+        if split:
+            return part_a, part_bc
+        return part_a + part_bc
 
     def deep_addr(self, slot_reg):
         sh = {2: 6, 4: 7}[self.S]                         # a slot is 32 S bytes per lane
@@ -190,18 +208,21 @@ class Gen:
         add(["lh_walk_ctip_np:"] + ctip + ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + ROTATE + PREFETCH + self.product(U, X) + self.states(70, 71) +
             ["s_branch lh_walk_tail"])
         # tip into accumulator: a = tipcol_A * (P a)
+        st_a, st_bc = self.states(70, 71, split=True)
+        mv = self.matvec(X)
+        half = len(mv) // 2
         add(["; tip into accumulator", "lh_walk_tip:"] + self.p_load() + self.tip_column(U, r.sa, tip_a) + ["s_waitcnt lgkmcnt(0)"] +
-            ROTATE + P_ADV + PREFETCH + self.states(70, 71) + self.matvec(X) + self.product(U, X) + ["s_branch lh_walk_tail"])
+            ROTATE + weave(mv[:half], P_ADV + PREFETCH + st_a) + st_bc + mv[half:] + self.product(U, X) + ["s_branch lh_walk_tail"])
         # cherry table into accumulator: a = table * (P a)
         add(["; cherry table into accumulator", "lh_walk_ctab:"] + self.p_load() + self.table_entry(U) + ["s_waitcnt lgkmcnt(0)"] + ROTATE +
-            P_ADV + PREFETCH + self.matvec(X) + ["s_waitcnt vmcnt(0)"] + self.product(U, X) + self.states(70, 71) + ["s_branch lh_walk_tail"])
+            weave(mv, P_ADV + PREFETCH, 4) + ["s_waitcnt vmcnt(0)"] + self.product(U, X) + self.states(70, 71) + ["s_branch lh_walk_tail"])
         # pop: a = pending sibling * (P a)
         add(["; pop", "lh_walk_pop:"] + self.p_load() + ["s_bfe_u32 s88, s68, 0x40009", "s_cmp_eq_u32 s88, 0",
                                                         "s_cbranch_scc1 lh_walk_pop0", "s_add_i32 s89, s88, -1"] +
             self.deep_addr("s89") + self.block_io("scratch_load_dwordx4", U) + ["s_waitcnt lgkmcnt(0)"] + ROTATE + P_ADV + PREFETCH +
             self.matvec(X) + ["s_waitcnt vmcnt(0)"] + self.product(U, X) + self.states(70, 71) +
-            ["s_branch lh_walk_tail", "lh_walk_pop0:", "s_waitcnt lgkmcnt(0)"] + ROTATE + P_ADV + PREFETCH + self.states(70, 71) +
-            self.matvec(X) + self.product(ST0, X))
+            ["s_branch lh_walk_tail", "lh_walk_pop0:", "s_waitcnt lgkmcnt(0)"] + ROTATE + weave(mv[:half], P_ADV + PREFETCH + st_a) + st_bc +
+            mv[half:] + self.product(ST0, X))
         # tail: 2^256 rescaling test on the high words (libpll's per-site scalers), next op
         add(["; ---- rescaling test, next op ------------------------------------------------------------------------",
              "lh_walk_tail:"])
