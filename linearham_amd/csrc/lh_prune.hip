@@ -733,14 +733,26 @@ __device__ __forceinline__ void prune_wave_ct(int site0, int site_end, const uin
 
 }  // namespace
 
-// The older form of the workgroup, kept for what the cherry-table form does not cover: large trees (kSeg: tip table
-// built a schedule segment at a time) and deep stacks (one site per lane).  One workgroup per (site tile, rate,
-// sample); block = n2 two-site waves followed by n1 one-site waves; the tile's sites are blockIdx.x * tile ..
-// +tile-1 (clipped to L).  It walks the schedule as lh_schedule_tree wrote it (K0c has checked it: hdr.w).
-template <int kDepth, bool kTwo, bool kN, bool kSeg = false>
+// The register-stack form of the workgroup (round 2's kernel): it walks the schedule as lh_schedule_tree wrote it.
+// It is what configs[2]-like shapes run (fused: all rates in one workgroup) -- measured against the cherry-table
+// form below it has the shorter prologue (1.2 against 2.5 ms per 49 152 with every op skipped) and loses less there
+// than the tables save in the walk -- and what large trees run (kSeg: tip table built a schedule
+// segment at a time).  Block = n2 two-site waves followed by n1 one-site waves per rate; the tile's sites are
+// blockIdx.x * tile .. +tile-1 (clipped to L).
+//
+// Device-resident schedules are not trusted.  hdr != nullptr: K0c has checked this launch's schedules (hdr[sample].w);
+// hdr == nullptr (fused form): the prologue checks them itself -- every op's fields while it builds the matrix list,
+// every entry of the list against the op it names -- and a malformed schedule leaves NaN and raises *err_flag.
+//
+// kFused: the workgroup carries ALL rate categories of its sample (waves [r * wpr, (r + 1) * wpr) walk
+// rate r with their own LDS tip table) and, when the walks are done, mixes them itself:
+// site_lik[n][1][5][L] then holds the rate mixture (equal weights, scalers aligned to the smallest, the
+// arithmetic K2a would do) and K2a runs with a single "rate".  A quarter of the output traffic, and K2a's
+// bandwidth-bound assembly shrinks to a quarter.  Used when R * wpr <= 8 waves and the R tip tables fit.
+template <int kDepth, bool kTwo, bool kN, bool kFused, bool kSeg = false>
 __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, const uint8_t* __restrict__ msa, int L,
                                            int T, int n_ops, const int32_t* __restrict__ ops,
-                                           const int4* __restrict__ hdr,
+                                           const int4* __restrict__ hdr, int32_t* err_flag,
                                            const double* __restrict__ brlen, const double* __restrict__ rates,
                                            const double* __restrict__ eig, double* pmat_w, size_t rate_stride,
                                            const double* __restrict__ pi,
@@ -748,36 +760,35 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
   extern __shared__ double2 smem2[];
   LH_K1_PHASE(0)
   const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rate = (int)blockIdx.y;
-  const int nthr = (int)blockDim.x;
-  const int rtid = tid;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rate = kFused ? wave_all / wpr : (int)blockIdx.y;
+  const int wave = kFused ? wave_all - rate * wpr : wave_all;  // within the rate
+  const int nthr = kFused ? wpr * 64 : (int)blockDim.x;       // threads working on this rate
+  const int rtid = kFused ? tid - rate * nthr : tid;
   const int sample = blockIdx.z;
-  const int lane = tid & 63;
-  const int tile0 = blockIdx.x * tile;
-  const int site_end = min(tile0 + tile, L);
-  double* lik_out = site_lik + (((size_t)sample * R + rate) * 5) * (size_t)L;
-  int32_t* scal_out = site_scal + ((size_t)sample * R + rate) * (size_t)L;
-  if (hdr[sample].w != 0) {  // K0c rejected the schedule (uniform per workgroup): no number may look like a result
-    for (int site = tile0 + tid; site < site_end; site += nthr) {
-      for (int b = 0; b < 5; ++b) lik_out[(size_t)b * L + site] = __builtin_nan("");
-      scal_out[site] = 0;
+  if (hdr != nullptr && hdr[sample].w != 0) {  // K0c rejected the schedule (uniform per workgroup): no number may look like a result
+    const int planes = kFused ? 1 : R, plane = kFused ? 0 : rate;
+    const int t0 = blockIdx.x * tile, t1 = min(t0 + tile, L);
+    for (int site = t0 + tid; site < t1; site += blockDim.x) {
+      for (int b = 0; b < 5; ++b) site_lik[(((size_t)sample * planes + plane) * 5 + b) * (size_t)L + site] = __builtin_nan("");
+      site_scal[((size_t)sample * planes + plane) * (size_t)L + site] = 0;
     }
     return;
   }
   // scratch area of one (sample, rate): the schedule's P-matrices
   const size_t pm_off = ((size_t)sample * R + rate) * rate_stride;
-  // LDS tip table [T][4][4]; large trees (kSeg): the segment slots [2 kSegOps][4][4] followed by the naive tip's entry
-  double* tiptab = reinterpret_cast<double*>(smem2);
+  // LDS tip table [T][4][4] (per rate when fused); large trees (kSeg): the segment slots [2 kSegOps][4][4]
+  // followed by the naive tip's entry
+  double* tiptab = reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);
   const double* naive_tab = kSeg ? tiptab + 2 * kSegOps * 16 : tiptab;
   const int4* __restrict__ op_ptr = reinterpret_cast<const int4*>(ops) + (size_t)sample * n_ops;
 
-  // Prologue: the P-matrices of this (sample, rate).
+  // Prologue (formerly a kernel of its own): the P-matrices of this (sample, rate).
   //   P = I + U expm1(lambda t r) U^-1   (pll_update_prob_matrices [3P])
-  // One thread per matrix.  The first half of the threads takes the schedule's ops: op k's
+  // One thread per matrix.  The first half of the rate's threads takes the schedule's ops: op k's
   // accumulator-child matrix goes to pmat[k][0], its popped-child matrix to pmat[k][1] -- global memory,
   // because the walk below wants them as SCALAR operands and scalar loads only read memory; the lines
-  // are written and, a barrier later, read back on the same CU.  The
+  // are written and, a barrier later, read back on the same CU, so they are served by its L2.  The
   // second half takes the tip branches: a tip child needs no mat-vec, P * onehot(state) is a column of
   // P, and those columns go straight into the LDS table tiptab[tip][state][4] (states A,C,G,T).
   {
@@ -786,6 +797,71 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
     const double* __restrict__ bl = brlen + (size_t)sample * (2 * (size_t)T - 2);
     double* pw = pmat_w + pm_off;
     double P[4][4];
+    if constexpr (kFused) {
+      // Packed form: the T - 3 inner-branch matrices are numbered by the schedule (lh_schedule_tree leaves each
+      // op's running count in its descriptor); every op thread notes where its one or two matrices go in a
+      // list in LDS (the same for every rate: one copy per workgroup, behind the tip tables), and after a
+      // barrier thread t of a rate takes items t, t + nthr, ... of [inner matrices | tips]: no lane idles on a
+      // cherry, none computes two matrices while its neighbours compute one.
+      uint16_t* mat_list = reinterpret_cast<uint16_t*>(reinterpret_cast<double*>(smem2) + (size_t)R * T * 16);
+      int* bad_flag = reinterpret_cast<int*>(mat_list + ((T + 1) & ~1));  // (the launcher sizes the list's slot for both)
+      const int nodes = 2 * T - 2;
+      bool bad = false;
+      if (tid == 0) *bad_flag = 0;
+      if (rate == 0) {
+        for (int k = rtid; k < n_ops; k += nthr) {
+          const int4 op = op_ptr[k];
+          const int kind = op.x & 15, rank = op.x >> OP_RANK_SHIFT;
+          const bool push = (op.x & OP_PUSH_FLAG) != 0;
+          // the op's fields: everything the walk indexes with (tips: MSA rows and tip-table entries; slots: registers)
+          bool ok = op.x >= 0 && (op.x & 0xe0) == 0 && kind <= OP_POP_ACC;
+          if (kind == OP_CHERRY) ok = ok && op.y >= 1 && op.y < T && op.z >= 1 && op.z < T && (push || k == 0);
+          if (kind == OP_TIP_ACC) ok = ok && !push && k > 0 && op.y >= 1 && op.y < T && op.z >= T && op.z < nodes;
+          if (kind == OP_POP_ACC) ok = ok && !push && k > 0 && op.y >= T && op.y < nodes && op.z >= T && op.z < nodes;
+          if (push || kind == OP_POP_ACC) ok = ok && op.w >= 0 && op.w < kDepth;
+          if (kind != OP_CHERRY) ok = ok && rank + (kind == OP_POP_ACC ? 2 : 1) <= T - 3;
+          if (!ok) {
+            bad = true;
+            continue;
+          }
+          if (kind == OP_CHERRY) continue;
+          mat_list[rank] = (uint16_t)(2 * k);          // the accumulator child's matrix: node op.z, slot [k][0]
+          if (kind == OP_POP_ACC) mat_list[rank + 1] = (uint16_t)(2 * k + 1);  // the popped child's: node op.y, slot [k][1]
+        }
+      }
+      __syncthreads();
+      LH_K1_PHASE(1)
+      const int n_inner = T - 3;
+      for (int it = rtid; it < n_inner + T; it += nthr) {
+        if (it < n_inner) {
+          // entry `it` of the list must name an op that claims it (an entry nobody wrote holds whatever LDS held)
+          const int code = mat_list[it], k = min(code >> 1, n_ops - 1);
+          const int4 op = op_ptr[k];
+          {
+            const int kind = op.x & 15;
+            if ((code >> 1) >= n_ops || op.x < 0 || kind == OP_CHERRY || kind > OP_POP_ACC || ((code & 1) && kind != OP_POP_ACC) ||
+                (op.x >> OP_RANK_SHIFT) + (code & 1) != it)
+              bad = true;
+          }
+          const int node = min(max((code & 1) ? op.y : op.z, 0), nodes - 1);
+          compute_pmatrix(e, bl[node] * rt, P);
+          double* o = pw + (size_t)k * 32 + (code & 1) * 16;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[i * 4 + q] = P[i][q];
+        } else {
+          const int j = it - n_inner;
+          compute_pmatrix(e, bl[j] * rt, P);
+          double* o = tiptab + j * 16;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
+        }
+      }
+      if (bad) atomicOr(bad_flag, 1);
+    } else {
     const int half = nthr >= 128 ? (nthr / 128) * 64 : 0;  // whole waves on either side
     const bool do_ops = half == 0 || rtid < half;
     const bool do_tips = half == 0 || rtid >= half;
@@ -822,6 +898,7 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
           for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
       }
     }
+    }
   }
   SegCtx seg{eig + (size_t)sample * 36, brlen + (size_t)sample * (2 * (size_t)T - 2),
              rates[(size_t)sample * R + rate], tiptab, rtid, nthr};
@@ -834,8 +911,25 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
   __syncthreads();
   LH_K1_PHASE(3)
 
+  if constexpr (kFused) {
+    // the prologue's verdict on the schedule (uniform: every thread reads the flag behind the barrier)
+    const int* bad_flag = reinterpret_cast<const int*>(
+        reinterpret_cast<const uint16_t*>(reinterpret_cast<double*>(smem2) + (size_t)R * T * 16) + ((T + 1) & ~1));
+    if (*bad_flag != 0) {
+      const int t0 = blockIdx.x * tile, t1 = min(t0 + tile, L);
+      for (int site = t0 + tid; site < t1; site += blockDim.x) {
+        for (int b = 0; b < 5; ++b) site_lik[((size_t)sample * 5 + b) * (size_t)L + site] = __builtin_nan("");
+        site_scal[(size_t)sample * (size_t)L + site] = 0;
+      }
+      if (tid == 0) atomicOr(err_flag, 1);
+      return;
+    }
+  }
   // P-matrices in schedule order (addresses depend on the op number only), readable from here on
   const pmat_ptr pm = pmat_after_barrier(pmat_w + pm_off);
+  const int lane = tid & 63;
+  const int tile0 = blockIdx.x * tile;
+  const int site_end = min(tile0 + tile, L);
   const double* __restrict__ p4 = pi + (size_t)sample * 4;
   // results of this wave's walk: five naive-state likelihoods and a scaler count per site
   double lik[2][5];
@@ -858,14 +952,58 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
     for (int b = 0; b < 5; ++b) lik[0][b] = lik1[0][b];
     scl[0] = scl1[0];
   }
+
+  if constexpr (!kFused) {
+    double* lik_out = site_lik + (((size_t)sample * R + rate) * 5) * (size_t)L;
+    int32_t* scal_out = site_scal + ((size_t)sample * R + rate) * (size_t)L;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int site = site0 + 64 * s;
-    if (s < n_own && site < site_end) {
+    for (int s = 0; s < 2; ++s) {
+      const int site = site0 + 64 * s;
+      if (s < n_own && site < site_end) {
 #pragma unroll
-      for (int b = 0; b < 5; ++b) lik_out[(size_t)b * L + site] = lik[s][b];
-      scal_out[site] = scl[s];
+        for (int b = 0; b < 5; ++b) lik_out[(size_t)b * L + site] = lik[s][b];
+        scal_out[site] = scl[s];
+      }
     }
+  } else {
+    // exchange through LDS (over the tip tables, which no wave needs any more), then mix the rates
+    const int pad = n2 * 128 + (wpr - n2) * 64;  // sites a rate's waves cover
+    LH_K1_PHASE(4)
+    __syncthreads();
+    LH_K1_PHASE(5)
+    double* X = reinterpret_cast<double*>(smem2);                 // [R][5][pad]
+    int* SC = reinterpret_cast<int*>(X + (size_t)R * 5 * pad);    // [R][pad]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int idx = site0 + 64 * s - tile0;
+      if (s < n_own && idx < pad) {
+#pragma unroll
+        for (int b = 0; b < 5; ++b) X[((size_t)rate * 5 + b) * pad + idx] = lik[s][b];
+        SC[rate * pad + idx] = scl[s];
+      }
+    }
+    __syncthreads();
+    // PhyloHMM::FillXmsaEmission's rate mixture (src/PhyloHMM.cpp:226-237): equal weights, scalers aligned
+    // to the smallest one -- the same operations in the same order as K2a performs on unmixed input
+    const int n_tile = site_end - tile0;
+    const double w = 1.0 / R;
+    double* lik_out = site_lik + ((size_t)sample * 5) * (size_t)L;
+    int32_t* scal_out = site_scal + (size_t)sample * (size_t)L;
+    for (int j = tid; j < 5 * n_tile; j += blockDim.x) {
+      const int b = j / n_tile, p = j - b * n_tile;
+      int smin = 0x7fffffff;
+      for (int r = 0; r < R; ++r) smin = min(smin, SC[r * pad + p]);
+      double acc = 0.0;
+      for (int r = 0; r < R; ++r) {
+        double v = X[((size_t)r * 5 + b) * pad + p];
+        const int d = SC[r * pad + p] - smin;
+        for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
+        acc += w * v;
+      }
+      lik_out[(size_t)b * L + tile0 + p] = acc;
+      if (b == 0) scal_out[tile0 + p] = smin;
+    }
+    LH_K1_PHASE(6)
   }
 }
 
@@ -1245,21 +1383,38 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))
 // pmat_w: the scratch area (see prune_body); written in the prologue, read back after the barrier.
 #define LH_PRUNE_PARAMS                                                                                     \
   int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, int n_ops,               \
-      const int32_t *__restrict__ ops, const int4 *__restrict__ hdr,                                        \
+      const int32_t *__restrict__ ops, const int4 *__restrict__ hdr, int32_t *err_flag,                     \
       const double *__restrict__ brlen, const double *__restrict__ rates, const double *__restrict__ eig,  \
       double *pmat_w, size_t rate_stride, const double *__restrict__ pi,                                   \
       double *__restrict__ site_lik, int32_t *__restrict__ site_scal
-#define LH_PRUNE_ARGS n2, tile, R, wpr, msa, L, T, n_ops, ops, hdr, brlen, rates, eig, pmat_w, rate_stride, pi, site_lik, site_scal
+#define LH_PRUNE_ARGS \
+  n2, tile, R, wpr, msa, L, T, n_ops, ops, hdr, err_flag, brlen, rates, eig, pmat_w, rate_stride, pi, site_lik, site_scal
+
+// Shallow stacks (depth <= 4, any tree up to a few hundred tips), all rates in one workgroup: two sites per lane.  The
+// walk needs ~100 VGPRs; resident waves matter more to it than a few spilled registers, as long as the LDS tip
+// tables of that many workgroups fit a CU.  Three register budgets are therefore built -- 6 waves per
+// SIMD (80 VGPRs), 5 (96) and 4 (128, no spills) -- and the launcher takes the tightest one whose
+// occupancy the tip tables allow: configs[2] runs 6 waves per SIMD, 5 % faster than 5 and 19 % faster than 4.
+#define LH_PRUNE_KERNEL(NAME, WAVES)                                                                 \
+  template <int kDepth, bool kN>                                                                     \
+  __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) NAME(    \
+      LH_PRUNE_PARAMS) {                                                                             \
+    prune_body<kDepth, true, kN, true>(LH_PRUNE_ARGS);                                               \
+  }
+LH_PRUNE_KERNEL(prune_kernel_w6, 6)
+LH_PRUNE_KERNEL(prune_kernel_w5, 5)
+LH_PRUNE_KERNEL(prune_kernel_w4, 4)
+#undef LH_PRUNE_KERNEL
 
 // Large trees: tip table built a schedule segment at a time (see SegCtx); register budgets for five and four
 // waves per SIMD.
 template <int kDepth, bool kN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) prune_kernel_seg(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, true, kN, true>(LH_PRUNE_ARGS);
+  prune_body<kDepth, true, kN, false, true>(LH_PRUNE_ARGS);
 }
 template <int kDepth, bool kN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) prune_kernel_seg4(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, true, kN, true>(LH_PRUNE_ARGS);
+  prune_body<kDepth, true, kN, false, true>(LH_PRUNE_ARGS);
 }
 
 PruneWsSizes prune_ws_sizes(int T, bool mixed_n) {
@@ -1284,36 +1439,39 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
     (void)hipMemcpyToSymbol(HIP_SYMBOL(lh_dbg_max_ops), &m, sizeof(m));
   }
 #endif
-  // K0c: every schedule is checked on the device (and rewritten into walk ops) before K1 indexes anything with it
-  static const bool no_tables = getenv("LH_K1_NO_TABLES") != nullptr;  // experiment: no cherry tables (every cherry walked)
-  hipLaunchKernelGGL(schedule_check_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, T, max_depth,
-                     (int)sizes.tabs_per_sample, no_tables ? 0 : 1, ops, brlen, ws.wops, ws.wlen, ws.tabs, ws.hdr, ws.err_flag);
-  if (L == 0) return R;       // nothing but all-N padding (K2a reads no plane at all)
+  if (L == 0) {               // nothing but all-N padding (K2a reads no plane at all): the schedules still get checked
+    hipLaunchKernelGGL(schedule_check_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, T, max_depth,
+                       (int)sizes.tabs_per_sample, 1, ops, brlen, ws.wops, ws.wlen, ws.tabs, ws.hdr, ws.err_flag);
+    return R;
+  }
   double* pmat = ws.scratch;
   const size_t rate_stride = sizes.scratch_doubles_per_rate;
-  const bool two = true;  // (the one-site-per-lane form for deep stacks is gone: deep slots live in scratch memory)
-  // tile: up to 1024 sites as two-site waves plus at most one one-site wave for a remainder below 64
-  // (deep variant: up to 8 one-site waves = 512 sites); tiles rebalanced so that they are equally full.
-  // Large tiles matter for large trees: every workgroup of a (sample, rate) repeats the P-matrix
-  // prologue and holds its own T x 128-byte tip table in LDS.
+  // tile: up to 1024 sites as two-site waves plus at most one one-site wave for a remainder below 64; tiles
+  // rebalanced so that they are equally full.  Large tiles matter for large trees: every workgroup of a (sample,
+  // rate) repeats the P-matrix prologue and holds its own T x 128-byte tip table in LDS.
   // (LH_K1_TILE_CAP: test hook that forces small tiles so that the multi-tile path runs on small families)
   static const int cap_env = getenv("LH_K1_TILE_CAP") ? atoi(getenv("LH_K1_TILE_CAP")) : 0;
-  const int cap = cap_env >= 64 ? std::min(cap_env, two ? 1024 : 512) : two ? 1024 : 512;
+  const int cap = cap_env >= 64 ? std::min(cap_env, 1024) : 1024;
   const int tiles = (L + cap - 1) / cap;
   const int tile = (L + tiles - 1) / tiles;
-  // LH_K1_S4: the assembly walk with FOUR sites per lane (three waves per SIMD) where a tile is (nearly) whole
-  // multiples of 256 sites -- measured on configs[2] (253 patterns = one four-site wave per rate): the same time per op
-  // as two sites per lane at six waves per SIMD, so it is not the default; kept, tested, behind the switch.
+  // Test hooks / experiments (read once per process): LH_K1_CXX_WALK keeps the cherry-table form's C++ walk;
+  // LH_K1_S4 runs its assembly walk with FOUR sites per lane (three waves per SIMD) where a tile is (nearly) whole
+  // multiples of 256 sites -- measured on configs[2]: the same time per op as two sites per lane at six waves;
+  // LH_K1_TABLES makes the cherry-table form the choice for the fused shapes too (default: the register-stack form,
+  // which is faster there: DESIGN.md section 6); LH_K1_NO_TABLES: the cherry-table form without tables.
   static const bool cxx_walk = getenv("LH_K1_CXX_WALK") != nullptr;
   static const bool s4_env = getenv("LH_K1_S4") != nullptr;
+  static const bool tables_env = getenv("LH_K1_TABLES") != nullptr;
+  static const bool no_tables = getenv("LH_K1_NO_TABLES") != nullptr;
+  static const bool seg_env = getenv("LH_K1_SEGMENTS") != nullptr;  // test hook: segments on small trees too
+  static const int seg_waves = getenv("LH_K1_SEG_WAVES") ? atoi(getenv("LH_K1_SEG_WAVES")) : 4;  // measured: 4 (128 VGPRs, few spills) beats 5 by 9 %
+  static const bool no_fuse = getenv("LH_K1_NO_FUSE") != nullptr;  // test hook: one workgroup per (sample, rate)
   const bool use_asm = !cxx_walk && !fam.msa_mixed_n;
-  // (not for large trees: 160 KB / tip table < 3 workgroups means the segmented form below, which has two-site waves)
-  const bool s4 = use_asm && s4_env && (tile % 256 == 0 || tile % 256 > 192) && (size_t)T * 128 * 3 <= 160 * 1024 &&
-                  getenv("LH_K1_SEGMENTS") == nullptr;
+  // (four sites per lane not for large trees: 160 KB / tip table < 3 workgroups means the segmented form, two-site waves)
+  const bool s4 = use_asm && s4_env && (tile % 256 == 0 || tile % 256 > 192) && (size_t)T * 128 * 3 <= 160 * 1024 && !seg_env;
   const int spl = s4 ? 256 : 128;  // sites per multi-site wave
-  int n2 = 0, n1;
-  if (two) {
-    n2 = tile / spl;
+  int n2 = tile / spl, n1;
+  {
     const int rem = tile - spl * n2;
     if (rem > 64) {
       ++n2;
@@ -1321,33 +1479,35 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
     } else {
       n1 = rem > 0 ? 1 : 0;
     }
-  } else {
-    n1 = (tile + 63) / 64;
   }
   const int wpr = n2 + n1;  // waves per rate
   const size_t tip_bytes = (size_t)T * 16 * sizeof(double);
   // all rates of a sample in one workgroup, mixed there: at most 8 waves, and R tip tables (later reused
-  // as the exchange area [R][5][pad] doubles + [R][pad] ints) within a third of a CU's LDS
+  // as the exchange area [R][5][pad] doubles + [R][pad] ints) within a third of a CU's LDS; behind the tip tables the
+  // register-stack form keeps its matrix list and verdict word, the cherry-table form its copy of the walk descriptors
   const size_t pad = (size_t)n2 * spl + (size_t)n1 * 64;
-  const size_t desc_bytes = (((size_t)std::max(T - 2, 1) * sizeof(int2)) + 15) & ~(size_t)15;  // the walk descriptors' copy
-  const size_t fused_lds = std::max((size_t)R * tip_bytes + desc_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
-  static const bool seg_env = getenv("LH_K1_SEGMENTS") != nullptr;  // test hook: segments on small trees too
-  static const int seg_waves = getenv("LH_K1_SEG_WAVES") ? atoi(getenv("LH_K1_SEG_WAVES")) : 4;  // measured: 4 (128 VGPRs, few spills) beats 5 by 9 %
-  static const bool no_fuse = getenv("LH_K1_NO_FUSE") != nullptr;  // test hook: one workgroup per (sample, rate)
-  const bool fused = allow_fused && !no_fuse && two && R * wpr <= 8 && fused_lds <= 53 * 1024 && !seg_env;
+  const size_t tail_bytes = (((size_t)std::max(T - 2, 1) * sizeof(int2)) + 31) & ~(size_t)15;
+  const size_t fused_lds = std::max((size_t)R * tip_bytes + tail_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
+  const bool fused = allow_fused && !no_fuse && R * wpr <= 8 && fused_lds <= 53 * 1024 && !seg_env;
   // large trees: with the whole tip table in LDS fewer than five waves per SIMD would be resident
   const bool seg = max_depth <= 4 && !fused && ((160 * 1024 / tip_bytes) * wpr / 4 < 5 || seg_env);
-  const size_t lds = fused ? fused_lds : seg ? (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) : tip_bytes + desc_bytes;
+  // the register-stack form with all rates in one workgroup checks its schedules in its own prologue; everything else
+  // runs behind K0c
+  const bool stack_fused = fused && max_depth <= 4 && !tables_env && !no_tables && !s4;
+  if (!stack_fused)
+    hipLaunchKernelGGL(schedule_check_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, T, max_depth,
+                       (int)sizes.tabs_per_sample, no_tables ? 0 : 1, ops, brlen, ws.wops, ws.wlen, ws.tabs, ws.hdr, ws.err_flag);
+  const size_t lds = fused ? fused_lds : seg ? (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) : tip_bytes + tail_bytes;
   const int wg_waves = fused ? R * wpr : wpr;
   dim3 grid(tiles, fused ? 1 : R, n), block(64 * wg_waves);
   const int n_ops = T - 2;
-#define LH_LAUNCH_K(K)                                                                                        \
+#define LH_LAUNCH_K(K, HDR)                                                                                   \
   {                                                                                                           \
     if (lds > 64 * 1024)                                                                                      \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                    \
-    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, R, wpr, fam.msa, L, T, n_ops, ops, ws.hdr, brlen, rates, \
-                       eig, pmat, rate_stride, pi, site_lik, site_scal);                                      \
+    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, R, wpr, fam.msa, L, T, n_ops, ops, HDR, ws.err_flag, brlen, \
+                       rates, eig, pmat, rate_stride, pi, site_lik, site_scal);                              \
   }
 #define LH_LAUNCH_CT(K)                                                                                       \
   {                                                                                                           \
@@ -1360,13 +1520,50 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   }
   // waves per SIMD that the LDS of the resident workgroups allows (160 KB per CU, 4 SIMDs)
   const int lds_waves = lds == 0 ? 8 : (int)((160 * 1024 / lds) * wg_waves / 4);
-  // The cherry-table form (two sites per lane, whole tip table in LDS; one stack slot in registers, deeper ones in
-  // scratch memory, so any depth up to 16 runs it).  Three register budgets -- the launcher takes the tightest one whose
-  // occupancy the tip tables allow -- and, for alignments without N, the walk in assembly (LH_K1_CXX_WALK: test hook
-  // that keeps the C++ walk).
 #ifndef LH_EXP_CT_BUDGET
 #define LH_EXP_CT_BUDGET 6
 #endif
+  if (stack_fused) {
+    // register-stack form, all rates in one workgroup; three register budgets, the tightest one whose occupancy the
+    // tip tables allow (a fourth stack slot spills too much at 80 VGPRs)
+    const int null_hdr = 0;
+    (void)null_hdr;
+#define LH_LAUNCH_STACK(D, N)                                          \
+  {                                                                    \
+    if (lds_waves >= 6 && D == 3)                                      \
+      LH_LAUNCH_K((prune_kernel_w6<D, N>), (const int4*)nullptr)       \
+    else if (lds_waves >= 5)                                           \
+      LH_LAUNCH_K((prune_kernel_w5<D, N>), (const int4*)nullptr)       \
+    else                                                               \
+      LH_LAUNCH_K((prune_kernel_w4<D, N>), (const int4*)nullptr)       \
+  }
+    if (max_depth <= 3 && !fam.msa_mixed_n)
+      LH_LAUNCH_STACK(3, false)
+    else if (max_depth <= 3)
+      LH_LAUNCH_STACK(3, true)
+    else if (!fam.msa_mixed_n)
+      LH_LAUNCH_STACK(4, false)
+    else
+      LH_LAUNCH_STACK(4, true)
+#undef LH_LAUNCH_STACK
+  } else if (seg) {
+    // large trees: register-stack form with the tip table built a schedule segment at a time
+    if (seg_waves == 4) {
+      if (fam.msa_mixed_n)
+        LH_LAUNCH_K((prune_kernel_seg4<4, true>), ws.hdr)
+      else
+        LH_LAUNCH_K((prune_kernel_seg4<4, false>), ws.hdr)
+    } else {
+      if (fam.msa_mixed_n)
+        LH_LAUNCH_K((prune_kernel_seg<4, true>), ws.hdr)
+      else
+        LH_LAUNCH_K((prune_kernel_seg<4, false>), ws.hdr)
+    }
+  } else {
+    // The cherry-table form (two sites per lane, whole tip table in LDS; one stack slot in registers, deeper ones in
+    // scratch memory, so any depth up to 16 runs it): shapes whose rates do not fit one workgroup, deep stacks, the
+    // ancestral-sequence step's unmixed planes.  Three register budgets, and for alignments without N the walk in
+    // assembly.
 #define LH_LAUNCH_BUDGET(D, N, F, A)                          \
   {                                                           \
     if (s4 && A)                                              \
@@ -1378,33 +1575,30 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
     else                                                      \
       LH_LAUNCH_CT((prune_kernel_ct4<D, N, F, A>))            \
   }
-#define LH_LAUNCH_FORM(D, N, A)              \
-  {                                          \
-    if (fused)                               \
-      LH_LAUNCH_BUDGET(D, N, true, A)        \
-    else if (seg && seg_waves == 4)          \
-      LH_LAUNCH_K((prune_kernel_seg4<4, N>)) \
-    else if (seg)                            \
-      LH_LAUNCH_K((prune_kernel_seg<4, N>))  \
-    else                                     \
-      LH_LAUNCH_BUDGET(D, N, false, A)       \
+#define LH_LAUNCH_FORM(D, N, A)        \
+  {                                    \
+    if (fused)                         \
+      LH_LAUNCH_BUDGET(D, N, true, A)  \
+    else                               \
+      LH_LAUNCH_BUDGET(D, N, false, A) \
   }
-#define LH_LAUNCH_SHALLOW(D)        \
-  {                                 \
-    if (fam.msa_mixed_n)            \
-      LH_LAUNCH_FORM(D, true, false) \
-    else if (use_asm)               \
-      LH_LAUNCH_FORM(D, false, true) \
-    else                            \
-      LH_LAUNCH_FORM(D, false, false) \
+#define LH_LAUNCH_SHALLOW(D)           \
+  {                                    \
+    if (fam.msa_mixed_n)               \
+      LH_LAUNCH_FORM(D, true, false)   \
+    else if (use_asm)                  \
+      LH_LAUNCH_FORM(D, false, true)   \
+    else                               \
+      LH_LAUNCH_FORM(D, false, false)  \
   }
-  if (max_depth <= 4)
-    LH_LAUNCH_SHALLOW(4)
-  else
-    LH_LAUNCH_SHALLOW(16)
-#undef LH_LAUNCH_FORM
+    if (max_depth <= 4)
+      LH_LAUNCH_SHALLOW(4)
+    else
+      LH_LAUNCH_SHALLOW(16)
 #undef LH_LAUNCH_SHALLOW
+#undef LH_LAUNCH_FORM
 #undef LH_LAUNCH_BUDGET
+  }
 #undef LH_LAUNCH_K
 #undef LH_LAUNCH_CT
 #ifdef LH_EXP_CT_STAMPS
