@@ -42,6 +42,12 @@ def _lib():
     lib = C.CDLL(path)
     lib.oc_eval_batch.argtypes = [C.POINTER(_Family), C.c_int, c_i32p, c_i32p, c_i32p, c_f64p, c_f64p, c_f64p,
                                   c_f64p, c_f64p, c_f64p, C.c_int]
+    lib.oc_forward_size.argtypes = [C.POINTER(_Family)]
+    lib.oc_forward_size.restype = C.c_int64
+    lib.oc_counts_size.argtypes = [C.POINTER(_Family)]
+    lib.oc_counts_size.restype = C.c_int64
+    lib.oc_eval_batch_fwd.argtypes = [C.POINTER(_Family), C.c_int, c_i32p, c_i32p, c_i32p, c_f64p, c_f64p, c_f64p,
+                                      c_f64p, c_f64p, c_f64p, c_i32p, C.c_int]
     return lib
 
 
@@ -137,6 +143,43 @@ class COracleFamily:
                                er.ctypes.data_as(c_f64p), pi.ctypes.data_as(c_f64p), rates.ctypes.data_as(c_f64p),
                                ll.ctypes.data_as(c_f64p), em.ctypes.data_as(c_f64p) if want_em else None, n_threads)
         return (ll, em) if want_em else ll
+
+    def eval_forward(self, trees, er, pi, alphas, n_threads=1):
+        """Log-likelihoods plus, per sample, the dense forward arrays and scaler counts SampleNaiveSequence reads
+        (src/HMM.cpp:326,1250,1333), as dicts with the names of the reference's members."""
+        n, T, f = len(trees), self.f.T, self.f
+        children = np.stack([np.asarray(t[0], dtype=np.int32) for t in trees])
+        roots = np.array([t[1] for t in trees], dtype=np.int32)
+        brlen = np.stack([np.asarray(t[2], dtype=np.float64) for t in trees])
+        order = np.stack([postorder(T, children[s], roots[s]) for s in range(n)])
+        rates = np.stack([orc.gamma_rates_mean(a, self.num_rates) for a in alphas])
+        er, pi = np.ascontiguousarray(er, dtype=np.float64), np.ascontiguousarray(pi, dtype=np.float64)
+        fs, cs = self.lib.oc_forward_size(C.byref(f)), self.lib.oc_counts_size(C.byref(f))
+        ll, fwd, cnt = np.zeros(n), np.zeros((n, fs)), np.zeros((n, cs), dtype=np.int32)
+        self.lib.oc_eval_batch_fwd(C.byref(f), n, children.ctypes.data_as(c_i32p), roots.ctypes.data_as(c_i32p),
+                                   order.ctypes.data_as(c_i32p), brlen.ctypes.data_as(c_f64p), er.ctypes.data_as(c_f64p),
+                                   pi.ctypes.data_as(c_f64p), rates.ctypes.data_as(c_f64p), ll.ctypes.data_as(c_f64p),
+                                   fwd.ctypes.data_as(c_f64p), cnt.ctypes.data_as(c_i32p), n_threads)
+        out = []
+        nV, nD, nJ = f.vgerm.n_genes, f.dgerm.n_genes, f.jgerm.n_genes
+        for i in range(n):
+            fo, co, r = fwd[i], cnt[i], {"loglik": ll[i]}
+            p, q = 0, 0
+            r["vgerm_forward"], p = fo[p:p + nV].copy(), p + nV
+            r["vgerm_scaler_count"], q = int(co[q]), q + 1
+            w, s_ = f.vd.W, f.vd.S
+            r["vd_junction_forward"], p = fo[p:p + w * s_].reshape(w, s_).copy(), p + w * s_
+            r["vd_junction_scaler_counts"], q = co[q:q + w].copy(), q + w
+            if f.has_d:
+                r["dgerm_forward"], p = fo[p:p + nD].copy(), p + nD
+                r["dgerm_scaler_count"], q = int(co[q]), q + 1
+                w, s_ = f.dj.W, f.dj.S
+                r["dj_junction_forward"], p = fo[p:p + w * s_].reshape(w, s_).copy(), p + w * s_
+                r["dj_junction_scaler_counts"], q = co[q:q + w].copy(), q + w
+            r["jgerm_forward"] = fo[p:p + nJ].copy()
+            r["jgerm_scaler_count"] = int(co[q])
+            out.append(r)
+        return out
 
 
 def postorder(T, children, root):

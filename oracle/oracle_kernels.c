@@ -147,7 +147,7 @@ static int fill_segments(const oc_segments* s, const double* em, const int* emc,
 /* ComputeJunctionForwardProbabilities + ComputeGermlineForwardProbabilities for one junction */
 static int junction(const oc_junction* J, const double* em, const int* emc, const double* g_in, int count_in,
                     const double* germ_em, const double* pad_trans, const double* pad_em, double* g_out,
-                    double* buf /* 3*S */) {
+                    double* buf /* 3*S */, double* rows_out /* W*S or NULL */, int* counts_out /* W or NULL */) {
   const int S = J->S, W = J->W;
   double* prev = buf;
   double* cur = buf + S;
@@ -188,6 +188,8 @@ static int junction(const oc_junction* J, const double* em, const int* emc, cons
     }
     for (int s = 0; s < S; ++s) cur[s] *= E[s];
     count += emc ? scale_vec_max(cur, S) : scale_vec(cur, S);
+    if (rows_out) memcpy(rows_out + (size_t)i * S, cur, sizeof(double) * S); /* junction_forward_.row(i), src/HMM.cpp:1133-1137 */
+    if (counts_out) counts_out[i] = count;                                   /* junction_scaler_counts_[i] */
     double* t = prev; prev = cur; cur = t;
   }
   for (int g = 0; g < J->n_to; ++g) {
@@ -205,9 +207,12 @@ static int junction(const oc_junction* J, const double* em, const int* emc, cons
 /* One evaluation.  children/root/brlen in the C ABI's rooted-at-naive form (any rooting gives the
  * same likelihood; the naive tip is an ordinary tip of every xMSA column here). order = inner nodes
  * in post-order.  Returns log-likelihood; writes em[C] if non-NULL. */
+/* fwd_out / cnt_out (optional): the forward arrays SampleNaiveSequence reads (src/HMM.cpp:326,1250,1333), dense:
+ * vgerm[nV] | vd junction [W][S] | dgerm[nD] | dj junction [W][S] | jgerm[nJ] (light chains: vgerm | junction | jgerm)
+ * and the scaler counts vgerm | vd rows | dgerm | dj rows | jgerm. */
 static double eval_one(const oc_family* F, const int32_t* children, int root, const int32_t* order,
                        const double* brlen, const double* er, const double* pi, const double* rates,
-                       double* em_out, int ext) {
+                       double* em_out, int ext, double* fwd_out, int* cnt_out) {
   const int T = F->T, C = F->C, R = F->R, nodes = 2 * T - 2, I = T - 2;
   /* GTR eigendecomposition */
   double S[4][4] = {{0}}, A[4][4], W[4][4], sq[4], lam[4], U[4][4], Ui[4][4];
@@ -332,21 +337,33 @@ static double eval_one(const oc_family* F, const int32_t* children, int root, co
     gA[g] = v;
   }
   vcount += ext ? scale_vec_max(gA, nV) : scale_vec(gA, nV);
+  double* fo = fwd_out;
+  int* co = cnt_out;
+  if (fo) { memcpy(fo, gA, sizeof(double) * nV); fo += nV; }
+  if (co) *co++ = vcount;
   int jcount;
   const double* gJ;
   if (F->has_d) {
     int dcount = fill_segments(&F->dgerm, em, emc, e1);
-    dcount += junction(&F->vd, em, emc, gA, vcount, e1, NULL, NULL, gB, buf);
+    dcount += junction(&F->vd, em, emc, gA, vcount, e1, NULL, NULL, gB, buf, fo, co);
+    if (fo) { fo += (size_t)F->vd.W * F->vd.S; memcpy(fo, gB, sizeof(double) * F->dgerm.n_genes); fo += F->dgerm.n_genes; }
+    if (co) { co += F->vd.W; *co++ = dcount; }
     jcount = fill_segments(&F->jgerm, em, emc, e1);
     jcount += fill_segments(&F->jpadding, em, emc, e2);
-    jcount += junction(&F->dj, em, emc, gB, dcount, e1, F->jpadding_transition, e2, gA, buf);
+    jcount += junction(&F->dj, em, emc, gB, dcount, e1, F->jpadding_transition, e2, gA, buf, fo, co);
+    if (fo) fo += (size_t)F->dj.W * F->dj.S;
+    if (co) co += F->dj.W;
     gJ = gA;
   } else {
     jcount = fill_segments(&F->jgerm, em, emc, e1);
     jcount += fill_segments(&F->jpadding, em, emc, e2);
-    jcount += junction(&F->vd, em, emc, gA, vcount, e1, F->jpadding_transition, e2, gB, buf);
+    jcount += junction(&F->vd, em, emc, gA, vcount, e1, F->jpadding_transition, e2, gB, buf, fo, co);
+    if (fo) fo += (size_t)F->vd.W * F->vd.S;
+    if (co) co += F->vd.W;
     gJ = gB;
   }
+  if (fo) memcpy(fo, gJ, sizeof(double) * F->jgerm.n_genes);
+  if (co) *co = jcount;
   double tot = 0;
   for (int g = 0; g < F->jgerm.n_genes; ++g) tot += gJ[g];
   const double ll = log(tot) - jcount * LOG_SCALE_FACTOR;
@@ -364,7 +381,30 @@ int oc_eval_batch(const oc_family* F, int n, const int32_t* children, const int3
   for (int s = 0; s < n; ++s)
     loglik[s] = eval_one(F, children + (size_t)s * 2 * (T - 2), roots[s], order + (size_t)s * (T - 2),
                          brlen + (size_t)s * (2 * T - 2), er + (size_t)s * 6, pi + (size_t)s * 4,
-                         rates + (size_t)s * F->R, em_out ? em_out + (size_t)s * F->C : NULL, 0);
+                         rates + (size_t)s * F->R, em_out ? em_out + (size_t)s * F->C : NULL, 0, NULL, NULL);
+  return 0;
+}
+
+/* Sizes of the dense forward output of oc_eval_batch_fwd (doubles / ints per sample). */
+int64_t oc_forward_size(const oc_family* F) {
+  int64_t n = F->vgerm.n_genes + (int64_t)F->vd.W * F->vd.S + F->jgerm.n_genes;
+  if (F->has_d) n += F->dgerm.n_genes + (int64_t)F->dj.W * F->dj.S;
+  return n;
+}
+int64_t oc_counts_size(const oc_family* F) { return 2 + F->vd.W + (F->has_d ? 1 + F->dj.W : 0); }
+
+/* oc_eval_batch that also returns what sampling reads: forward[n][oc_forward_size] and counts[n][oc_counts_size]
+ * (layout at eval_one). */
+int oc_eval_batch_fwd(const oc_family* F, int n, const int32_t* children, const int32_t* roots,
+                      const int32_t* order, const double* brlen, const double* er, const double* pi,
+                      const double* rates, double* loglik, double* forward, int32_t* counts, int n_threads) {
+  const int T = F->T;
+  const int64_t fs = oc_forward_size(F), cs = oc_counts_size(F);
+#pragma omp parallel for schedule(dynamic) num_threads(n_threads > 0 ? n_threads : 1)
+  for (int s = 0; s < n; ++s)
+    loglik[s] = eval_one(F, children + (size_t)s * 2 * (T - 2), roots[s], order + (size_t)s * (T - 2),
+                         brlen + (size_t)s * (2 * T - 2), er + (size_t)s * 6, pi + (size_t)s * 4,
+                         rates + (size_t)s * F->R, NULL, 0, forward + (size_t)s * fs, (int*)counts + (size_t)s * cs);
   return 0;
 }
 
@@ -377,6 +417,6 @@ int oc_eval_batch_ext(const oc_family* F, int n, const int32_t* children, const 
   for (int s = 0; s < n; ++s)
     loglik[s] = eval_one(F, children + (size_t)s * 2 * (T - 2), roots[s], order + (size_t)s * (T - 2),
                          brlen + (size_t)s * (2 * T - 2), er + (size_t)s * 6, pi + (size_t)s * 4,
-                         rates + (size_t)s * F->R, NULL, 1);
+                         rates + (size_t)s * F->R, NULL, 1, NULL, NULL);
   return 0;
 }

@@ -1,0 +1,75 @@
+"""Helper of tests/test_device_schedules.py (its own process: the K1 form is chosen by environment variables read
+once per process).  Evaluates a small synthetic family through lh_eval_batch_device with one sample's DEVICE-RESIDENT
+schedule corrupted in a given way; prints a JSON line with what came back."""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(mode, n_leaves):
+    import numpy as np
+    import torch
+    import linearham_amd
+    from oracle import linearham_oracle as orc
+    from tests import desc_builder as db
+    from tools import synth_family as sf
+    out = "/tmp/lh_devsched_%d_%d" % (n_leaves, os.getpid())
+    # small: one one-site wave per rate; from 30 leaves on a 400-site family whose 100+ patterns need two-site waves
+    spec = sf.Spec.small(n_leaves=n_leaves, n_samples=6, seed=31) if n_leaves < 30 else \
+        sf.Spec(n_leaves=n_leaves, n_sites=400, n_v=24, n_d=6, n_j=4, n_samples=6, seed=31)
+    sf.generate(spec, out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    hip = linearham_amd.load_library()
+    fam = linearham_amd.Family(db.build_family_desc(h), hip)
+    T = h.msa.shape[0] + 1
+    ops, brl, depth = [], [], 0
+    for r in rows:
+        children, root, brlen = db.tree_arrays(orc.parse_newick(r["tree"]), h.xmsa_labels)
+        o, d = hip.schedule_tree(T, children, root)
+        ops.append(np.asarray(o, dtype=np.int32).reshape(-1, 4)), brl.append(brlen)
+        depth = max(depth, d)
+    ops = np.stack(ops)
+    victim = 2
+    k_tip = next(k for k in range(ops.shape[1]) if (ops[victim, k, 0] & 15) == 1)     # a tip-into-accumulator op
+    if mode == "tip":            # a tip number far outside the alignment: would index the MSA and the tip table out of bounds
+        ops[victim, k_tip, 1] = 1 << 20
+    elif mode == "kind":         # an op kind that does not exist
+        ops[victim, 0, 0] = (ops[victim, 0, 0] & ~15) | 7
+    elif mode == "node":         # a branch node beyond 2T - 2: would index the branch lengths out of bounds
+        ops[victim, k_tip, 2] = 5 * T
+    elif mode == "rank":         # the running matrix count the register-stack form's prologue places matrices by, zeroed
+        ops[victim, :, 0] &= 0xff
+    elif mode == "slot":         # a stack slot beyond the depth the kernel was built for
+        k_pop = next(k for k in range(ops.shape[1]) if (ops[victim, k, 0] & 15) == 2)
+        ops[victim, k_pop, 3] = 40
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    d_ops, d_brl = t(ops, np.int32), t(np.stack(brl), np.float64)
+    d_er, d_pi = t([r["er"] for r in rows], np.float64), t([r["pi"] for r in rows], np.float64)
+    d_al = t([r["alpha"] for r in rows], np.float64)
+    ll = torch.zeros(len(rows), dtype=torch.float64, device=dev)
+    fam.eval_batch_device(len(rows), T, depth, d_ops.data_ptr(), d_brl.data_ptr(), d_er.data_ptr(), d_pi.data_ptr(),
+                          d_al.data_ptr(), 4, ll.data_ptr())
+    status = ""
+    try:
+        fam.status()
+    except RuntimeError as e:
+        status = str(e)
+    second = ""
+    try:
+        fam.status()             # the error state is reported once
+    except RuntimeError as e:
+        second = str(e)
+    # the same batch with the schedule as lh_schedule_tree wrote it: no error, and the other samples' values unchanged
+    got = ll.cpu().numpy()
+    print(json.dumps({"status": status, "second": second, "ll": [None if not np.isfinite(x) else float(x) for x in got]}))
+    fam.close()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]))

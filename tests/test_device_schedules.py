@@ -1,0 +1,48 @@
+"""Device-resident schedules are not trusted (lh_eval_batch_device): a malformed op must come back as a status code
+and NaN for that sample, never as an out-of-bounds access on the GPU.  The reference checks nothing here
+(src/PhyloHMM.cpp:421 uses the parsed tree unchecked); this is the C ABI's own contract (include/linearham_amd.h).
+Both forms of K1 are exercised: the register-stack form checks schedules in its prologue, the cherry-table form
+(LH_K1_TABLES=1) behind K0c (schedule_check_kernel)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "device_schedule_worker.py")
+
+
+def _run(mode, env_extra, n_leaves=12):
+    r = subprocess.run([sys.executable, WORKER, mode, str(n_leaves)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, **env_extra))
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["stack", "tables"])
+@pytest.mark.parametrize("mode", ["tip", "kind", "node", "rank", "slot"])
+def test_corrupted_device_schedule_gets_a_status_code(mode, form):
+    env = {"LH_K1_TABLES": "1"} if form == "tables" else {}
+    good = _run("none", env)
+    assert good["status"] == "" and all(x is not None for x in good["ll"])
+    if mode == "rank" and form == "tables":
+        return                        # the cherry-table form does not read the rank field at all
+    bad = _run(mode, env)
+    assert "malformed schedule" in bad["status"], bad
+    assert bad["second"] == ""                                   # reported once, then cleared
+    assert bad["ll"][2] is None                                  # the corrupted sample: NaN
+    for i, (a, b) in enumerate(zip(bad["ll"], good["ll"])):
+        if i != 2:
+            assert a == b, (i, a, b)                             # its neighbours: the bits of the clean run
+
+
+@pytest.mark.gpu
+def test_corrupted_schedule_in_a_larger_tree():
+    """A 60-leaf family (more than one two-site wave per rate: the assembly walk of the cherry-table form runs)."""
+    for env in ({}, {"LH_K1_TABLES": "1"}):
+        bad = _run("tip", env, n_leaves=60)
+        assert "malformed schedule" in bad["status"] and bad["ll"][2] is None
+        assert all(x is not None for i, x in enumerate(bad["ll"]) if i != 2)

@@ -467,3 +467,48 @@ def test_subnormal_entry_next_to_normal_ones_is_documented_corner(hip, data_dir)
     assert ex["jgerm_scaler_count"] == 0                            # ... the device path did not
     np.testing.assert_allclose(np.ldexp(ex["jgerm_forward"], 1024), h.jgerm_forward, rtol=1e-10)
     assert pos.min() > 1e-20                                        # (what the reference holds after its rescaling)
+
+
+@pytest.mark.parametrize("preset", ["config2", "config4"])
+def test_full_size_forward_arrays_match_dense_oracle(hip, tmp_path, preset):
+    """What SampleNaiveSequence consumes (src/HMM.cpp:1222-1353, 1107-1177), at BASELINE.json's full sizes: the forward
+    arrays and ScaleMatrix counts the two-samples-per-wave K2b kernels write for configs[2] (100 leaves x 400 sites,
+    200 V / 30 D / 12 J) and configs[4] (500 leaves x 600 sites) against the dense reference algorithm in C
+    (oracle_kernels.c, oc_eval_batch_fwd): values 1e-8, counts exactly, on every row the reference evaluates finitely."""
+    import linearham_amd
+    from oracle import oracle_c
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    spec = sf.Spec(n_samples=4) if preset == "config2" else sf.Spec(n_leaves=500, n_sites=600, n_samples=6)
+    sf.generate(spec, out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    desc = db.build_family_desc(h)
+    fam = linearham_amd.Family(desc, hip)
+    T = h.msa.shape[0] + 1
+    trees, ops, depth = [], [], 0
+    for r in rows:
+        t = db.tree_arrays(orc.parse_newick(r["tree"]), h.xmsa_labels)
+        o, d = hip.schedule_tree(T, t[0], t[1])
+        trees.append(t), ops.append(o)
+        depth = max(depth, d)
+    ll, res = fam.eval_batch(T, depth, np.stack(ops), np.stack([t[2] for t in trees]), [r["er"] for r in rows],
+                             [r["pi"] for r in rows], [r["alpha"] for r in rows], 4, want=("forward", "scaler_counts"))
+    fam.close()
+    oracle_c.build()
+    ref = oracle_c.COracleFamily(h, 4).eval_forward(trees, [r["er"] for r in rows], [r["pi"] for r in rows],
+                                                    [r["alpha"] for r in rows], n_threads=min(8, len(os.sched_getaffinity(0))))
+    checked = 0
+    for i, r in enumerate(ref):
+        if not np.isfinite(r["loglik"]):      # the reference's own 2^(256 d) overflow rows (DESIGN.md section 2)
+            assert not np.isfinite(ll[i])
+            continue
+        assert abs(ll[i] - r["loglik"]) <= 1e-10 * abs(r["loglik"])
+        ex = expand_forward(h, desc, res["forward"][i], res["scaler_counts"][i])
+        for k in ex:
+            if "scaler" in k:
+                assert np.array_equal(np.asarray(ex[k]), np.asarray(r[k])), (i, k, ex[k], r[k])
+            else:
+                np.testing.assert_allclose(ex[k], r[k], rtol=1e-8, atol=0, err_msg="%d %s" % (i, k))
+        checked += 1
+    assert checked >= 3

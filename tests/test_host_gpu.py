@@ -254,20 +254,36 @@ def test_cli_pipeline(tmp_path):
     assert bad.returncode != 0 and "ERROR:" in bad.stderr
 
 
-@pytest.mark.parametrize("locus, seed", [("igh", 3), ("igk", 4), ("igh", 11)])
-def test_device_sampler_matches_host_sampler(tmp_path, locus, seed):
+SAMPLER_FAMILIES = {
+    "igh3": dict(kind="small", n_rows=5000, kw=dict(n_samples=64, seed=3, locus="igh")),
+    "igk4": dict(kind="small", n_rows=5000, kw=dict(n_samples=64, seed=4, locus="igk")),
+    "igh11": dict(kind="small", n_rows=5000, kw=dict(n_samples=64, seed=11, locus="igh")),
+    # more than 64 alleles per segment: K4's multi-chunk loops over the left genes (lh_sample.hip: 64 genes at a time)
+    "many_alleles": dict(kind="small", n_rows=1500, kw=dict(n_samples=32, seed=21, n_v=300, n_d=70, n_j=5)),
+    "many_alleles_igk": dict(kind="small", n_rows=1500, kw=dict(n_samples=32, seed=22, locus="igk", n_v=150, n_j=70)),
+    # BASELINE.json configs[2] at full size: 100 leaves x 400 sites, 200 V (four chunks) / 30 D / 12 J
+    "config2": dict(kind="full", n_rows=256, kw=dict(n_samples=256)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SAMPLER_FAMILIES))
+def test_device_sampler_matches_host_sampler(tmp_path, name):
     """The states K4 (lh_eval_sample_batch) draws on the device are the ones HMM::SampleRow draws on the host from
     the same forward arrays and the same std::mt19937 stream (src/HMM.cpp:358-431): `linearham --pipeline` writes the
-    same bytes with and without LH_HOST_SAMPLING, over several launch batches (5000 rows > RunPipeline's 2048)."""
+    same bytes with and without LH_HOST_SAMPLING, over several launch batches (5000 rows > RunPipeline's 2048) --
+    small families, families with 150-300 alleles per segment, and configs[2] at its full size."""
     from tools import synth_family as sf
+    cfg = SAMPLER_FAMILIES[name]
+    seed = cfg["kw"].get("seed", 1)
     out = str(tmp_path / "fam")
-    sf.generate(sf.Spec.small(n_samples=64, seed=seed, locus=locus), out)
+    sf.generate(sf.Spec.small(**cfg["kw"]) if cfg["kind"] == "small" else sf.Spec(**cfg["kw"]), out)
     yaml_path, pdir, tsv = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params"), os.path.join(out, "trees.tsv")
     lines = open(tsv).read().splitlines()
     big = os.path.join(out, "big.tsv")
+    n_rows = cfg["n_rows"]
     with open(big, "w") as f:
         f.write(lines[0] + "\n")
-        for i in range(5000):
+        for i in range(n_rows):
             f.write(lines[1 + i % (len(lines) - 1)] + "\n")
     common = ["--yaml-path", yaml_path, "--cluster-ind", "0", "--hmm-param-dir", pdir, "--input-path", big,
               "--num-rates", "4", "--seed", str(seed)]
@@ -288,10 +304,10 @@ def test_device_sampler_matches_host_sampler(tmp_path, locus, seed):
     assert outs["device"] == outs["host"]
     rows = [ln.split("\t") for ln in outs["device"].splitlines()]
     c = rows[0].index("NaiveSequence")
-    assert len(rows) == 5001 and len({r[c] for r in rows[1:]}) > 1   # the draws do vary over the rows
+    assert len(rows) == n_rows + 1 and len({r[c] for r in rows[1:]}) > 1   # the draws do vary over the rows
 
 
-@pytest.mark.parametrize("locus", ["igh", "igk"])
+@pytest.mark.parametrize("locus", ["igh", "igk", "many_alleles", "many_alleles_igk"])
 def test_device_sampler_on_crafted_engine_outputs(tmp_path, locus):
     """K4 against HMM::SampleRow draw by draw on engine outputs chosen to hit the corners of libstdc++'s
     discrete_distribution (bits/random.tcc): a uniform of exactly 0 (lower_bound returns element 0 whatever it holds),
@@ -299,7 +315,9 @@ def test_device_sampler_on_crafted_engine_outputs(tmp_path, locus):
     The host engine is a std::mt19937 whose state is set so that it returns exactly these words."""
     from tools import synth_family as sf
     out = str(tmp_path / "fam")
-    sf.generate(sf.Spec.small(n_samples=3, seed=23, locus=locus), out)
+    kw = {"igh": dict(locus="igh"), "igk": dict(locus="igk"), "many_alleles": dict(n_v=300, n_d=70, n_j=5),
+          "many_alleles_igk": dict(locus="igk", n_v=150, n_j=70)}[locus]   # the last two: K4's loops over > 64 genes
+    sf.generate(sf.Spec.small(n_samples=3, seed=23, **kw), out)
     yaml_path, pdir = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params")
     rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
     h = host.PhyloHMM(yaml_path, 0, pdir, 0)
