@@ -80,6 +80,8 @@ HMM::HMM(const std::string& yaml_path, int cluster_ind, const std::string& hmm_p
 
 HMM::~HMM() {
   if (family_) lh_family_destroy(family_);
+  for (lh_family* f : more_families_)
+    if (f) lh_family_destroy(f);
 }
 
 // src/HMM.cpp:71-83

@@ -98,6 +98,11 @@ class HMM {
   // GPU side
   lh_family* family_ = nullptr;
   bool device_sampler_ = false;  // lh_family_set_sampler accepted this family's junctions
+  // Several GPUs in one process (the loop that shards is src/PhyloHMM.cpp:414-442): devices_ lists the
+  // HIP devices RunPipeline deals its rows to (row i -> devices_[i mod N]); family_ belongs to devices_[0] (or to the
+  // calling thread's current device when the list is empty), more_families_[k] to devices_[k + 1].
+  std::vector<int> devices_;
+  std::vector<lh_family*> more_families_;
 
   void InitializeMsa();
   void InitializeStateSpace();

@@ -135,6 +135,7 @@ void PhyloHMM::CreateFamily() {
   d.vd = vd.c();
   if (igh) d.dj = dj.c();
   StageTimer timer;
+  if (!devices_.empty()) CheckHip(lh_set_device(devices_[0]), "lh_set_device");
   CheckHip(lh_family_create(&d, &family_), "lh_family_create");
   timer.Mark("lh_family_create (+ HIP init)");
   // Device-side naive-sequence sampling (lh_eval_sample_batch).  The one structural condition it has -- the left and
@@ -154,7 +155,29 @@ void PhyloHMM::CreateFamily() {
     sd.vd = svd.c();
     device_sampler_ = lh_family_set_sampler(family_, &sd) == 0 && lh_sample_words(family_) == RawDrawsPerSample();
     timer.Mark("lh_family_set_sampler");
+    // the other devices' handles: the same descriptors, uploaded with that device current
+    for (std::size_t k = 1; k < devices_.size(); ++k) {
+      CheckHip(lh_set_device(devices_[k]), "lh_set_device");
+      lh_family* f = nullptr;
+      CheckHip(lh_family_create(&d, &f), "lh_family_create");
+      more_families_.push_back(f);
+      if (device_sampler_ && lh_family_set_sampler(f, &sd) != 0) throw std::runtime_error(lh_last_error());
+    }
+  } else {
+    for (std::size_t k = 1; k < devices_.size(); ++k) {
+      CheckHip(lh_set_device(devices_[k]), "lh_set_device");
+      lh_family* f = nullptr;
+      CheckHip(lh_family_create(&d, &f), "lh_family_create");
+      more_families_.push_back(f);
+    }
   }
+  if (devices_.size() > 1) CheckHip(lh_set_device(devices_[0]), "lh_set_device");
+}
+
+void PhyloHMM::SetDevices(const std::vector<int>& devices) {
+  Require(family_ == nullptr, "SetDevices must be called before the first evaluation");
+  for (int dev : devices) Require(dev >= 0 && dev < lh_device_count(), "SetDevices: no such device");
+  devices_ = devices;
 }
 
 // src/PhyloHMM.cpp:350-361
@@ -861,9 +884,57 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
           s.words.resize(m * (std::size_t)raw_per_sample);
           for (uint32_t& w : s.words) w = (uint32_t)word_rng();
           t_words += secs(t2, now());
-          CheckHip(lh_eval_sample_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(),
-                                        b.pi.data(), b.alpha.data(), num_rates, s.words.data(), s.ll, s.rates, s.states),
-                   "lh_eval_sample_batch");
+          if (more_families_.empty()) {
+            CheckHip(lh_eval_sample_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(),
+                                          b.pi.data(), b.alpha.data(), num_rates, s.words.data(), s.ll, s.rates, s.states),
+                     "lh_eval_sample_batch");
+          } else {
+            // Several devices: table row i goes to device i mod N.  One host thread per device gathers its rows of
+            // the batch, has its handle evaluate and sample them, and puts the results back at the rows' places
+            // (host memory, in-process: no collective; RCCL only joins separate processes, bench.py --gpus N).
+            const std::size_t D = 1 + more_families_.size();
+            const std::size_t n_ops4 = (std::size_t)(b.n_tips - 2) * 4, nodes = 2 * (std::size_t)b.n_tips - 2;
+            const std::size_t W = (std::size_t)raw_per_sample;
+            std::vector<std::exception_ptr> errs(D);
+            std::vector<std::thread> pool;
+            for (std::size_t d = 0; d < D; ++d)
+              pool.emplace_back([&, d] {
+                try {
+                  std::vector<std::size_t> idx;
+                  for (std::size_t i = 0; i < m; ++i)
+                    if ((off + i) % D == d) idx.push_back(i);
+                  const std::size_t q = idx.size();
+                  if (q == 0) return;
+                  std::vector<int32_t> ops(q * n_ops4), states(q * NS);
+                  std::vector<double> brlen(q * nodes), er(q * 6), pi(q * 4), alpha(q), ll(q), rates(q * (std::size_t)num_rates);
+                  std::vector<uint32_t> words(q * W);
+                  for (std::size_t j = 0; j < q; ++j) {
+                    const std::size_t i = idx[j];
+                    std::copy_n(b.ops.data() + i * n_ops4, n_ops4, ops.data() + j * n_ops4);
+                    std::copy_n(b.brlen.data() + i * nodes, nodes, brlen.data() + j * nodes);
+                    std::copy_n(b.er.data() + i * 6, 6, er.data() + j * 6);
+                    std::copy_n(b.pi.data() + i * 4, 4, pi.data() + j * 4);
+                    alpha[j] = b.alpha[i];
+                    std::copy_n(s.words.data() + i * W, W, words.data() + j * W);
+                  }
+                  lh_family* fam = d == 0 ? family_ : more_families_[d - 1];
+                  if (lh_eval_sample_batch(fam, (int32_t)q, b.n_tips, b.max_depth, ops.data(), brlen.data(), er.data(), pi.data(),
+                                           alpha.data(), num_rates, words.data(), ll.data(), rates.data(), states.data()))
+                    throw std::runtime_error(std::string("lh_eval_sample_batch: ") + lh_last_error());
+                  for (std::size_t j = 0; j < q; ++j) {
+                    const std::size_t i = idx[j];
+                    s.ll[i] = ll[j];
+                    std::copy_n(rates.data() + j * (std::size_t)num_rates, (std::size_t)num_rates, s.rates + i * (std::size_t)num_rates);
+                    std::copy_n(states.data() + j * NS, NS, s.states + i * NS);
+                  }
+                } catch (...) {
+                  errs[d] = std::current_exception();
+                }
+              });
+            for (std::thread& th : pool) th.join();
+            for (const std::exception_ptr& e : errs)
+              if (e) std::rethrow_exception(e);
+          }
           auto one_row = [&](std::size_t i, int k_fwd) {  // forward arrays of one row, for the host-side checks
             const std::size_t n_ops = (std::size_t)(b.n_tips - 2) * 4, nodes = 2 * (std::size_t)b.n_tips - 2;
             double ll1 = 0;
@@ -1230,6 +1301,8 @@ void StoreXmsaIndex(std::pair<int, int> id, std::map<std::pair<int, int>, int>& 
 void PhyloHMM::SetExtendedRange(bool on) {
   // takes effect with the next InitializePhyloEmission / RunPipeline
   if (lh_family_set_extended_range(family(), on ? 1 : 0)) throw std::runtime_error(lh_last_error());
+  for (lh_family* f : more_families_)
+    if (lh_family_set_extended_range(f, on ? 1 : 0)) throw std::runtime_error(lh_last_error());
 }
 
 }  // namespace linearham

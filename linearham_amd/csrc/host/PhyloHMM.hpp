@@ -132,6 +132,11 @@ class PhyloHMM : public HMM {
   /// Opt-in extended-range arithmetic of the device path (lh_family_set_extended_range): finite log-likelihoods
   /// where the reference's equalisation overflows or its exp underflows; off by default.
   void SetExtendedRange(bool on);
+  /// The HIP devices RunPipeline uses (before the first evaluation): one family handle and one host thread per
+  /// entry, table row i evaluated and sampled on devices[i mod N], output in file order -- the split of
+  /// src/PhyloHMM.cpp:414-442's loop over one node's GPUs.  The same device may be listed more than once (two
+  /// handles on one GPU).  Single-row members (LogLikelihood, SampleNaiveSequence ...) use devices[0].
+  void SetDevices(const std::vector<int>& devices);
   int n_xmsa() const { return xmsa_.cols(); }
 
  private:

@@ -55,7 +55,7 @@ int main(int argc, char** argv) {
     if (argc < 2 || std::string(argv[1]) == "-h" || std::string(argv[1]) == "--help") {
       std::cout << "A Phylo-HMM implementation for B cell receptor sequence analysis.\n"
                    "USAGE: linearham {--compute-logl|--sample|--pipeline|--asr} --yaml-path <string> --cluster-ind <int> "
-                   "--hmm-param-dir <string> [--seed <int>] [--num-rates <int>] [--extended-range <0|1>] ...\n";
+                   "--hmm-param-dir <string> [--seed <int>] [--num-rates <int>] [--extended-range <0|1>] [--devices <a,b,...>] ...\n";
       return argc < 2 ? EXIT_FAILURE : EXIT_SUCCESS;
     }
     const auto t_main = std::chrono::steady_clock::now();
@@ -82,6 +82,20 @@ int main(int argc, char** argv) {
         std::make_shared<linearham::PhyloHMM>(yaml_path, cluster_ind, hmm_param_dir, seed);
     warmup.join();
     if (timing) std::fprintf(stderr, "[main] family object + HIP context ready at %.3f s\n", since_start());
+    // not in the reference: --devices a,b,... -- the GPUs --pipeline deals the table's rows to (row i -> device i mod N)
+    {
+      const std::string devs = a.opt("devices", "");
+      if (!devs.empty()) {
+        std::vector<int> list;
+        std::size_t pos = 0;
+        while (pos <= devs.size()) {
+          const std::size_t comma = std::min(devs.find(',', pos), devs.size());
+          list.push_back(std::stoi(devs.substr(pos, comma - pos)));
+          pos = comma + 1;
+        }
+        phylo_hmm_ptr->SetDevices(list);
+      }
+    }
     // not in the reference: finite log-likelihoods where its scaling over/underflows (include/linearham_amd.h)
     if (std::stoi(a.opt("extended-range", "0")) != 0) phylo_hmm_ptr->SetExtendedRange(true);
     if (subcmd == "--pipeline") {

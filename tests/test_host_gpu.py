@@ -307,6 +307,39 @@ def test_device_sampler_matches_host_sampler(tmp_path, name):
     assert len(rows) == n_rows + 1 and len({r[c] for r in rows[1:]}) > 1   # the draws do vary over the rows
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_pipeline_with_several_handles_writes_the_same_table(tmp_path, devices):
+    """`linearham --pipeline --devices a,b,...`: one family handle and one host thread per listed device, table row i
+    evaluated and sampled on device i mod N (the loop that shards: src/PhyloHMM.cpp:414-442), output in
+    file order.  On the one-GPU box the list names device 0 two and three times -- two / three handles driven from
+    their own threads: the table must be byte-identical to the single-handle one (5000 rows, several launch batches,
+    shards of unequal size)."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_samples=64, seed=9), out)
+    yaml_path, pdir, tsv = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params"), os.path.join(out, "trees.tsv")
+    lines = open(tsv).read().splitlines()
+    big = os.path.join(out, "big.tsv")
+    with open(big, "w") as f:
+        f.write(lines[0] + "\n")
+        for i in range(5000):
+            f.write(lines[1 + i % (len(lines) - 1)] + "\n")
+    common = ["--yaml-path", yaml_path, "--cluster-ind", "0", "--hmm-param-dir", pdir, "--input-path", big,
+              "--num-rates", "4", "--seed", "9"]
+    tables = {}
+    for name, extra in (("one", []), ("many", ["--devices", devices])):
+        o = os.path.join(out, name + ".tsv")
+        r = subprocess.run([_exe(), "--pipeline"] + common + extra + ["--output-path", o], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, LH_PIPELINE_TIMING="1"))
+        assert r.returncode == 0, r.stderr
+        assert "device sampler" in r.stderr, r.stderr
+        tables[name] = open(o).read()
+    assert tables["one"] == tables["many"] and tables["one"].count("\n") == 5001
+    bad = subprocess.run([_exe(), "--pipeline"] + common + ["--devices", "0,7", "--output-path", os.path.join(out, "x.tsv")],
+                         capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "no such device" in bad.stderr      # a device the box does not have
+
+
 @pytest.mark.parametrize("locus", ["igh", "igk", "many_alleles", "many_alleles_igk"])
 def test_device_sampler_on_crafted_engine_outputs(tmp_path, locus):
     """K4 against HMM::SampleRow draw by draw on engine outputs chosen to hit the corners of libstdc++'s
