@@ -41,7 +41,7 @@ WORKLOADS = {
                "germline set, R=4 rate categories (not the headline workload)",
     "small": "small synthetic family (development only, not the headline workload)",
 }
-PMC_PROFILE = {"config2": "r02_bench_pmc_per_launch.json", "config4": "r02_config4_pmc_per_launch.json"}
+PMC_PROFILE = {"config2": "r03_bench_pmc_per_launch.json", "config4": "r02_config4_pmc_per_launch.json"}
 GEN_VERSION = 2                # bump when tools/synth_family.py changes what it writes
 
 
@@ -178,6 +178,97 @@ def cpu_oracle(fam_dir, row_ids, budget_s=None, n_timed=0):
     return ref, base
 
 
+def extra_rates(args, lib, fam_handle, hmm, d, T, depth, R, n, dev, stream, fam_dir, sizes, shard):
+    """Two more rates of the same family, measured OUTSIDE the `value` region (never part of it), inputs resident:
+    pipeline_rows_per_s -- what RunPipeline's device side does per row: K0-K2 with the forward arrays written, then the
+    naive-sequence state draws on them (K4, lh_eval_sample_batch_device; src/HMM.cpp:358-431);
+    asr_tree_samples_per_s -- the ancestral-sequence step (K3, lh_asr_batch_device; scripts/run_bootstrap_asr_ess.R:48-104),
+    batch 4096, its draws checked against oracle/asr_oracle.py on two samples (that oracle's parity is UNPINNED: the
+    reference holds no fixture for the step)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    fam = C.c_void_p(fam_handle)
+    res = {}
+    # ---- pipeline rows: evaluation + device sampler ----
+    n_words = lib.lib.lh_sample_words(fam)
+    n_states = lib.lib.lh_sample_states(fam)
+    if n_words > 0:
+        g = torch.Generator(device="cpu").manual_seed(7)
+        words = torch.randint(0, 2 ** 31 - 1, (n, n_words), generator=g, dtype=torch.int64).to(torch.int32).to(dev)
+        states = torch.zeros((n, n_states), dtype=torch.int32, device=dev)
+        ll2 = torch.zeros(n, dtype=torch.float64, device=dev)
+
+        def row_step():
+            lib.check(lib.lib.lh_eval_sample_batch_device(fam, n, T, depth, d["ops"].data_ptr(), d["brlen"].data_ptr(),
+                                                          d["er"].data_ptr(), d["pi"].data_ptr(), d["alpha"].data_ptr(), R,
+                                                          words.data_ptr(), ll2.data_ptr(), None, states.data_ptr(),
+                                                          C.c_void_p(stream)))
+        row_step()
+        torch.cuda.synchronize()
+        k = max(1, min(args.steps, 5))
+        t = time.perf_counter()
+        for _ in range(k):
+            row_step()
+        torch.cuda.synchronize()
+        res["pipeline_rows_per_s"] = n * k / (time.perf_counter() - t)
+        res["pipeline_rows_note"] = ("K0-K2 with forward arrays + K4 (device sampler) on resident inputs, %d rows per step; "
+                                     "parsing, formatting and file I/O of RunPipeline are host work outside this figure" % n)
+        if not args.no_check and int(states.min().item()) < 0:
+            raise SystemExit("device sampler returned a negative state index")
+    # ---- ancestral-sequence step ----
+    try:
+        m = min(n, 4096)
+        L = sizes["n_sites"]
+        rates = torch.zeros((m, R), dtype=torch.float64, device=dev)
+        from linearham_amd.capi import _EvalOutputs
+        outs = _EvalOutputs()
+        outs.rates = C.cast(rates.data_ptr(), C.POINTER(C.c_double))
+        ll3 = torch.zeros(m, dtype=torch.float64, device=dev)
+        lib.check(lib.lib.lh_eval_batch_device(fam, m, T, depth, d["ops"].data_ptr(), d["brlen"].data_ptr(),
+                                               d["er"].data_ptr(), d["pi"].data_ptr(), d["alpha"].data_ptr(), R,
+                                               ll3.data_ptr(), C.byref(outs), C.c_void_p(stream)))
+        rng = np.random.default_rng(1)
+        naive = rng.integers(0, 4, size=(m, L)).astype(np.uint8)
+        d_naive = torch.from_numpy(naive).to(dev)
+        anc = torch.zeros((m, T - 2, L), dtype=torch.uint8, device=dev)
+
+        def asr_step(seed):
+            lib.check(lib.lib.lh_asr_batch_device(fam, m, T, depth, d["ops"].data_ptr(), d["brlen"].data_ptr(),
+                                                  d["er"].data_ptr(), d["pi"].data_ptr(), rates.data_ptr(), R,
+                                                  d_naive.data_ptr(), seed, 0, anc.data_ptr(), None, C.c_void_p(stream)))
+        asr_step(1)
+        torch.cuda.synchronize()
+        k = max(1, min(args.steps, 5))
+        t = time.perf_counter()
+        for s_ in range(k):
+            asr_step(100 + s_)
+        torch.cuda.synchronize()
+        res["asr_tree_samples_per_s"] = m * k / (time.perf_counter() - t)
+        res["asr_note"] = ("ancestral-sequence sampling (K3) at batch %d, unmixed K1 planes + K3a/K3s/K3b per step; "
+                           "checked against oracle/asr_oracle.py, whose parity is UNPINNED (no reference fixture)" % m)
+        if not args.no_check:
+            from oracle import asr_oracle as ao
+            from oracle import linearham_oracle as orc
+            from linearham_amd import host as _host
+            from tools import synth_family as sf
+            o = orc.PhyloHMM(os.path.join(fam_dir, "cluster.yaml"), 0, os.path.join(fam_dir, "hmm_params"), 0)
+            labels = list(o.xmsa_labels)
+            rows = sf.read_trees_tsv(os.path.join(fam_dir, "trees.tsv"), max_rows=2)
+            a = anc[:2].cpu().numpy()
+            r_host = rates[:2].cpu().numpy()
+            for i in range(2):
+                children, root, brlen = _host.newick_arrays(rows[i]["tree"], labels)
+                _, anc_ref, _ = ao.asr_sample(children, root, brlen, T, o.msa, naive[i], rows[i]["er"], np.asarray(rows[i]["pi"]),
+                                              r_host[i], 100 + k - 1, i)
+                if int((anc_ref != a[i]).sum()):
+                    raise SystemExit("parity failure: ancestral-sequence draws differ from oracle/asr_oracle.py")
+            res["asr_samples_checked"] = 2
+    except RuntimeError as e:      # (a tree too large for K3's LDS tables: the step does not exist for this shape)
+        res["asr_note"] = "not run: %s" % e
+    return res
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +285,10 @@ def parse_args():
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-samples", type=int, default=192,
                     help="evaluations of the CPU baseline sample (also the rows the parity check covers)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra keys measured outside the `value` region (pipeline_rows_per_s, asr_tree_samples_per_s)")
+    ap.add_argument("--timeout-s", type=float, default=1500.0,
+                    help="--gpus N without a launcher: stop the rank processes after this many seconds (exit status 124)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo (through host copies) only to rehearse the multi-rank path on "
                          "a box with fewer GPUs than ranks -- ranks then share devices (LOCAL_RANK modulo)")
@@ -209,7 +304,7 @@ def launcher(args):
     from linearham_amd import sharding
     prepare_family(args.preset, args.batch, may_generate=True)
     argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-    status, out = sharding.spawn_ranks(argv, args.gpus)
+    status, out = sharding.spawn_ranks(argv, args.gpus, timeout_s=args.timeout_s)
     sys.stdout.write(out)
     sys.stdout.flush()
     if status == 0 and not any(l.startswith("{") for l in out.splitlines()):
@@ -249,11 +344,17 @@ def worker(args, rank, local_rank, world):
     t0 = time.time()
     hmm = host.PhyloHMM(os.path.join(fam_dir, "cluster.yaml"), 0, os.path.join(fam_dir, "hmm_params"), 0)
     sizes = hmm.sizes()
-    flat = hmm.flatten_tsv(os.path.join(fam_dir, "trees.tsv"), spec.n_samples)
     strong = args.preset == "config3"
     n_total = spec.n_samples if strong else world * args.batch
-    shard, ids = sharding.take_shard(flat, n_total, world, rank)
+    # this rank's tree samples (global sample g -> rank g mod N) and the table rows they read: only those rows are
+    # parsed and scheduled here
+    ids = sharding.shard_ids(n_total, world, rank)
+    my_rows = sharding.table_rows(ids, spec.n_samples, world, n_total)
     n = len(ids)
+    flat = hmm.flatten_tsv(os.path.join(fam_dir, "trees.tsv"), n, rows=my_rows if n else [0])
+    if flat["n_rows"] != spec.n_samples:
+        raise SystemExit("the tree table has %d rows, expected %d" % (flat["n_rows"], spec.n_samples))
+    shard = {k: np.ascontiguousarray(flat[k][:n]) for k in ("ops", "brlen", "er", "pi", "alpha")}
     T, depth, R = flat["n_tips"], flat["max_depth"], 4
     d = {k: torch.from_numpy(v).to(dev) for k, v in shard.items()}
     loglik = torch.zeros(max(n, 1), dtype=torch.float64, device=dev)[:n]
@@ -263,8 +364,8 @@ def worker(args, rank, local_rank, world):
     lib = linearham_amd.load_library()
     fam_handle = flat["family"]
     stream = torch.cuda.current_stream().cuda_stream
-    log("[rank %d] host set-up %.2fs; %s; %d of %d samples, %d distinct table rows, max stack depth %d"
-        % (rank, time.time() - t0, sizes, n, n_total, flat["n_rows"], depth))
+    log("[rank %d of %d] host set-up %.2fs; %s; %d of %d samples (%d distinct table rows parsed here, table of %d), "
+        "max stack depth %d" % (rank, world, time.time() - t0, sizes, n, n_total, len(set(my_rows.tolist())), flat["n_rows"], depth))
 
     def evaluate(outs=None):
         lib.check(lib.lib.lh_eval_batch_device(C.c_void_p(fam_handle), n, T, depth, d["ops"].data_ptr(),
@@ -362,7 +463,8 @@ def worker(args, rank, local_rank, world):
         model_bytes_per_eval = Cx * (2 * (T - 2) * R * 32 + T + 8)   # CLV-streaming model
         out = {
             "metric": "phylo-HMM log-likelihood evals/sec (100-leaf x 400-site family)",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "evals/s", "n_gpus": dist.get_world_size() if world > 1 else 1,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -373,12 +475,17 @@ def worker(args, rank, local_rank, world):
                        "n_tips": T, "n_sites": sizes["n_sites"], "xmsa_columns": Cx, "site_patterns": n_pat.value,
                        "distinct_xmsa_columns": n_ucol.value, "S_vd": sizes["s_vd"],
                        "S_dj": sizes["s_dj"], "W_vd": sizes["w_vd"], "W_dj": sizes["w_dj"],
-                       "G": sizes["g_total"], "backend": args.backend if world > 1 else None,
+                       "G": sizes["g_total"], "backend": dist.get_backend() if world > 1 else None,
+                       "collective_world_size": dist.get_world_size() if world > 1 else 1,
                        "sharding": "tree sample i -> rank i mod N; one RCCL gather of log-likelihoods per step"},
             "roofline": {"bound": "fp64_valu", "kernel": "prune_kernel (K1, Felsenstein pruning)",
                          "achieved": k1_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": k1_tflops / FP64_VALU_PEAK_TFLOPS,
                          "traffic": traffic,
+                         "traffic_source": ("profiles/%s: HBM-side bytes per K1 launch from separate rocprofv3 --pmc passes of this "
+                                            "same command (2 x FETCH_SIZE + WRITE_SIZE); counters cannot be collected inside "
+                                            "this run, so this one figure is NOT measured by it" % PMC_PROFILE.get(args.preset))
+                         if traffic else None,
                          "hbm_measured_gbs": (traffic / (prune_ms * 1e-3) / 1e9) if traffic else None,
                          "flop_per_launch": k1_flops, "evals_per_launch": per_launch, "avg_launch_ms": prune_ms,
                          "peak_source": "half the 157.3 TFLOP/s FP32 vector peak of MI355X_MICROARCH.md (FP64 FMAs "
@@ -396,6 +503,8 @@ def worker(args, rank, local_rank, world):
             out["evals_per_s_with_forward"] = n_total / dt_fwd
             out["with_forward_note"] = ("the same step with lh_eval_outputs.forward and .scaler_counts written (what "
                                         "SampleNaiveSequence consumes); `value` leaves them off, as SURVEY 8(d) excludes sampling")
+        if world == 1 and not args.no_extras and n > 0:
+            out.update(extra_rates(args, lib, fam_handle, hmm, d, T, depth, R, n, dev, stream, fam_dir, sizes, shard))
         if world == 1 and args.pcie:
             # PCIe-inclusive rate through the host-pointer entry point (never `value`): H2D of the
             # flattened inputs, the same kernels, D2H of the log-likelihoods, synchronous per call.

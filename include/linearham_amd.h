@@ -205,6 +205,13 @@ int lh_eval_sample_batch(lh_family* fam, int32_t n, int32_t n_tips, int32_t max_
                          const double* brlen, const double* er, const double* pi, const double* alpha,
                          int32_t num_rates, const uint32_t* words, double* loglik, double* rates, int32_t* states);
 
+/* The same with every array resident on the handle's device (words, loglik, rates [may be NULL], states too);
+ * enqueued on `hip_stream` without synchronising.  What a host calls that keeps its tree samples on the GPU. */
+int lh_eval_sample_batch_device(lh_family* fam, int32_t n, int32_t n_tips, int32_t max_depth, const int32_t* ops,
+                                const double* brlen, const double* er, const double* pi, const double* alpha,
+                                int32_t num_rates, const uint32_t* words, double* loglik, double* rates,
+                                int32_t* states, void* hip_stream);
+
 /* Tree in rooted-at-naive form: tips are nodes 0..T-1 (0 = `naive`, i = MSA row i-1), inner nodes
  * T..2T-3.  children[2*(v-T)+{0,1}] are the two children of inner node v when the tree is rooted at
  * `root`, the inner node adjacent to `naive`.  Writes the kernel's post-order schedule:

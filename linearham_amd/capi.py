@@ -44,7 +44,8 @@ EXPORTS = ["lh_last_error", "lh_device_count", "lh_family_create", "lh_family_de
            "lh_forward_size", "lh_scaler_size", "lh_family_info", "lh_family_consensus_sets", "lh_schedule_tree", "lh_eval_batch",
            "lh_eval_batch_device", "lh_forward_batch", "lh_asr_batch", "lh_asr_batch_device",
            "lh_profile_enable", "lh_profile_read", "lh_asr_profile_read", "lh_family_set_extended_range", "lh_warmup", "lh_host_alloc", "lh_host_free", "lh_family_set_sampler",
-           "lh_sample_words", "lh_sample_states", "lh_eval_sample_batch", "lh_set_device", "lh_family_status"]
+           "lh_sample_words", "lh_sample_states", "lh_eval_sample_batch", "lh_set_device", "lh_family_status",
+           "lh_eval_sample_batch_device"]
 
 
 def library_path():
@@ -89,6 +90,11 @@ class HipLibrary:
         lib.lh_profile_enable.argtypes = [C.c_void_p, C.c_int]
         lib.lh_family_set_extended_range.argtypes = [C.c_void_p, C.c_int]
         lib.lh_profile_read.argtypes = [C.c_void_p, c_f64p, c_f64p, c_f64p, C.POINTER(C.c_int64)]
+        if hasattr(lib, "lh_eval_sample_batch_device"):
+            lib.lh_eval_sample_batch_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5 + \
+                [C.c_int32] + [C.c_void_p] * 5
+            lib.lh_sample_words.argtypes = [C.c_void_p]
+            lib.lh_sample_states.argtypes = [C.c_void_p]
         if hasattr(lib, "lh_set_device"):      # (absent from round-2 builds loaded through LH_LIB_DIR for comparisons)
             lib.lh_set_device.argtypes = [C.c_int32]
             lib.lh_family_status.argtypes = [C.c_void_p]

@@ -748,6 +748,24 @@ PhyloHMM::DeviceBatch PhyloHMM::FlattenTsv(const std::string& path, int* n_rows)
   return FlattenTable(t, 0, t.rows.size(), false, false, path).dev;
 }
 
+PhyloHMM::DeviceBatch PhyloHMM::FlattenTsvRows(const std::string& path, const int64_t* row_ids, int n, int* n_rows) const {
+  TsvTable t = TsvTable::Read(path, "RevBayes output file");
+  const char* names[15] = {"alpha", "alpha", "alpha", "alpha", "er[1]", "er[2]", "er[3]", "er[4]",
+                           "er[5]", "er[6]",  "pi[1]", "pi[2]", "pi[3]", "pi[4]", "tree"};
+  t.Locate(names, 15, t.col, path);
+  if (t.rows.empty()) throw std::runtime_error("no rows in table");
+  *n_rows = (int)t.rows.size();
+  // the line index restricted to the rows asked for: the rest of the table is never parsed
+  std::vector<std::pair<std::size_t, std::size_t>> sel((std::size_t)std::max(n, 0));
+  for (int i = 0; i < n; ++i) {
+    if (row_ids[i] < 0 || (std::size_t)row_ids[i] >= t.rows.size()) throw std::runtime_error("FlattenTsvRows: row outside the table");
+    sel[i] = t.rows[(std::size_t)row_ids[i]];
+  }
+  t.rows.swap(sel);
+  if (t.rows.empty()) return DeviceBatch{};
+  return FlattenTable(t, 0, t.rows.size(), false, false, path).dev;
+}
+
 // src/PhyloHMM.cpp:393-446.  The reference evaluates, samples and writes row by row on one core.  Here the table
 // is read once, and per batch of rows: worker threads parse and schedule the trees, the GPU evaluates the batch and
 // draws every row's states (lh_eval_sample_batch), and worker threads derive the naive sequences from the states and

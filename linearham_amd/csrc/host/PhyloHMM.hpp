@@ -125,6 +125,8 @@ class PhyloHMM : public HMM {
                            std::vector<std::string>* exported = nullptr) const;
   /// The whole RevBayes table `path` as device inputs (rows parsed and scheduled by worker threads).
   DeviceBatch FlattenTsv(const std::string& path, int* n_rows) const;
+  /// Only the table rows `row_ids[0..n)` (any order, repeats allowed), in that order.
+  DeviceBatch FlattenTsvRows(const std::string& path, const int64_t* row_ids, int n, int* n_rows) const;
   lh_family* family() {
     CreateFamily();
     return family_;

@@ -302,6 +302,31 @@ int lhh_phylo_flatten_tsv(void* h, const char* tsv_path, int n, int32_t* ops, do
   });
 }
 
+// The rows `row_ids[0..n)` of the table (any order, repeats allowed) as device inputs: only these rows are parsed and
+// scheduled (a rank of a multi-GPU run flattens the rows it evaluates, not the whole table).
+int lhh_phylo_flatten_tsv_rows(void* h, const char* tsv_path, int n, const int64_t* row_ids, int32_t* ops, double* brlen,
+                               double* er, double* pi, double* alpha, int* n_tips, int* max_depth, int* n_rows_in_file,
+                               int need_family, void** family) {
+  return Guard([&] {
+    PhyloHMM& p = dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h));
+    int n_file = 0;
+    const PhyloHMM::DeviceBatch b = p.FlattenTsvRows(tsv_path, row_ids, n, &n_file);
+    *n_rows_in_file = n_file;
+    *n_tips = b.n_tips;
+    *max_depth = b.max_depth;
+    *family = need_family ? p.family() : nullptr;
+    std::memcpy(ops, b.ops.data(), b.ops.size() * sizeof(int32_t));
+    std::memcpy(brlen, b.brlen.data(), b.brlen.size() * sizeof(double));
+    std::memcpy(er, b.er.data(), b.er.size() * sizeof(double));
+    std::memcpy(pi, b.pi.data(), b.pi.size() * sizeof(double));
+    std::memcpy(alpha, b.alpha.data(), b.alpha.size() * sizeof(double));
+  });
+}
+
+int lhh_phylo_set_devices(void* h, const int* devices, int n) {
+  return Guard([&] { dynamic_cast<PhyloHMM&>(*static_cast<HMM*>(h)).SetDevices(std::vector<int>(devices, devices + n)); });
+}
+
 int lhh_phylo_sizes(void* h, int* n_tips, int* n_sites, int* n_xmsa, int* s_vd, int* s_dj, int* w_vd, int* w_dj,
                     int* g_total) {
   return Guard([&] {

@@ -1191,6 +1191,27 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
   return 0;
 }
 
+int lh_eval_sample_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const int32_t* ops,
+                                const double* brlen, const double* er, const double* pi, const double* alpha, int32_t R,
+                                const uint32_t* words, double* loglik, double* rates, int32_t* states, void* hip_stream) {
+  if (!f) return fail("lh_eval_sample_batch_device: null family");
+  DeviceGuard guard(f);
+  if (!f->have_sampler) return fail("lh_eval_sample_batch_device: lh_family_set_sampler has not been called");
+  if (n <= 0) return n == 0 ? 0 : fail("lh_eval_sample_batch_device: negative batch size");
+  if (!words || !states) return fail("lh_eval_sample_batch_device: null array");
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const size_t FS = f->host.forward_size;
+  void* d_fwd;  // the forward arrays never leave the device (grow-only slot; a growing call waits for earlier work)
+  if (sizeof(double) * FS * n > f->st.cap[8]) LH_HIP(hipDeviceSynchronize());
+  if (stage(f, 8, sizeof(double) * FS * n, &d_fwd)) return 1;
+  lh_eval_outputs outs{rates, nullptr, (double*)d_fwd, nullptr};
+  if (lh_eval_batch_device(f, n, T, max_depth, ops, brlen, er, pi, alpha, R, loglik, &outs, hip_stream)) return 1;
+  const lh::DevSampler& smp = f->sampler;
+  lh::launch_sample(smp, n, (const double*)d_fwd, FS, words, smp.words_per_sample, states, stream);
+  LH_HIP(hipGetLastError());
+  return 0;
+}
+
 int lh_eval_sample_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const int32_t* ops,
                          const double* brlen, const double* er, const double* pi, const double* alpha, int32_t R,
                          const uint32_t* words, double* loglik, double* rates, int32_t* states) {

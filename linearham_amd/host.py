@@ -148,9 +148,18 @@ class PhyloHMM(_HMM):
         keys = ["n_tips", "n_sites", "n_xmsa", "s_vd", "s_dj", "w_vd", "w_dj", "g_total"]
         return {k: x.value for k, x in zip(keys, v)}
 
-    def flatten_tsv(self, tsv_path, n, need_family=True):
-        """Device-ready inputs for lh_eval_batch_device: n samples taken cyclically from the table.
+    def set_devices(self, devices):
+        """The HIP devices run_pipeline deals the table's rows to (before the first evaluation)."""
+        arr = (C.c_int * len(devices))(*devices)
+        _check(self.lib.lhh_phylo_set_devices(self.h, arr, len(devices)))
+
+    def flatten_tsv(self, tsv_path, n, need_family=True, rows=None):
+        """Device-ready inputs for lh_eval_batch_device: n samples taken cyclically from the table, or -- rows given --
+        the table rows rows[0..n) in that order (only those are parsed: a rank flattens what it evaluates).
         Returns dict(ops, brlen, er, pi, alpha, n_tips, max_depth, n_rows, family)."""
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, dtype=np.int64)
+            n = len(rows)
         n_tips, depth, n_rows = C.c_int(), C.c_int(), C.c_int()
         fam = C.c_void_p()
         flag = C.c_int(1 if need_family else 0)
@@ -161,10 +170,16 @@ class PhyloHMM(_HMM):
 
         def p(a, t):
             return a.ctypes.data_as(C.POINTER(t))
-        _check(self.lib.lhh_phylo_flatten_tsv(self.h, tsv_path.encode(), n, p(ops, C.c_int32),
-                                              p(brlen, C.c_double), p(er, C.c_double), p(pi, C.c_double),
-                                              p(alpha, C.c_double), C.byref(n_tips), C.byref(depth),
-                                              C.byref(n_rows), flag, C.byref(fam)))
+        if rows is not None:
+            _check(self.lib.lhh_phylo_flatten_tsv_rows(self.h, tsv_path.encode(), n, p(rows, C.c_int64), p(ops, C.c_int32),
+                                                       p(brlen, C.c_double), p(er, C.c_double), p(pi, C.c_double),
+                                                       p(alpha, C.c_double), C.byref(n_tips), C.byref(depth),
+                                                       C.byref(n_rows), flag, C.byref(fam)))
+        else:
+            _check(self.lib.lhh_phylo_flatten_tsv(self.h, tsv_path.encode(), n, p(ops, C.c_int32),
+                                                  p(brlen, C.c_double), p(er, C.c_double), p(pi, C.c_double),
+                                                  p(alpha, C.c_double), C.byref(n_tips), C.byref(depth),
+                                                  C.byref(n_rows), flag, C.byref(fam)))
         assert n_tips.value == T
         return dict(ops=ops, brlen=brlen, er=er, pi=pi, alpha=alpha, n_tips=T, max_depth=depth.value,
                     n_rows=n_rows.value, family=fam.value)

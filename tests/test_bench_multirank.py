@@ -36,6 +36,24 @@ def test_bench_two_ranks_without_torchrun():
 
 
 @pytest.mark.gpu
+def test_bench_two_ranks_on_the_real_family_reuse_the_table():
+    """The weak-scaling path of the driver's multi-GPU runs, with the configs[2] family: two ranks (gloo, sharing the
+    one GPU), 6144 tree samples each per step out of a table of 6144 rows -- the table is reused (sharding.table_rows'
+    rotation: every rank still works through 6144 distinct rows), every rank parses only the rows it evaluates, and
+    samples of both shards are checked against the CPU oracle."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--preset",
+                        "config2", "--batch", "6144", "--steps", "2", "--warmup", "1", "--no-forward-rate"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    c = out["config"]
+    assert out["n_gpus"] == 2 and c["collective_world_size"] == 2 and c["backend"] == "gloo" and out["scaling"] == "weak"
+    assert c["tree_samples_per_step"] == 12288 and c["tree_samples_per_gpu_per_step"] == 6144
+    assert c["distinct_tree_samples"] == 6144 and c["distinct_tree_samples_per_gpu"] == 6144
+    assert out["delta_logl_samples_checked"] >= 4 and out["delta_logl_vs_cpu_max_rel"] < 1e-9
+
+
+@pytest.mark.gpu
 def test_bench_single_rank_small():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preset", "small", "--steps", "2", "--warmup",
                         "1"], env=_clean_env(), capture_output=True, text=True, timeout=900)
@@ -43,6 +61,8 @@ def test_bench_single_rank_small():
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["delta_logl_vs_cpu_max_rel"] < 1e-9
     assert out["evals_per_s_with_forward"] > 0 and out["cpu_baseline"]["cores"] >= 1
+    # the extra rates measured outside the `value` region: device-side pipeline rows and the ancestral-sequence step
+    assert out["pipeline_rows_per_s"] > 0 and out["asr_tree_samples_per_s"] > 0 and out["asr_samples_checked"] == 2
 
 
 @pytest.mark.gpu
