@@ -750,7 +750,7 @@ __device__ __forceinline__ void prune_wave_ct(int site0, int site_end, const uin
 // arithmetic K2a would do) and K2a runs with a single "rate".  A quarter of the output traffic, and K2a's
 // bandwidth-bound assembly shrinks to a quarter.  Used when R * wpr <= 8 waves and the R tip tables fit.
 template <int kDepth, bool kTwo, bool kN, bool kFused, bool kSeg = false>
-__device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, const uint8_t* __restrict__ msa, int L,
+__device__ __forceinline__ void prune_body(int sample, int slot, int n2, int tile, int R, int wpr, const uint8_t* __restrict__ msa, int L,
                                            int T, int n_ops, const int32_t* __restrict__ ops,
                                            const int4* __restrict__ hdr, int32_t* err_flag,
                                            const double* __restrict__ brlen, const double* __restrict__ rates,
@@ -765,7 +765,6 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
   const int wave = kFused ? wave_all - rate * wpr : wave_all;  // within the rate
   const int nthr = kFused ? wpr * 64 : (int)blockDim.x;       // threads working on this rate
   const int rtid = kFused ? tid - rate * nthr : tid;
-  const int sample = blockIdx.z;
   if (hdr != nullptr && hdr[sample].w != 0) {  // K0c rejected the schedule (uniform per workgroup): no number may look like a result
     const int planes = kFused ? 1 : R, plane = kFused ? 0 : rate;
     const int t0 = blockIdx.x * tile, t1 = min(t0 + tile, L);
@@ -775,8 +774,8 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
     }
     return;
   }
-  // scratch area of one (sample, rate): the schedule's P-matrices
-  const size_t pm_off = ((size_t)sample * R + rate) * rate_stride;
+  // scratch area of one (workgroup slot, rate): the schedule's P-matrices
+  const size_t pm_off = ((size_t)slot * R + rate) * rate_stride;
   // LDS tip table [T][4][4] (per rate when fused); large trees (kSeg): the segment slots [2 kSegOps][4][4]
   // followed by the naive tip's entry
   double* tiptab = reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);
@@ -925,7 +924,9 @@ __device__ __forceinline__ void prune_body(int n2, int tile, int R, int wpr, con
       return;
     }
   }
-  // P-matrices in schedule order (addresses depend on the op number only), readable from here on
+  // P-matrices in schedule order (addresses depend on the op number only), readable from here on; a workgroup that
+  // works through several samples has read these addresses before (the scalar cache may still hold the last sample's lines)
+  if (slot != sample) asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   const pmat_ptr pm = pmat_after_barrier(pmat_w + pm_off);
   const int lane = tid & 63;
   const int tile0 = blockIdx.x * tile;
@@ -1382,13 +1383,28 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))
 }
 // pmat_w: the scratch area (see prune_body); written in the prologue, read back after the barrier.
 #define LH_PRUNE_PARAMS                                                                                     \
-  int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, int n_ops,               \
+  int n_samples, int n2, int tile, int R, int wpr, const uint8_t *__restrict__ msa, int L, int T, int n_ops, \
       const int32_t *__restrict__ ops, const int4 *__restrict__ hdr, int32_t *err_flag,                     \
       const double *__restrict__ brlen, const double *__restrict__ rates, const double *__restrict__ eig,  \
       double *pmat_w, size_t rate_stride, const double *__restrict__ pi,                                   \
       double *__restrict__ site_lik, int32_t *__restrict__ site_scal
 #define LH_PRUNE_ARGS \
   n2, tile, R, wpr, msa, L, T, n_ops, ops, hdr, err_flag, brlen, rates, eig, pmat_w, rate_stride, pi, site_lik, site_scal
+// -DLH_EXP_K1_PERSIST (experiment, profiles/r03_k1_persistent_slots.txt): a workgroup takes samples blockIdx.z,
+// blockIdx.z + gridDim.z, ... and keeps ONE scratch slot for all of them; with LH_K1_PERSIST=<workgroups> in the
+// environment the grid has that many workgroups and the scratch area in use is <workgroups> x R x rate_stride instead of
+// n x R x rate_stride.  The barrier between two samples: the mixing loop of one reads the LDS the prologue of the next
+// writes.  Measured 11 % SLOWER on configs[2] (every sample of a workgroup invalidates its CU's scalar cache, which the
+// other resident workgroups are reading their matrices through), so the product build has a workgroup per sample.
+#ifdef LH_EXP_K1_PERSIST
+#define LH_PRUNE_SAMPLES(BODY)                                                           \
+  for (int sample = blockIdx.z; sample < n_samples; sample += gridDim.z) {               \
+    if (sample != (int)blockIdx.z) __syncthreads();                                      \
+    BODY(sample, (int)blockIdx.z, LH_PRUNE_ARGS);                                        \
+  }
+#else
+#define LH_PRUNE_SAMPLES(BODY) BODY((int)blockIdx.z, (int)blockIdx.z, LH_PRUNE_ARGS);
+#endif
 
 // Shallow stacks (depth <= 4, any tree up to a few hundred tips), all rates in one workgroup: two sites per lane.  The
 // walk needs ~100 VGPRs; resident waves matter more to it than a few spilled registers, as long as the LDS tip
@@ -1399,7 +1415,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3))
   template <int kDepth, bool kN>                                                                     \
   __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) NAME(    \
       LH_PRUNE_PARAMS) {                                                                             \
-    prune_body<kDepth, true, kN, true>(LH_PRUNE_ARGS);                                               \
+    LH_PRUNE_SAMPLES((prune_body<kDepth, true, kN, true>))                                           \
   }
 LH_PRUNE_KERNEL(prune_kernel_w6, 6)
 LH_PRUNE_KERNEL(prune_kernel_w5, 5)
@@ -1410,11 +1426,11 @@ LH_PRUNE_KERNEL(prune_kernel_w4, 4)
 // waves per SIMD.
 template <int kDepth, bool kN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5))) prune_kernel_seg(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, true, kN, false, true>(LH_PRUNE_ARGS);
+  LH_PRUNE_SAMPLES((prune_body<kDepth, true, kN, false, true>))
 }
 template <int kDepth, bool kN>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) prune_kernel_seg4(LH_PRUNE_PARAMS) {
-  prune_body<kDepth, true, kN, false, true>(LH_PRUNE_ARGS);
+  LH_PRUNE_SAMPLES((prune_body<kDepth, true, kN, false, true>))
 }
 
 PruneWsSizes prune_ws_sizes(int T, bool mixed_n) {
@@ -1500,13 +1516,19 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   const size_t lds = fused ? fused_lds : seg ? (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) : tip_bytes + tail_bytes;
   const int wg_waves = fused ? R * wpr : wpr;
   dim3 grid(tiles, fused ? 1 : R, n), block(64 * wg_waves);
+#ifdef LH_EXP_K1_PERSIST
+  // LH_K1_PERSIST=<workgroups>: the register-stack kernels with that many workgroups, each working through samples
+  // z, z + grid.z, ... with one scratch slot
+  static const int persist = getenv("LH_K1_PERSIST") ? atoi(getenv("LH_K1_PERSIST")) : 0;
+  if (persist > 0 && (stack_fused || seg)) grid.z = std::min(n, persist);
+#endif
   const int n_ops = T - 2;
 #define LH_LAUNCH_K(K, HDR)                                                                                   \
   {                                                                                                           \
     if (lds > 64 * 1024)                                                                                      \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds);                                                                    \
-    hipLaunchKernelGGL(K, grid, block, lds, stream, n2, tile, R, wpr, fam.msa, L, T, n_ops, ops, HDR, ws.err_flag, brlen, \
+    hipLaunchKernelGGL(K, grid, block, lds, stream, n, n2, tile, R, wpr, fam.msa, L, T, n_ops, ops, HDR, ws.err_flag, brlen, \
                        rates, eig, pmat, rate_stride, pi, site_lik, site_scal);                              \
   }
 #define LH_LAUNCH_CT(K)                                                                                       \
