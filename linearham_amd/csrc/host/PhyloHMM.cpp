@@ -1,5 +1,6 @@
 #include "PhyloHMM.hpp"
 
+#include <cerrno>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -522,6 +523,32 @@ struct FileBytes {
       throw std::runtime_error("Can't read " + path);
     }
     FileBytes b;
+    if (!S_ISREG(st.st_mode) || st.st_size == 0) {
+      // a pipe, a FIFO, /dev/stdin, a process substitution (or a /proc-style file that reports no size): no length to
+      // divide among threads -- read to the end into a growing buffer
+      std::size_t cap = 1u << 20;
+      std::unique_ptr<char[]> buf(new char[cap + 1]);
+      for (;;) {
+        if (b.n == cap) {
+          std::unique_ptr<char[]> more(new char[2 * cap + 1]);
+          std::memcpy(more.get(), buf.get(), b.n);
+          buf.swap(more);
+          cap *= 2;
+        }
+        const ssize_t got = ::read(fd, buf.get() + b.n, cap - b.n);
+        if (got < 0) {
+          if (errno == EINTR) continue;
+          ::close(fd);
+          throw std::runtime_error("Can't read " + path);
+        }
+        if (got == 0) break;
+        b.n += (std::size_t)got;
+      }
+      ::close(fd);
+      buf[b.n] = '\0';
+      b.data = std::move(buf);
+      return b;
+    }
     b.n = (std::size_t)st.st_size;
     b.data.reset(new char[b.n + 1]);
     b.data[b.n] = '\0';

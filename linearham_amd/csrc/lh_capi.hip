@@ -1064,6 +1064,26 @@ static bool valid_op(const int32_t* op, int T, int nodes, int max_depth) {
   return ok;
 }
 
+// One sample's schedule: every op well-formed, and the rank field of each op the running count of inner-branch matrices
+// lh_schedule_tree leaves there (a tip-accumulate op takes one, a pop-accumulate op two, a cherry none; T - 3 in all) --
+// the fused K1 prologue files its matrices by that number.  (The kernels check the same thing again on the device:
+// schedules may also arrive in device memory.)
+static bool valid_schedule(const int32_t* ops, int T, int nodes, int max_depth) {
+  int count = 0;
+  for (int k = 0; k < T - 2; ++k) {
+    const int32_t* op = ops + (size_t)k * 4;
+    if (!valid_op(op, T, nodes, max_depth)) return false;
+    const int kind = op[0] & 15, rank = op[0] >> lh::OP_RANK_SHIFT;
+    if (kind == lh::OP_CHERRY) {
+      if (rank != 0 && rank != count) return false;  // (lh_schedule_tree writes the running count here too)
+    } else {
+      if (rank != count) return false;
+      count += kind == lh::OP_POP_ACC ? 2 : 1;
+    }
+  }
+  return count == T - 3;
+}
+
 // Host pointers in, host pointers out.  The batch moves in sub-chunks through two pinned staging slots:
 // while the kernels of one sub-chunk run on the compute stream, a few host threads validate the next
 // sub-chunk's schedules and gather its inputs into the other slot, and the copy stream ships it.
@@ -1136,8 +1156,8 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
     }
     std::atomic<bool> bad{false};
     auto work = [&](int lo, int hi) {
-      for (size_t k = (size_t)lo * n_ops; k < (size_t)hi * n_ops; ++k)
-        if (!valid_op(ops + ((size_t)off * n_ops + k) * 4, T, (int)nodes, max_depth)) {
+      for (int i = lo; i < hi; ++i)
+        if (!valid_schedule(ops + ((size_t)off + i) * n_ops * 4, T, (int)nodes, max_depth)) {
           bad = true;
           return;
         }
@@ -1225,8 +1245,8 @@ int lh_eval_sample_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
   static const bool timing = std::getenv("LH_SAMPLE_TIMING") != nullptr;  // stage times of every call, on stderr
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto t0 = now();
-  for (size_t k = 0; k < (size_t)n * n_ops; ++k)
-    if (!valid_op(ops + k * 4, T, (int)nodes, max_depth))
+  for (size_t i = 0; i < (size_t)n; ++i)
+    if (!valid_schedule(ops + i * n_ops * 4, T, (int)nodes, max_depth))
       return fail("lh_eval_sample_batch: malformed schedule op (use lh_schedule_tree)");
   auto t1 = now();
   const lh::DevSampler& smp = f->sampler;
@@ -1404,8 +1424,8 @@ int lh_asr_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const in
   if (max_depth < 0 || max_depth > 16) return fail("lh_asr_batch: max_depth out of range");
   if (!ops || !brlen || !er || !pi || !rates || !naive || !anc) return fail("lh_asr_batch: null array");
   const size_t nodes = 2 * (size_t)T - 2, n_ops = (size_t)T - 2, L = f->host.n_sites;
-  for (size_t k = 0; k < (size_t)n * n_ops; ++k)
-    if (!valid_op(ops + k * 4, T, (int)nodes, max_depth))
+  for (size_t i = 0; i < (size_t)n; ++i)
+    if (!valid_schedule(ops + i * n_ops * 4, T, (int)nodes, max_depth))
       return fail("lh_asr_batch: malformed schedule op (use lh_schedule_tree)");
   for (size_t k = 0; k < (size_t)n * L; ++k)
     if (naive[k] > 4) return fail("lh_asr_batch: naive base out of range");

@@ -65,9 +65,16 @@ def main(mode, n_leaves):
         fam.status()             # the error state is reported once
     except RuntimeError as e:
         second = str(e)
-    # the same batch with the schedule as lh_schedule_tree wrote it: no error, and the other samples' values unchanged
     got = ll.cpu().numpy()
-    print(json.dumps({"status": status, "second": second, "ll": [None if not np.isfinite(x) else float(x) for x in got]}))
+    # the same corrupted batch through the HOST-pointer entry point: refused before anything reaches the device
+    host_error = ""
+    try:
+        fam.eval_batch(T, depth, ops, np.stack(brl), [r["er"] for r in rows], [r["pi"] for r in rows],
+                       [r["alpha"] for r in rows], 4)
+    except RuntimeError as e:
+        host_error = str(e)
+    print(json.dumps({"status": status, "second": second, "host_error": host_error,
+                      "ll": [None if not np.isfinite(x) else float(x) for x in got]}))
     fam.close()
 
 

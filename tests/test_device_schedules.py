@@ -27,10 +27,13 @@ def _run(mode, env_extra, n_leaves=12):
 def test_corrupted_device_schedule_gets_a_status_code(mode, form):
     env = {"LH_K1_TABLES": "1"} if form == "tables" else {}
     good = _run("none", env)
-    assert good["status"] == "" and all(x is not None for x in good["ll"])
-    if mode == "rank" and form == "tables":
-        return                        # the cherry-table form does not read the rank field at all
+    assert good["status"] == "" and good["host_error"] == "" and all(x is not None for x in good["ll"])
     bad = _run(mode, env)
+    # lh_eval_batch (host pointers) refuses the batch whatever the kernel form -- rank bits zeroed (ops built against the
+    # round-1 ABI) included: the rank of every op must be the running matrix count
+    assert "malformed schedule op" in bad["host_error"], bad
+    if mode == "rank" and form == "tables":
+        return                        # (on the device the cherry-table form does not read the rank field at all)
     assert "malformed schedule" in bad["status"], bad
     assert bad["second"] == ""                                   # reported once, then cleared
     assert bad["ll"][2] is None                                  # the corrupted sample: NaN

@@ -86,6 +86,23 @@ def test_synthetic_family_host_matches_oracle(tmp_path, locus):
         t = orc.parse_newick(r["tree"])
         total = sum(l for a in t.adj for _, l in a) / 2
         assert abs(flat["brlen"][i].sum() - total) < 1e-12
+    if locus == "igh":
+        # the table through a FIFO (no size to stat: the reader falls back to a sequential read, as the reference's
+        # streaming csv reader would): the same arrays
+        import threading
+        fifo = str(tmp_path / "trees.fifo")
+        os.mkfifo(fifo)
+        data = open(os.path.join(out, "trees.tsv"), "rb").read()
+
+        def feed():
+            with open(fifo, "wb") as f:
+                f.write(data)
+        th = threading.Thread(target=feed)
+        th.start()
+        piped = h.flatten_tsv(fifo, 7, need_family=False)
+        th.join()
+        for k in ("ops", "brlen", "er", "pi", "alpha"):
+            assert np.array_equal(piped[k], flat[k]), k
 
 
 def test_host_errors(data_dir, tmp_path):
