@@ -2,6 +2,7 @@
 
 #include <cerrno>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -68,6 +69,21 @@ void PhyloHMM::InitializeXmsaStructs() {
 }
 
 namespace {
+
+// Worker threads a host stage may start: the cores this process may run on (its affinity mask; a container's share can
+// be smaller than the machine), at most `cap`; LH_HOST_THREADS overrides the count (experiments, small containers).
+// The stages of RunPipeline run side by side with up to 16 workers each (measured on a 256-thread host, 262144 rows of
+// configs[2]: 8 workers 1.22 s, 16 1.02 s, 24 1.22 s, 32 1.05 s -- profiles/r03_pipeline_e2e.txt).
+int HostThreads(int cap) {
+  static const int avail = [] {
+    if (const char* e = std::getenv("LH_HOST_THREADS")) return std::max(1, std::atoi(e));
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n > 0 ? n : 1 << 20, CPU_COUNT(&set));
+    return std::max(1, n);
+  }();
+  return std::max(1, std::min(avail, cap));
+}
 
 SegmentTables MakeSegments(const GeneRanges& ranges, const VectorXi& inds) {
   SegmentTables s;
@@ -239,7 +255,7 @@ PhyloHMM::DeviceBatch PhyloHMM::FlattenBatch(const std::vector<TreeSample>& samp
       if (trees) (*trees)[s] = std::move(tr);
     }
   };
-  const int hw = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+  const int hw = HostThreads(16);
   const int n_threads = std::max(1, std::min(hw, b.n / 64));
   if (n_threads == 1) {
     flatten_rows(0, b.n, &b.max_depth);
@@ -552,7 +568,7 @@ struct FileBytes {
     b.n = (std::size_t)st.st_size;
     b.data.reset(new char[b.n + 1]);
     b.data[b.n] = '\0';
-    const int n_threads = b.n < (8u << 20) ? 1 : (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 8u));
+    const int n_threads = b.n < (8u << 20) ? 1 : HostThreads(8);
     std::vector<int> bad(n_threads, 0);
     auto part = [&](int w) {
       std::size_t lo = b.n * w / n_threads;
@@ -732,7 +748,7 @@ PhyloHMM::TableBatch PhyloHMM::FlattenTable(const TsvTable& t, std::size_t r0, s
       *max_depth = std::max(*max_depth, (int)depth);
     }
   };
-  const int hw = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+  const int hw = HostThreads(16);
   const int n_threads = (int)std::max<std::size_t>(1, std::min<std::size_t>(hw, m / 32));
   std::vector<std::thread> pool;
   std::vector<int> depths(n_threads, 0);
@@ -838,7 +854,10 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
   const std::size_t NS = dev_sampling ? (std::size_t)lh_sample_states(family_) : 0;
   // Two stages, two batches in flight: a producer thread parses / schedules batch k + 1 and has the GPU
   // evaluate it into one of two page-locked result slots while this thread's workers sample and format batch k.
-  const std::size_t kBatch = std::min<std::size_t>(2048, std::max<std::size_t>(N, 1));
+  // Batch size: a sixteenth of the table (the stages overlap batch by batch: few batches mean a long fill and drain),
+  // between 2048 rows and 16384 (768 tree samples fill the chip's resident workgroups once; from 8192 on the kernels run
+  // at their full-batch rate).
+  const std::size_t kBatch = std::min<std::size_t>(std::max<std::size_t>(N, 1), std::min<std::size_t>(16384, std::max<std::size_t>(2048, (N + 15) / 16)));
   struct Slot {
     TableBatch tb;
     double *ll = nullptr, *rates = nullptr, *fwd = nullptr;
@@ -898,10 +917,34 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
     parser_done = true;
     cv.notify_all();
   });
+  // The device sampler's random words: one engine stream in file order (a copy of rng_ that just runs on), drawn by a
+  // thread of its own, at most two batches ahead of the producer.
+  std::deque<std::vector<uint32_t>> drawn;
+  std::thread drawer([&] {
+    if (!dev_sampling) return;
+    try {
+      std::mt19937 word_rng = rng_;
+      for (std::size_t off = 0; off < N; off += kBatch) {
+        const std::size_t m = std::min(kBatch, N - off);
+        const auto t0 = now();
+        std::vector<uint32_t> w(m * (std::size_t)raw_per_sample);
+        for (uint32_t& x : w) x = (uint32_t)word_rng();
+        t_words += secs(t0, now());
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return drawn.size() < 2 || cancel; });
+        if (cancel) return;
+        drawn.push_back(std::move(w));
+        cv.notify_all();
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lock(mu);
+      if (!producer_error) producer_error = std::current_exception();
+      cv.notify_all();
+    }
+  });
   std::thread producer([&] {
     try {
       int k = 0;
-      std::mt19937 word_rng = rng_;  // rows are produced in file order: the engine copy just runs on
       for (std::size_t off = 0; off < N; off += kBatch, k ^= 1) {
         Slot& s = slots[k];
         const std::size_t m = std::min(kBatch, N - off);
@@ -926,9 +969,14 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
         const DeviceBatch& b = s.tb.dev;
         const auto t2 = now();
         if (dev_sampling) {
-          s.words.resize(m * (std::size_t)raw_per_sample);
-          for (uint32_t& w : s.words) w = (uint32_t)word_rng();
-          t_words += secs(t2, now());
+          {
+            std::unique_lock<std::mutex> lock(mu);
+            cv.wait(lock, [&] { return !drawn.empty() || cancel || producer_error; });
+            if (cancel || producer_error) return;
+            s.words = std::move(drawn.front());
+            drawn.pop_front();
+            cv.notify_all();
+          }
           if (more_families_.empty()) {
             CheckHip(lh_eval_sample_batch(family_, b.n, b.n_tips, b.max_depth, b.ops.data(), b.brlen.data(), b.er.data(),
                                           b.pi.data(), b.alpha.data(), num_rates, s.words.data(), s.ll, s.rates, s.states),
@@ -1010,16 +1058,17 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
       cv.notify_all();
     }
   });
-  struct Joiner {  // the two threads are stopped, joined and the slots are freed on every way out
-    std::thread &t, &t0;
+  struct Joiner {  // the three threads are stopped, joined and the slots are freed on every way out
+    std::thread &t, &t0, &t1;
     std::function<void()> before, after;
     ~Joiner() {
       before();
       if (t0.joinable()) t0.join();
+      if (t1.joinable()) t1.join();
       if (t.joinable()) t.join();
       after();
     }
-  } joiner{producer, parser,
+  } joiner{producer, parser, drawer,
            [&] {
              {
                std::lock_guard<std::mutex> lock(mu);
@@ -1048,7 +1097,7 @@ void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& out
     t_wait += secs(tw, t2);
     // rows of this batch except the table's very last one: sampled and formatted by the workers
     const std::size_t m_par = (off + m == N) ? m - 1 : m;
-    const int hw = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    const int hw = HostThreads(16);
     const int n_threads = (int)std::max<std::size_t>(1, std::min<std::size_t>(hw, m_par / 8));
     std::vector<std::string> chunks(n_threads);
     std::vector<std::exception_ptr> errors(n_threads);
@@ -1294,7 +1343,7 @@ void PhyloHMM::RunAsr(const std::string& input_path, const std::string& output_p
     // the annotated strings (86 KB per tree for 100 leaves x 400 sites) are most of this step's host time:
     // rows are formatted by several threads, written in order
     std::vector<std::string> lines(m);
-    const int hw = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    const int hw = HostThreads(16);
     const int n_threads = std::max(1, std::min(hw, (int)(m / 16)));
     auto format_rows = [&](std::size_t lo, std::size_t hi) {
       for (std::size_t i = lo; i < hi; ++i)
