@@ -76,7 +76,7 @@ namespace {
 // configs[2]: 8 workers 1.22 s, 16 1.02 s, 24 1.22 s, 32 1.05 s -- profiles/r03_pipeline_e2e.txt).
 int HostThreads(int cap) {
   static const int avail = [] {
-    if (const char* e = std::getenv("LH_HOST_THREADS")) return std::max(1, std::atoi(e));
+    if (host_options().host_threads > 0) return host_options().host_threads;
     int n = (int)std::thread::hardware_concurrency();
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n > 0 ? n : 1 << 20, CPU_COUNT(&set));
@@ -159,7 +159,7 @@ void PhyloHMM::CreateFamily() {
   // the right genes of a junction occupy two blocks of the junction's state vector, true for gene names that start
   // with their locus and segment letters -- is checked by the library; a family that does not meet it keeps the
   // host sampler (the same algorithm, HMM::SampleRow), and so does LH_HOST_SAMPLING=1.
-  if (std::getenv("LH_HOST_SAMPLING") == nullptr) {
+  if (!host_options().host_sampling) {
     SamplerJunction svd, sdj;
     lh_sampler_desc sd{};
     if (igh) {
@@ -771,7 +771,7 @@ PhyloHMM::TableBatch PhyloHMM::FlattenTable(const TsvTable& t, std::size_t r0, s
   for (const std::exception_ptr& e : errors)
     if (e) std::rethrow_exception(e);  // the first failing row range, in file order
   for (int d : depths) b.max_depth = std::max(b.max_depth, d);
-  if (std::getenv("LH_PIPELINE_TIMING"))
+  if (host_options().pipeline_timing)
     std::fprintf(stderr, "[FlattenTable] %zu rows on %d threads: %.3f s\n", m, n_threads,
                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   return tb;
@@ -780,7 +780,7 @@ PhyloHMM::TableBatch PhyloHMM::FlattenTable(const TsvTable& t, std::size_t r0, s
 PhyloHMM::DeviceBatch PhyloHMM::FlattenTsv(const std::string& path, int* n_rows) const {
   const auto t0 = std::chrono::steady_clock::now();
   TsvTable t = TsvTable::Read(path, "RevBayes output file");
-  if (std::getenv("LH_PIPELINE_TIMING"))
+  if (host_options().pipeline_timing)
     std::fprintf(stderr, "[FlattenTsv] read + line index %.3f s\n",
                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   const char* names[15] = {"alpha", "alpha", "alpha", "alpha", "er[1]", "er[2]", "er[3]", "er[4]",
@@ -821,7 +821,7 @@ PhyloHMM::DeviceBatch PhyloHMM::FlattenTsvRows(const std::string& path, const in
 // row on every run; the seed-0 goldens).  The last row also goes through the object's own members, which are then
 // in the state the reference's loop leaves behind.
 void PhyloHMM::RunPipeline(const std::string& input_path, const std::string& output_path, int num_rates) {
-  const bool timing = std::getenv("LH_PIPELINE_TIMING") != nullptr;
+  const bool timing = host_options().pipeline_timing;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double>(b - a).count();

@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
       return argc < 2 ? EXIT_FAILURE : EXIT_SUCCESS;
     }
     const auto t_main = std::chrono::steady_clock::now();
-    const bool timing = std::getenv("LH_PIPELINE_TIMING") != nullptr;
+    const bool timing = linearham::host_options().pipeline_timing;
     auto since_start = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(); };
     const std::string subcmd = argv[1];
     const Args a = Parse(argc, argv, 2);

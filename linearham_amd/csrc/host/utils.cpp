@@ -97,10 +97,21 @@ std::string FixGeneName(std::string name) {
   return name;
 }
 
+const HostOptions& host_options() {
+  static const HostOptions opts = [] {
+    HostOptions o;
+    o.pipeline_timing = std::getenv("LH_PIPELINE_TIMING") != nullptr;
+    o.host_sampling = std::getenv("LH_HOST_SAMPLING") != nullptr;
+    if (const char* e = std::getenv("LH_HOST_THREADS")) o.host_threads = std::max(1, std::atoi(e));
+    return o;
+  }();
+  return opts;
+}
+
 double StageTimer::Now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-StageTimer::StageTimer() : on(std::getenv("LH_PIPELINE_TIMING") != nullptr), t0(Now()) {}
+StageTimer::StageTimer() : on(host_options().pipeline_timing), t0(Now()) {}
 void StageTimer::Mark(const char* what) {
   if (!on) return;
   const double t = Now();

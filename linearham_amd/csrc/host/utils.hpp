@@ -69,6 +69,14 @@ inline void Require(bool cond, const std::string& what) {
   if (!cond) throw std::runtime_error("linearham: requirement failed: " + what);
 }
 
+/// The environment switches of the host library (test hooks; read once per process).
+struct HostOptions {
+  bool pipeline_timing = false;  // LH_PIPELINE_TIMING: stage times of RunPipeline / RunASR / main on stderr
+  bool host_sampling = false;    // LH_HOST_SAMPLING: HMM::SampleRow on the host even where the device sampler could run
+  int host_threads = 0;          // LH_HOST_THREADS=<n>: worker threads per host stage (0: from the affinity mask)
+};
+const HostOptions& host_options();
+
 /// Wall-clock marks printed to stderr when LH_PIPELINE_TIMING is set (where the host side of a run spends its time).
 struct StageTimer {
   bool on;

@@ -543,7 +543,7 @@ int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, co
                      fam.n_prune, fam.site_pat, site_lik, site_scal, naive, seed, sample0, rate_choice);
   const size_t sched_lds = (size_t)(T - 2) * (sizeof(int4) + 2 * sizeof(int32_t));
   hipLaunchKernelGGL(asr_sched_kernel, dim3(n), dim3(64), sched_lds, stream, T, ops, hdr, static_cast<AsrOp*>(desc));
-  static const int dbg = getenv("LH_ASR_DBG") ? atoi(getenv("LH_ASR_DBG")) : 0;  // phase-timing hook
+  static const int dbg = debug_options().asr_dbg;  // phase-timing hook
   hipLaunchKernelGGL(asr_kernel, dim3(R, n), dim3(256), lds, stream, R, T, L, fam.n_prune, fam.msa, fam.site_pat,
                      static_cast<const AsrOp*>(desc), brlen, rates, eig, pi, (const uint8_t*)rate_choice, naive, seed,
                      sample0, reinterpret_cast<double2*>(clv), (int)asr_slots(L, R), anc, dbg, hdr);

@@ -12,6 +12,34 @@
 
 #include "lh_device.h"
 
+namespace lh {
+const DebugOptions& debug_options() {
+  static const DebugOptions opts = [] {
+    DebugOptions o;
+    auto set = [](const char* name) { return std::getenv(name) != nullptr; };
+    auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+    o.chunk = std::max(256, num("LH_CHUNK", o.chunk));
+    o.k2a_direct = set("LH_K2A_DIRECT");
+    o.k2b_no_pair = set("LH_K2B_NO_PAIR");
+    o.k2b_vd_single = set("LH_K2B_VD_SINGLE");
+    o.sample_timing = set("LH_SAMPLE_TIMING");
+    o.k1_tile_cap = num("LH_K1_TILE_CAP", 0);
+    o.k1_cxx_walk = set("LH_K1_CXX_WALK");
+    o.k1_s4 = set("LH_K1_S4");
+    o.k1_tables = set("LH_K1_TABLES");
+    o.k1_no_tables = set("LH_K1_NO_TABLES");
+    o.k1_segments = set("LH_K1_SEGMENTS");
+    o.k1_seg_waves = num("LH_K1_SEG_WAVES", o.k1_seg_waves);
+    o.k1_no_fuse = set("LH_K1_NO_FUSE");
+    o.k1_persist = num("LH_K1_PERSIST", 0);
+    o.dbg_maxops = num("LH_DBG_MAXOPS", o.dbg_maxops);
+    o.asr_dbg = num("LH_ASR_DBG", 0);
+    return o;
+  }();
+  return opts;
+}
+}  // namespace lh
+
 namespace {
 
 thread_local std::string g_error;
@@ -161,7 +189,7 @@ int upload_vec(lh_family* f, const std::vector<T>& v, const T** out);
 // sites (xmsa_site known), the set spans at most 510 sites, and the form at least halves the factor count.
 int upload_consensus(lh_family* f, const lh_segments& s, const std::vector<int32_t>& ucol, int n_ucol,
                      const int32_t* xmsa_site, int scale, lh::DevSegments* d) {
-  const bool off = getenv("LH_K2A_DIRECT") != nullptr;  // test hook: always the factor-by-factor walk
+  const bool off = lh::debug_options().k2a_direct;  // test hook: always the factor-by-factor walk
   if (off || !xmsa_site || s.n_genes < 1) return 0;
   const int n = s.n_genes;
   int lo = INT32_MAX, hi = -1;
@@ -406,10 +434,9 @@ int stage(lh_family* f, int slot, size_t bytes, void** out) {
   return 0;
 }
 
-// LH_CHUNK: test hook (several groups inside one small call)
-static const int kChunk = getenv("LH_CHUNK") ? std::max(256, atoi(getenv("LH_CHUNK"))) : 49152;  // samples per launch group (bounds the workspace: ~150 KB per sample for a
-                               // 100-tip tree; a multiple of 6144 = whole rounds of all three kernels on
-                               // 256 CUs for configs[2]-like shapes)
+// samples per launch group (bounds the workspace: ~150 KB per sample for a 100-tip tree; a multiple of 6144 = whole
+// rounds of all three kernels on 256 CUs for configs[2]-like shapes); LH_CHUNK: test hook
+static const int kChunk = lh::debug_options().chunk;
 
 int run_forward(lh_family* f, int n, int R, const double* site_lik, const int32_t* site_scal, const double* pi,
                 const double* em_in, double* em_out, double* loglik_dev, const lh_eval_outputs* outs,
@@ -1262,7 +1289,7 @@ int lh_eval_sample_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
   if (T < 3) return fail("lh_eval_sample_batch: need at least 3 tips");
   if (!ops || !brlen || !er || !pi || !alpha || !words || !loglik || !states) return fail("lh_eval_sample_batch: null array");
   const size_t nodes = 2 * (size_t)T - 2, n_ops = (size_t)T - 2, FS = f->host.forward_size;
-  static const bool timing = std::getenv("LH_SAMPLE_TIMING") != nullptr;  // stage times of every call, on stderr
+  static const bool timing = lh::debug_options().sample_timing;  // stage times of every call, on stderr
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto t0 = now();
   auto t1 = now();

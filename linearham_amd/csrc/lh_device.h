@@ -231,4 +231,27 @@ void launch_forward(const DevFamily& fam, const DevFamily* fam_dev, int n, int R
                     bool extended, hipStream_t stream);
 size_t forward_lds_bytes(const DevFamily& fam);
 
+// Every environment switch of the device library in one place: test hooks and experiments, none of them part of the
+// C ABI.  Read once per process (the first call of debug_options(), lh_capi.hip); a switch that is not set leaves the
+// product behaviour.
+struct DebugOptions {
+  int chunk = 49152;           // LH_CHUNK=<n>: tree samples per launch group (tests: several groups inside one small call)
+  bool k2a_direct = false;     // LH_K2A_DIRECT: K2a walks every gene factor by factor (no consensus form)
+  bool k2b_no_pair = false;    // LH_K2B_NO_PAIR: K2b with one sample per wave
+  bool k2b_vd_single = false;  // LH_K2B_VD_SINGLE: one sample per V-D wave
+  bool sample_timing = false;  // LH_SAMPLE_TIMING: stage times of every lh_eval_sample_batch call on stderr
+  int k1_tile_cap = 0;         // LH_K1_TILE_CAP=<sites>: small K1 tiles, so that small families run the multi-tile path
+  bool k1_cxx_walk = false;    // LH_K1_CXX_WALK: the cherry-table form with its C++ walk instead of the assembly one
+  bool k1_s4 = false;          // LH_K1_S4: the assembly walk with four sites per lane (three waves per SIMD)
+  bool k1_tables = false;      // LH_K1_TABLES: the cherry-table form for the fused shapes too
+  bool k1_no_tables = false;   // LH_K1_NO_TABLES: the cherry-table form's kernels without tables
+  bool k1_segments = false;    // LH_K1_SEGMENTS: the segmented tip table (large trees) on small trees too
+  int k1_seg_waves = 4;        // LH_K1_SEG_WAVES=<4|5>: register budget of the segmented kernels
+  bool k1_no_fuse = false;     // LH_K1_NO_FUSE: one workgroup per (sample, rate)
+  int k1_persist = 0;          // LH_K1_PERSIST=<workgroups> (builds with -DLH_EXP_K1_PERSIST only)
+  int dbg_maxops = 1 << 30;    // LH_DBG_MAXOPS=<m> (builds with -DLH_DEBUG_WALK only): the walk stops after m ops
+  int asr_dbg = 0;             // LH_ASR_DBG=<phase>: K3 stops after a phase (timing hook)
+};
+const DebugOptions& debug_options();
+
 }  // namespace lh

@@ -1634,7 +1634,7 @@ static size_t junction_lds_bytes(const DevFamily& fam) {
 
 // Two samples per wave on the D-J junction (junction_kernel_pair): igh families with at most 32 D and J alleles.
 static bool junction_pair_form(const DevFamily& fam) {
-  static const bool off = getenv("LH_K2B_NO_PAIR") != nullptr;  // test hook: the one-sample-per-wave form
+  static const bool off = debug_options().k2b_no_pair;  // test hook: the one-sample-per-wave form
   return !off && fam.has_d && fam.dgerm.n_genes <= 32 && fam.jgerm.n_genes <= 32;
 }
 
@@ -1701,7 +1701,7 @@ static void launch_junction_g(const DevFamily& fam, int n, const double* gem, co
     const size_t lds_vd = ((size_t)kJunctionWaves * (fam.n_jcols + 1) + 16 * (size_t)fam.vd.right_pad) * sizeof(double);
     const size_t lds_dj = ((size_t)2 * kPairWaves * (fam.n_jcols + 1) + 16 * (size_t)fam.dj.right_pad) * sizeof(double);
     const dim3 grid_vd((n + kJunctionWaves - 1) / kJunctionWaves), grid_dj(((n + 1) / 2 + kPairWaves - 1) / kPairWaves);
-    static const bool vd_single = getenv("LH_K2B_VD_SINGLE") != nullptr;  // test hook: one sample per V-D wave
+    static const bool vd_single = debug_options().k2b_vd_single;  // test hook: one sample per V-D wave
     if (!vd_single && GA <= 4) {  // (beyond 256 V alleles the second sample's left-gene registers no longer fit)
       const size_t lds_vd2 = ((size_t)2 * kVdPairWaves * (fam.n_jcols + 1) + 16 * (size_t)fam.vd.right_pad) * sizeof(double);
       const dim3 grid_vd2(((n + 1) / 2 + kVdPairWaves - 1) / kVdPairWaves);

@@ -1451,7 +1451,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   const PruneWsSizes sizes = prune_ws_sizes(T, fam.msa_mixed_n != 0);
 #ifdef LH_DEBUG_WALK
   {
-    const int m = getenv("LH_DBG_MAXOPS") ? atoi(getenv("LH_DBG_MAXOPS")) : 1 << 30;
+    const int m = debug_options().dbg_maxops;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(lh_dbg_max_ops), &m, sizeof(m));
   }
 #endif
@@ -1466,7 +1466,8 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   // rebalanced so that they are equally full.  Large tiles matter for large trees: every workgroup of a (sample,
   // rate) repeats the P-matrix prologue and holds its own T x 128-byte tip table in LDS.
   // (LH_K1_TILE_CAP: test hook that forces small tiles so that the multi-tile path runs on small families)
-  static const int cap_env = getenv("LH_K1_TILE_CAP") ? atoi(getenv("LH_K1_TILE_CAP")) : 0;
+  const DebugOptions& dbg = debug_options();
+  const int cap_env = dbg.k1_tile_cap;
   const int cap = cap_env >= 64 ? std::min(cap_env, 1024) : 1024;
   const int tiles = (L + cap - 1) / cap;
   const int tile = (L + tiles - 1) / tiles;
@@ -1475,13 +1476,10 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   // multiples of 256 sites -- measured on configs[2]: the same time per op as two sites per lane at six waves;
   // LH_K1_TABLES makes the cherry-table form the choice for the fused shapes too (default: the register-stack form,
   // which is faster there: DESIGN.md section 6); LH_K1_NO_TABLES: the cherry-table form without tables.
-  static const bool cxx_walk = getenv("LH_K1_CXX_WALK") != nullptr;
-  static const bool s4_env = getenv("LH_K1_S4") != nullptr;
-  static const bool tables_env = getenv("LH_K1_TABLES") != nullptr;
-  static const bool no_tables = getenv("LH_K1_NO_TABLES") != nullptr;
-  static const bool seg_env = getenv("LH_K1_SEGMENTS") != nullptr;  // test hook: segments on small trees too
-  static const int seg_waves = getenv("LH_K1_SEG_WAVES") ? atoi(getenv("LH_K1_SEG_WAVES")) : 4;  // measured: 4 (128 VGPRs, few spills) beats 5 by 9 %
-  static const bool no_fuse = getenv("LH_K1_NO_FUSE") != nullptr;  // test hook: one workgroup per (sample, rate)
+  const bool cxx_walk = dbg.k1_cxx_walk, s4_env = dbg.k1_s4, tables_env = dbg.k1_tables, no_tables = dbg.k1_no_tables;
+  const bool seg_env = dbg.k1_segments;   // test hook: segments on small trees too
+  const int seg_waves = dbg.k1_seg_waves; // measured: 4 (128 VGPRs, few spills) beats 5 by 9 %
+  const bool no_fuse = dbg.k1_no_fuse;    // test hook: one workgroup per (sample, rate)
   const bool use_asm = !cxx_walk && !fam.msa_mixed_n;
   // (four sites per lane not for large trees: 160 KB / tip table < 3 workgroups means the segmented form, two-site waves)
   const bool s4 = use_asm && s4_env && (tile % 256 == 0 || tile % 256 > 192) && (size_t)T * 128 * 3 <= 160 * 1024 && !seg_env;
@@ -1519,7 +1517,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
 #ifdef LH_EXP_K1_PERSIST
   // LH_K1_PERSIST=<workgroups>: the register-stack kernels with that many workgroups, each working through samples
   // z, z + grid.z, ... with one scratch slot
-  static const int persist = getenv("LH_K1_PERSIST") ? atoi(getenv("LH_K1_PERSIST")) : 0;
+  const int persist = dbg.k1_persist;
   if (persist > 0 && (stack_fused || seg)) grid.z = std::min(n, persist);
 #endif
   const int n_ops = T - 2;
