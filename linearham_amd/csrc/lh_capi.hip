@@ -19,7 +19,6 @@ const DebugOptions& debug_options() {
     auto set = [](const char* name) { return std::getenv(name) != nullptr; };
     auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
     o.chunk = std::max(256, num("LH_CHUNK", o.chunk));
-    o.k2a_direct = set("LH_K2A_DIRECT");
     o.k2b_no_pair = set("LH_K2B_NO_PAIR");
     o.k2b_vd_single = set("LH_K2B_VD_SINGLE");
     o.sample_timing = set("LH_SAMPLE_TIMING");
@@ -29,6 +28,7 @@ const DebugOptions& debug_options() {
     o.k1_tables = set("LH_K1_TABLES");
     o.k1_no_tables = set("LH_K1_NO_TABLES");
     o.k1_segments = set("LH_K1_SEGMENTS");
+    o.k1_no_segments = set("LH_K1_NO_SEGMENTS");
     o.k1_seg_waves = num("LH_K1_SEG_WAVES", o.k1_seg_waves);
     o.k1_no_fuse = set("LH_K1_NO_FUSE");
     o.k1_persist = num("LH_K1_PERSIST", 0);
@@ -189,7 +189,9 @@ int upload_vec(lh_family* f, const std::vector<T>& v, const T** out);
 // sites (xmsa_site known), the set spans at most 510 sites, and the form at least halves the factor count.
 int upload_consensus(lh_family* f, const lh_segments& s, const std::vector<int32_t>& ucol, int n_ucol,
                      const int32_t* xmsa_site, int scale, lh::DevSegments* d) {
-  const bool off = lh::debug_options().k2a_direct;  // test hook: always the factor-by-factor walk
+  // test hook: always the factor-by-factor walk (a property of the family being created: read here, so that a test can
+  // build both forms in one process)
+  const bool off = std::getenv("LH_K2A_DIRECT") != nullptr;
   if (off || !xmsa_site || s.n_genes < 1) return 0;
   const int n = s.n_genes;
   int lo = INT32_MAX, hi = -1;
@@ -1102,7 +1104,8 @@ static bool valid_schedule(const int32_t* ops, int T, int nodes, int max_depth) 
     if (!valid_op(op, T, nodes, max_depth)) return false;
     const int kind = op[0] & 15, rank = op[0] >> lh::OP_RANK_SHIFT;
     if (kind == lh::OP_CHERRY) {
-      if (rank != 0 && rank != count) return false;  // (lh_schedule_tree writes the running count here too)
+      if (rank != 0 && rank != count) return false;
+      if (((op[0] & lh::OP_PUSH_FLAG) != 0) != (k != 0)) return false;  // the first op has no accumulator to set aside, every later cherry does
     } else {
       if (rank != count) return false;
       count += kind == lh::OP_POP_ACC ? 2 : 1;

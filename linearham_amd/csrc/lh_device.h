@@ -236,7 +236,8 @@ size_t forward_lds_bytes(const DevFamily& fam);
 // product behaviour.
 struct DebugOptions {
   int chunk = 49152;           // LH_CHUNK=<n>: tree samples per launch group (tests: several groups inside one small call)
-  bool k2a_direct = false;     // LH_K2A_DIRECT: K2a walks every gene factor by factor (no consensus form)
+  // (LH_K2A_DIRECT -- K2a walks every gene factor by factor, no consensus form -- is a property of a family and is read
+  // when one is created: upload_consensus, lh_capi.hip)
   bool k2b_no_pair = false;    // LH_K2B_NO_PAIR: K2b with one sample per wave
   bool k2b_vd_single = false;  // LH_K2B_VD_SINGLE: one sample per V-D wave
   bool sample_timing = false;  // LH_SAMPLE_TIMING: stage times of every lh_eval_sample_batch call on stderr
@@ -246,6 +247,7 @@ struct DebugOptions {
   bool k1_tables = false;      // LH_K1_TABLES: the cherry-table form for the fused shapes too
   bool k1_no_tables = false;   // LH_K1_NO_TABLES: the cherry-table form's kernels without tables
   bool k1_segments = false;    // LH_K1_SEGMENTS: the segmented tip table (large trees) on small trees too
+  bool k1_no_segments = false; // LH_K1_NO_SEGMENTS: large trees through the cherry-table form (whole tip table in LDS)
   int k1_seg_waves = 4;        // LH_K1_SEG_WAVES=<4|5>: register budget of the segmented kernels
   bool k1_no_fuse = false;     // LH_K1_NO_FUSE: one workgroup per (sample, rate)
   int k1_persist = 0;          // LH_K1_PERSIST=<workgroups> (builds with -DLH_EXP_K1_PERSIST only)

@@ -814,7 +814,7 @@ __device__ __forceinline__ void prune_body(int sample, int slot, int n2, int til
           const bool push = (op.x & OP_PUSH_FLAG) != 0;
           // the op's fields: everything the walk indexes with (tips: MSA rows and tip-table entries; slots: registers)
           bool ok = op.x >= 0 && (op.x & 0xe0) == 0 && kind <= OP_POP_ACC;
-          if (kind == OP_CHERRY) ok = ok && op.y >= 1 && op.y < T && op.z >= 1 && op.z < T && (push || k == 0);
+          if (kind == OP_CHERRY) ok = ok && op.y >= 1 && op.y < T && op.z >= 1 && op.z < T && push == (k != 0);
           if (kind == OP_TIP_ACC) ok = ok && !push && k > 0 && op.y >= 1 && op.y < T && op.z >= T && op.z < nodes;
           if (kind == OP_POP_ACC) ok = ok && !push && k > 0 && op.y >= T && op.y < nodes && op.z >= T && op.z < nodes;
           if (push || kind == OP_POP_ACC) ok = ok && op.w >= 0 && op.w < kDepth;
@@ -1016,36 +1016,55 @@ __device__ __forceinline__ void matvec_v(const double (&p)[16], const double (&a
   x[3] = fma(p[15], a[3], fma(p[14], a[2], fma(p[13], a[1], p[12] * a[0])));
 }
 
-// K0c: one thread per sample checks the schedule (kinds, node ranges, stack discipline: everything K1 indexes with)
-// and writes the walk descriptors (WalkOp above; lh_device.h), the list of branch nodes whose P-matrices the walk
-// consumes (in that order) and the list of cherry tables.  A malformed schedule gets an empty walk, hdr.w = 1 (K1
+// K0c: one wave per sample checks the schedule (kinds, node ranges, stack discipline: everything K1 indexes with) and
+// -- rewrite != 0 -- writes the walk descriptors (WalkOp above; lh_device.h), the branch length of every P-matrix the
+// walk consumes (in that order) and the list of cherry tables.  A malformed schedule gets an empty walk, hdr.w = 1 (K1
 // then leaves NaN) and sets *err_flag, which lh_family_status reports: device-resident schedules are not trusted.
+// The check is a serial walk over the T - 2 ops, so it is organised around latency: the wave copies the sample's ops
+// into LDS (coalesced; ops_in_lds == 0: trees too large for that, read from global memory), walks them on the scalar unit
+// and notes the NODE of every matrix in LDS, then all lanes fetch those nodes' branch lengths side by side.  (One thread
+// per sample, loading each branch length where it was needed: 0.86 ms per 6144 samples of a 501-tip tree; this form:
+// profiles/r03_config4.txt.)
+// Dynamic LDS: [ops_in_lds ? n_ops : 0] int4 | [n_ops] int matrix nodes | [tabs_stride] int table nodes | [4 + 16] int.
 __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int max_depth, int tabs_stride, int use_tables,
+                                                            int rewrite, int ops_in_lds,
                                                             const int32_t* __restrict__ ops,
                                                             const double* __restrict__ brlen, int2* __restrict__ wops,
                                                             double* __restrict__ wlen, int4* __restrict__ tabs,
                                                             int4* __restrict__ hdr, int32_t* err_flag) {
-  const int smp = blockIdx.x * 64 + threadIdx.x;
-  if (smp >= n) return;
+  extern __shared__ int4 k0c_lds[];
+  const int smp = blockIdx.x;
+  const int lane = threadIdx.x;
   const int n_ops = T - 2, nodes = 2 * T - 2;
-  const int4* __restrict__ o = reinterpret_cast<const int4*>(ops) + (size_t)smp * n_ops;
+  const int4* __restrict__ og = reinterpret_cast<const int4*>(ops) + (size_t)smp * n_ops;
+  int* mnode = reinterpret_cast<int*>(k0c_lds + (ops_in_lds ? n_ops : 0));
+  int* tnode = mnode + n_ops;
+  int* verdict = tnode + tabs_stride;  // [4]: n_w, n_mat, n_tab, bad (for the lanes' second phase)
+  int* pend = verdict + 4;             // [16] per stack slot of the rewritten walk: where the pushed subtree's matrix sits in the walk's list
+  if (ops_in_lds) {
+    for (int k = lane; k < n_ops; k += 64) k0c_lds[k] = og[k];
+    __syncthreads();
+  }
   int2* wo = wops + (size_t)smp * n_ops;
-  // branch length of every inner-branch matrix K1's prologue computes, in the order it stores them: the walk's
-  // matrices in walk order, then the cherry branches' (table c at n_mat + c, written below once n_mat is known)
-  double* ml = wlen + (size_t)smp * n_ops;
-  const double* __restrict__ bl = brlen + (size_t)smp * nodes;
   int4* tl = tabs + (size_t)smp * tabs_stride;
+  // The walk itself is the same in every lane and written so that the compiler keeps it on the scalar unit: every op
+  // field passes through readfirstlane, all branches are uniform; lane 0 alone stores.
+  const bool first = lane == 0;
+  auto load_op = [&](int k) {
+    const int4 v = ops_in_lds ? k0c_lds[k] : og[k];
+    return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
+                     __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+  };
   int depth = 0, n_w = 0, n_mat = 0, n_tab = 0;
   int bdepth = 0;  // stack depth of the schedule as written (depth: of the rewritten walk, which pushes less)
-  int pend[16];    // per stack slot of the rewritten walk: where the pushed subtree's branch length goes in `wlen`
   bool bad = false;
   auto tip_ok = [&](int v) { return v >= 1 && v < T; };
   auto inner_ok = [&](int v) { return v >= T && v < nodes; };
   int k = 0;
-  int4 op = o[0];
+  int4 op = load_op(0);
   while (k < n_ops && !bad) {
     const bool has_next = k + 1 < n_ops;
-    const int4 nx = has_next ? o[k + 1] : make_int4(15, 0, 0, 0);
+    const int4 nx = has_next ? load_op(k + 1) : make_int4(15, 0, 0, 0);
     const int kind = op.x & 15;
     const bool push = (op.x & OP_PUSH_FLAG) != 0;
     if (op.x < 0 || (op.x & 0xe0)) bad = true;
@@ -1054,7 +1073,7 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
     if (kind == OP_CHERRY) {
       if (!tip_ok(op.y) || !tip_ok(op.z)) bad = true;
       if (push && (op.w != bdepth || bdepth >= max_depth || depth >= 16 || n_mat >= n_ops)) bad = true;
-      if (!push && k != 0) bad = true;  // a cherry that does not push would overwrite a live accumulator
+      if (push != (k != 0)) bad = true;  // a later cherry that does not push would overwrite a live accumulator; the first has none to push
       const int nk = nx.x & 15;
       const bool nx_plain = nx.x >= 0 && (nx.x & 0xf0) == 0;
       if (bad) {
@@ -1062,19 +1081,27 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
                  inner_ok(nx.z) && n_tab < tabs_stride) {
         // the cherry is the whole second subtree: the first one stays in the accumulator, nothing is pushed
         w = make_int2(W_CTAB_ACC | WOP_MATRIX | WOP_HAS_B | (op.y << 16), op.z | (1 << 16));
-        ml[n_mat++] = bl[nx.y];
-        tl[n_tab++] = make_int4(op.y, op.z, nx.z, 0);
+        if (first) {
+          mnode[n_mat] = nx.y;
+          tnode[n_tab] = nx.z;
+          if (rewrite) tl[n_tab] = make_int4(op.y, op.z, nx.z, 0);
+        }
+        ++n_mat, ++n_tab;
         step = 2;
       } else {
         int pushbits = 0;
         if (push) {  // the accumulator is set aside as P_first a: the matrix's node is named by the matching pop
           pushbits = WOP_MATRIX | ((depth + 1) << WOP_PUSH_SHIFT);
-          pend[depth] = n_mat++;
-          ++depth, ++bdepth;
+          if (first) pend[depth] = n_mat;
+          ++n_mat, ++depth, ++bdepth;
         }
         if (use_tables && has_next && nk == OP_TIP_ACC && nx_plain && tip_ok(nx.y) && inner_ok(nx.z) && n_tab < tabs_stride) {
           w = make_int2(W_CTIP | pushbits | WOP_HAS_B | WOP_HAS_C | (op.y << 16), op.z | (nx.y << 16));
-          tl[n_tab++] = make_int4(op.y, op.z, nx.z, 0);
+          if (first) {
+            tnode[n_tab] = nx.z;
+            if (rewrite) tl[n_tab] = make_int4(op.y, op.z, nx.z, 0);
+          }
+          ++n_tab;
           step = 2;
         } else {
           w = make_int2(W_CHERRY | pushbits | WOP_HAS_B | (op.y << 16), op.z | (1 << 16));
@@ -1085,7 +1112,8 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
         bad = true;
       } else {
         w = make_int2(W_TIP_ACC | WOP_MATRIX | (op.y << 16), 1 | (1 << 16));
-        ml[n_mat++] = bl[op.z];
+        if (first) mnode[n_mat] = op.z;
+        ++n_mat;
       }
     } else if (kind == OP_POP_ACC) {
       if (push || bdepth < 1 || depth < 1 || op.w != bdepth - 1 || !inner_ok(op.y) || !inner_ok(op.z) || n_mat >= n_ops) {
@@ -1093,23 +1121,64 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
       } else {
         --depth, --bdepth;
         w = make_int2(W_POP | WOP_MATRIX | (depth << WOP_POP_SHIFT) | (1 << 16), 1 | (1 << 16));
-        ml[pend[depth]] = bl[op.y];  // the popped child: its matrix was applied at the push
-        ml[n_mat++] = bl[op.z];      // the child whose CLV is in the accumulator
+        if (first) {
+          mnode[pend[depth]] = op.y;  // the popped child: its matrix was applied at the push
+          mnode[n_mat] = op.z;        // the child whose CLV is in the accumulator
+        }
+        ++n_mat;
       }
     } else {
       bad = true;
     }
-    if (!bad) wo[n_w++] = w;
+    if (!bad) {
+      if (rewrite && first) wo[n_w] = w;
+      ++n_w;
+    }
     k += step;
-    if (k < n_ops) op = step == 2 ? o[k] : nx;
+    if (k < n_ops) op = step == 2 ? load_op(k) : nx;
   }
   if (depth != 0 || bdepth != 0 || n_mat + n_tab > T - 3) bad = true;  // (the scratch area holds T - 3 matrices per rate)
-  if (bad) {
-    hdr[smp] = make_int4(0, 0, 0, 1);
+  if (first) {
+    if (bad) {
+      hdr[smp] = make_int4(0, 0, 0, 1);
+      atomicOr(err_flag, 1);
+    } else {
+      hdr[smp] = make_int4(n_w, n_mat, n_tab, 0);
+    }
+  }
+  if (!rewrite || bad) return;
+  __syncthreads();
+  // branch length of every inner-branch matrix K1's prologue computes, in the order it stores them: the walk's matrices
+  // in walk order, then the cherry branches' (table c at n_mat + c)
+  double* ml = wlen + (size_t)smp * n_ops;
+  const double* __restrict__ bl = brlen + (size_t)smp * nodes;
+  for (int i = lane; i < n_mat; i += 64) ml[i] = bl[mnode[i]];
+  for (int c = lane; c < n_tab; c += 64) ml[n_mat + c] = bl[tnode[c]];
+}
+
+// The register-stack kernels for large trees (segmented tip table) walk the schedule as lh_schedule_tree wrote it; what
+// they need from a device-resident schedule is that nothing in it indexes out of bounds: one thread per op checks the
+// fields the kernel indexes with (tips: MSA rows and branch lengths; nodes: branch lengths; slots: registers).  hdr is
+// cleared before the launch; any bad op marks its sample (hdr.w: K1 leaves NaN there) and sets *err_flag.  (A schedule
+// that breaks stack discipline within those bounds computes a wrong number without touching foreign memory; K0c, which
+// also checks the discipline, runs where the walk is rewritten anyway.)
+__global__ void __launch_bounds__(256) schedule_fields_kernel(int n, int T, int slots, const int32_t* __restrict__ ops,
+                                                              int4* __restrict__ hdr, int32_t* err_flag) {
+  const int n_ops = T - 2, nodes = 2 * T - 2;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)n * n_ops) return;
+  const int smp = (int)(i / n_ops), k = (int)(i - (size_t)smp * n_ops);
+  const int4 op = reinterpret_cast<const int4*>(ops)[i];
+  const int kind = op.x & 15;
+  const bool push = (op.x & OP_PUSH_FLAG) != 0;
+  bool ok = op.x >= 0 && (op.x & 0xe0) == 0 && kind <= OP_POP_ACC;
+  if (kind == OP_CHERRY) ok = ok && op.y >= 1 && op.y < T && op.z >= 1 && op.z < T && push == (k != 0);
+  if (kind == OP_TIP_ACC) ok = ok && !push && k > 0 && op.y >= 1 && op.y < T && op.z >= T && op.z < nodes;
+  if (kind == OP_POP_ACC) ok = ok && !push && k > 0 && op.y >= T && op.y < nodes && op.z >= T && op.z < nodes;
+  if (push || kind == OP_POP_ACC) ok = ok && op.w >= 0 && op.w < slots;
+  if (!ok) {
+    hdr[smp].w = 1;
     atomicOr(err_flag, 1);
-  } else {
-    for (int c = 0; c < n_tab; ++c) ml[n_mat + c] = bl[tl[c].z];
-    hdr[smp] = make_int4(n_w, n_mat, n_tab, 0);
   }
 }
 
@@ -1455,9 +1524,17 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
     (void)hipMemcpyToSymbol(HIP_SYMBOL(lh_dbg_max_ops), &m, sizeof(m));
   }
 #endif
+  // K0c: one wave per sample; the sample's ops staged in LDS while they fit (16 bytes per op)
+  auto launch_k0c = [&](bool use_tables, bool rewrite) {
+    const size_t n_ops_k = (size_t)std::max(T - 2, 1);
+    const size_t tail = (n_ops_k + sizes.tabs_per_sample + 20) * sizeof(int);
+    const bool in_lds = n_ops_k * 16 + tail <= 48 * 1024;
+    hipLaunchKernelGGL(schedule_check_kernel, dim3(n), dim3(64), (in_lds ? n_ops_k * 16 : 0) + tail, stream, n, T, max_depth,
+                       (int)sizes.tabs_per_sample, use_tables ? 1 : 0, rewrite ? 1 : 0, in_lds ? 1 : 0, ops, brlen, ws.wops,
+                       ws.wlen, ws.tabs, ws.hdr, ws.err_flag);
+  };
   if (L == 0) {               // nothing but all-N padding (K2a reads no plane at all): the schedules still get checked
-    hipLaunchKernelGGL(schedule_check_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, T, max_depth,
-                       (int)sizes.tabs_per_sample, 1, ops, brlen, ws.wops, ws.wlen, ws.tabs, ws.hdr, ws.err_flag);
+    launch_k0c(false, false);
     return R;
   }
   double* pmat = ws.scratch;
@@ -1504,13 +1581,20 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   const size_t fused_lds = std::max((size_t)R * tip_bytes + tail_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
   const bool fused = allow_fused && !no_fuse && R * wpr <= 8 && fused_lds <= 53 * 1024 && !seg_env;
   // large trees: with the whole tip table in LDS fewer than five waves per SIMD would be resident
-  const bool seg = max_depth <= 4 && !fused && ((160 * 1024 / tip_bytes) * wpr / 4 < 5 || seg_env);
+  const bool seg = max_depth <= 4 && !fused && ((160 * 1024 / tip_bytes) * wpr / 4 < 5 || seg_env) && !dbg.k1_no_segments;
   // the register-stack form with all rates in one workgroup checks its schedules in its own prologue; everything else
   // runs behind K0c
   const bool stack_fused = fused && max_depth <= 4 && !tables_env && !no_tables && !s4;
-  if (!stack_fused)
-    hipLaunchKernelGGL(schedule_check_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, T, max_depth,
-                       (int)sizes.tabs_per_sample, no_tables ? 0 : 1, ops, brlen, ws.wops, ws.wlen, ws.tabs, ws.hdr, ws.err_flag);
+  // (the register-stack kernels for large trees walk the schedule as written: a field check is all they need)
+  if (seg && allow_fused) {
+    (void)hipMemsetAsync(ws.hdr, 0, sizeof(int4) * (size_t)n, stream);
+    const size_t total = (size_t)n * (size_t)(T - 2);
+    hipLaunchKernelGGL(schedule_fields_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, n, T, 4, ops, ws.hdr,
+                       ws.err_flag);
+  } else if (!stack_fused) {
+    // (seg here: the ancestral-sequence step, whose own kernels follow the stack through the schedule -- full check, no rewrite)
+    launch_k0c(!no_tables && !seg, !seg);
+  }
   const size_t lds = fused ? fused_lds : seg ? (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) : tip_bytes + tail_bytes;
   const int wg_waves = fused ? R * wpr : wpr;
   dim3 grid(tiles, fused ? 1 : R, n), block(64 * wg_waves);
