@@ -1,12 +1,12 @@
 """Debug helper (GPU box): evaluates a synthetic family with the assembly walk and with the C++ walk
 (LH_K1_CXX_WALK=1, separate processes) and prints where their per-column emissions differ.
-usage: python tools/debug_walk.py [n_leaves] [seed]"""
+usage: python tests/dev_tools/debug_walk.py [n_leaves] [seed]"""
 import json
 import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

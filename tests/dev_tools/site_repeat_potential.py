@@ -7,9 +7,9 @@ all of its patterns (in alignment order and with patterns clustered by where the
 guide tree).  Result (profiles/r02_site_repeat_potential.txt): 35 % of the pairs are mixed -- a 2.9x saving
 exists per lane -- but a wave still has to execute 88-97 % of the ops, so the saving is out of reach of a
 walk that keeps CLVs in registers with one pattern per lane.
-usage: python tools/site_repeat_potential.py [family dir made by tools/synth_family.py]"""
+usage: python tests/dev_tools/site_repeat_potential.py [family dir made by tools/synth_family.py]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tools import synth_family as sf
 from oracle import linearham_oracle as orc
