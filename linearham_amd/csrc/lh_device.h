@@ -88,9 +88,13 @@ struct DevJunction {
 //  * identical alignment columns (site patterns) are pruned once: K1 runs over the n_pat distinct
 //    columns of the MSA, msa is stored pattern-major;
 //  * xMSA columns that pair the same naive base with the same pattern have the same emission: K2 works
-//    on the n_ucol distinct (naive base, pattern) pairs ("u-columns", sorted by base then pattern so that
-//    neighbouring lanes read neighbouring entries of K1's output planes); every index table below is in
-//    u-column space.  Families without an alignment (n_seqs == 0) keep their columns one to one.
+//    on (naive base, pattern) pairs ("u-columns").  With an alignment there are always n_ucol = 5 n_prune + 5 slots,
+//    numbered by their place in K1's output planes: u = base * n_prune + pattern, the all-N pattern's five pairs last;
+//    a pair no xMSA column uses keeps its slot (u_base = 0xff), so K2a fills its emission vector from the planes
+//    without a look-up.  Every index table below is in u-column space.  Limits that follow: K2a's LDS emission vector
+//    takes (n_ucol + 1) * 8 = (5 n_prune + 6) * 8 bytes per sample, and the segment index chunks can hold 16-bit BYTE
+//    offsets (idx_byte_offsets) while that is < 65 536, i.e. n_prune <= 1637.  Families without an alignment
+//    (n_seqs == 0) keep their columns one to one.
 struct DevFamily {
   int32_t has_d, n_seqs, n_sites, n_xmsa;  // as described by the caller
   int32_t n_pat;                           // distinct alignment columns
