@@ -478,18 +478,28 @@ typedef __attribute__((address_space(3))) const char* lds_ptr;
 #define LH_WALK_ASM_OPERANDS                                                                                             \
   [nw] "s"(n_w), [wops] "s"(wops), [pm] "s"(pm), [ctoff] "s"(ctoff), [msa] "s"(msa_m), [L] "s"(L), [tip] "s"(tip_lds),  \
       [site0] "s"(site_base), [last] "s"(last_site), [out] "v"((private_ptr)out_mem), [deep] "v"((private_ptr)deep_mem)
-template <int kDepth, int S>
+// kTipsG: the tip table sits in the scratch region (tip_off bytes behind pm) instead of LDS (large trees).
+template <int kDepth, int S, bool kTipsG = false>
 __device__ __forceinline__ void prune_wave_asm(int site_base, int site_end, const uint8_t* __restrict__ msa, int L, int n_w,
-                                               const WalkOp* __restrict__ wops, pmat_ptr pm, unsigned ctoff,
+                                               const WalkOp* __restrict__ wops, pmat_ptr pm, unsigned ctoff, unsigned tip_off,
                                                const double* tiptab, const double* naive_tab,
                                                const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
   static_assert(S == 2 || S == 4, "the assembly walk exists for two and four sites per lane");
   __attribute__((aligned(16))) double out_mem[4 * S + 2];                                   // a[S][4], then the packed scaler counts
   __attribute__((aligned(16))) double deep_mem[(kDepth > 1 ? kDepth - 1 : 1) * 4 * S];     // stack slots 1.. : [slot][site][4]
   const uint8_t* msa_m = msa - L;
-  const unsigned tip_lds = (unsigned)(size_t)(lds_ptr)tiptab;
+  const unsigned tip_lds = kTipsG ? tip_off : (unsigned)(size_t)(lds_ptr)tiptab;
   const int last_site = site_end - 1;
-  if constexpr (S == 2) {
+  static_assert(!kTipsG || S == 2, "tip columns from the scratch region: two sites per lane only");
+  if constexpr (S == 2 && kTipsG) {
+    asm volatile(
+#include "lh_prune_walk_asm_s2g.inc"
+        :
+        : LH_WALK_ASM_OPERANDS
+        : "memory", "vcc", "scc",
+#include "lh_prune_walk_clobbers_s2.inc"
+    );
+  } else if constexpr (S == 2) {
     asm volatile(
 #include "lh_prune_walk_asm_s2.inc"
         :
@@ -1185,7 +1195,7 @@ __global__ void __launch_bounds__(256) schedule_fields_kernel(int n, int T, int 
 // The workgroup of the cherry-table form.  Block layout as prune_body (n2 two-site waves + n1 one-site waves per rate;
 // kFused: all R rates of the sample in one workgroup, mixed at the end).  scratch: this (sample, rate)'s region of
 // rate_stride doubles: [n_mat + n_tab][16] P-matrices | [n_tab][E][4] tables.
-template <int kDepth, bool kN, bool kFused, int kS = 2, bool kAsm = false>
+template <int kDepth, bool kN, bool kFused, int kS = 2, bool kAsm = false, bool kTipsG = false>
 __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, const uint8_t* __restrict__ msa, int L,
                                               int T, const int2* __restrict__ wops, const double* __restrict__ wlen,
                                               const int4* __restrict__ tabs, int tabs_stride,
@@ -1213,11 +1223,15 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
   const bool malformed = h.w != 0;
   double* pw = pmat_w + ((size_t)sample * R + rate) * rate_stride;
   double* ctab = pw + (size_t)(T - 3 > 0 ? T - 3 : 0) * 16;
-  double* tiptab = reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);
+  // kTipsG (large trees: a 64 KB tip table in LDS would leave two workgroups per CU): the tip table [T][4][4] sits in the
+  // scratch region behind the cherry tables; the walk gathers its columns with vector loads, as it does table entries
+  static_assert(!kTipsG || !kFused, "tip tables in the scratch region: unfused kernels only");
+  const size_t tip_off = (size_t)(T - 3 > 0 ? T - 3 : 0) * 16 + (size_t)tabs_stride * E * 4;  // doubles
+  double* tiptab = kTipsG ? pw + tip_off : reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rate * T * 16 : 0);
   const double* naive_tab = tiptab;
   const int4* __restrict__ tl = tabs + (size_t)sample * tabs_stride;
   // the walk descriptors go to LDS behind the tip tables (one copy per workgroup) for the waves that run the C++ walk
-  WalkOp* desc = reinterpret_cast<WalkOp*>(reinterpret_cast<double*>(smem2) + (size_t)(kFused ? R : 1) * T * 16);
+  WalkOp* desc = reinterpret_cast<WalkOp*>(reinterpret_cast<double*>(smem2) + (kTipsG ? 0 : (size_t)(kFused ? R : 1) * T * 16));
   // (the assembly walk fetches its descriptors from global memory with scalar loads: this copy also brings their
   // lines into L2 before the walk asks for them -- without it every eighth op waited for HBM)
   for (int i = tid; i < n_w; i += blockDim.x) desc[i] = wops[(size_t)sample * n_ops + i];
@@ -1285,7 +1299,7 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
   }
   LH_CT_PHASE(1)
   // the tip tables are complete (LDS); the scratch-area stores need to have landed only if a table goes that way
-  if (n_tab > n_q) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (kTipsG || n_tab > n_q) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   LH_CT_PHASE(2)
   // Second half: the cherry tables, one thread per (table, state of the first tip): P_c (tipcol_y o tipcol_z) for
@@ -1353,8 +1367,9 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
     site0 = tile0 + wave * (64 * kS) + lane;
     n_own = kS;
     if constexpr (kAsm && !kN)
-      prune_wave_asm<kDepth, kS>(tile0 + wave * (64 * kS), site_end, msa, L, n_w, wops + (size_t)sample * n_ops, pm,
-                                 (unsigned)((T - 3 > 0 ? T - 3 : 0) * 128), tiptab, naive_tab, p4, lik, scl);
+      prune_wave_asm<kDepth, kS, kTipsG>(tile0 + wave * (64 * kS), site_end, msa, L, n_w, wops + (size_t)sample * n_ops, pm,
+                                         (unsigned)((T - 3 > 0 ? T - 3 : 0) * 128), (unsigned)(tip_off * 8), tiptab, naive_tab,
+                                         p4, lik, scl);
     else
       prune_wave_ct<kDepth, kS, kN>(site0, site_end, msa, L, n_w, desc, pm, tiptab, ctab, naive_tab, p4, lik, scl);
   } else {
@@ -1440,6 +1455,11 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
       LH_PRUNE_CT_PARAMS) {                                                                          \
     prune_body_ct<kDepth, kN, kFused, 2, kAsm>(LH_PRUNE_CT_ARGS);                                    \
   }
+// Large trees: the tip table in the scratch region, no LDS but the descriptors (six waves per SIMD; assembly walk)
+template <int kDepth>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) prune_kernel_ctg6(LH_PRUNE_CT_PARAMS) {
+  prune_body_ct<kDepth, false, false, 2, true, true>(LH_PRUNE_CT_ARGS);
+}
 LH_PRUNE_CT_KERNEL(prune_kernel_ct6, 6)
 LH_PRUNE_CT_KERNEL(prune_kernel_ct5, 5)
 LH_PRUNE_CT_KERNEL(prune_kernel_ct4, 4)
@@ -1502,12 +1522,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
   LH_PRUNE_SAMPLES((prune_body<kDepth, true, kN, false, true>))
 }
 
+// Trees from this many tips on (a 24 KB tip table) may run with the tip table in the scratch region
+constexpr int kTipsInScratchFrom = 192;
+
 PruneWsSizes prune_ws_sizes(int T, bool mixed_n) {
   PruneWsSizes z;
   z.tabs_per_sample = (size_t)std::max((T - 1) / 2, 1);
   const size_t e = mixed_n ? 25 : 16;
-  // the cherry-table form, and never less than the older kernels' [T-2][2][16]
-  z.scratch_doubles_per_rate = std::max((size_t)std::max(T - 3, 0) * 16 + z.tabs_per_sample * e * 4, (size_t)std::max(T - 2, 1) * 32);
+  // the cherry-table form (large trees: + the tip table [T][16], which those kernels keep here instead of in LDS), and
+  // never less than the older kernels' [T-2][2][16]
+  const size_t tips = debug_options().k1_tips_scratch && T >= kTipsInScratchFrom ? (size_t)T * 16 : 0;
+  z.scratch_doubles_per_rate = std::max((size_t)std::max(T - 3, 0) * 16 + z.tabs_per_sample * e * 4 + tips, (size_t)std::max(T - 2, 1) * 32);
   return z;
 }
 
@@ -1581,7 +1606,13 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   const size_t fused_lds = std::max((size_t)R * tip_bytes + tail_bytes, (size_t)R * pad * (5 * sizeof(double) + sizeof(int)));
   const bool fused = allow_fused && !no_fuse && R * wpr <= 8 && fused_lds <= 53 * 1024 && !seg_env;
   // large trees: with the whole tip table in LDS fewer than five waves per SIMD would be resident
-  const bool seg = max_depth <= 4 && !fused && ((160 * 1024 / tip_bytes) * wpr / 4 < 5 || seg_env) && !dbg.k1_no_segments;
+  const bool big = !fused && (160 * 1024 / tip_bytes) * wpr / 4 < 5;
+  // LH_K1_TIPS_SCRATCH (experiment, profiles/r03_config4.txt): large trees without N through the cherry-table form with
+  // the tip table in the scratch region (six waves per SIMD) instead of the segmented register-stack form (four).
+  // Measured on the configs[4] shape: 9.4 ms against 7.5 -- a workgroup's matrices, tables and tip table are 256 KB there,
+  // eight workgroups per CU put 64 MB in flight per XCD, and every tip and table gather comes from beyond L2.
+  const bool tips_g = dbg.k1_tips_scratch && big && !seg_env && !fam.msa_mixed_n && !cxx_walk && T >= kTipsInScratchFrom;
+  const bool seg = max_depth <= 4 && !fused && (big || seg_env) && !dbg.k1_no_segments && !tips_g;
   // the register-stack form with all rates in one workgroup checks its schedules in its own prologue; everything else
   // runs behind K0c
   const bool stack_fused = fused && max_depth <= 4 && !tables_env && !no_tables && !s4;
@@ -1595,7 +1626,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
     // (seg here: the ancestral-sequence step, whose own kernels follow the stack through the schedule -- full check, no rewrite)
     launch_k0c(!no_tables && !seg, !seg);
   }
-  const size_t lds = fused ? fused_lds : seg ? (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) : tip_bytes + tail_bytes;
+  const size_t lds = fused ? fused_lds : seg ? (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) : tips_g ? tail_bytes : tip_bytes + tail_bytes;
   const int wg_waves = fused ? R * wpr : wpr;
   dim3 grid(tiles, fused ? 1 : R, n), block(64 * wg_waves);
 #ifdef LH_EXP_K1_PERSIST
@@ -1695,7 +1726,11 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
     else                               \
       LH_LAUNCH_FORM(D, false, false)  \
   }
-    if (max_depth <= 4)
+    if (tips_g && max_depth <= 4)
+      LH_LAUNCH_CT((prune_kernel_ctg6<4>))
+    else if (tips_g)
+      LH_LAUNCH_CT((prune_kernel_ctg6<16>))
+    else if (max_depth <= 4)
       LH_LAUNCH_SHALLOW(4)
     else
       LH_LAUNCH_SHALLOW(16)

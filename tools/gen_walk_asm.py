@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Writes linearham_amd/csrc/lh_prune_walk_asm_s2.inc and _s4.inc (+ their clobber lists): the gfx950 assembly of K1's
-schedule walk for two and for four sites per lane (alignments without N tips), used by prune_wave_asm through one
-inline-asm statement.  The text is generated because the 4x4 mat-vec and the element-wise products are the same row
+"""Writes linearham_amd/csrc/lh_prune_walk_asm_s2.inc, _s4.inc and _s2g.inc (+ clobber lists): the gfx950 assembly of K1's
+schedule walk for two and for four sites per lane (alignments without N tips), and for two sites per lane with the tip
+columns gathered from the scratch region instead of LDS (large trees), used by prune_wave_asm through one inline-asm
+statement.  The text is generated because the 4x4 mat-vec and the element-wise products are the same row
 pattern over four register blocks and S sites; everything else is written out below once.  Run from the repo root
 after editing:    python tools/gen_walk_asm.py
 
@@ -81,9 +82,10 @@ PREFETCH = [                                       # the descriptor two ops ahea
 
 
 class Gen:
-    def __init__(self, S):
+    def __init__(self, S, gtips=False):
         self.r = Regs(S)
         self.S = S
+        self.gtips = gtips   # tip columns gathered from the scratch region (large trees) instead of the LDS tip table
 
     def matvec(self, dst):
         """dst <- P a for all sites, rows interleaved (4 S independent chains), in the order of lh::matvec:
@@ -112,8 +114,12 @@ class Gen:
         out = tip_expr + ["s_lshl_b32 s87, s87, 7", "s_add_i32 s87, s87, s81"]
         out += ["v_lshl_add_u32 v%d, v%d, 5, s87" % (self.r.tmp + s, st + s) for s in range(self.S)]
         for s in range(self.S):
-            out += ["ds_read_b128 v[%d:%d], v%d" % (dst + 8 * s, dst + 8 * s + 3, self.r.tmp + s),
-                    "ds_read_b128 v[%d:%d], v%d offset:16" % (dst + 8 * s + 4, dst + 8 * s + 7, self.r.tmp + s)]
+            if self.gtips:   # s81 = byte offset of the tip table in the scratch region s[74:75]
+                out += ["global_load_dwordx4 v[%d:%d], v%d, s[74:75]" % (dst + 8 * s, dst + 8 * s + 3, self.r.tmp + s),
+                        "global_load_dwordx4 v[%d:%d], v%d, s[74:75] offset:16" % (dst + 8 * s + 4, dst + 8 * s + 7, self.r.tmp + s)]
+            else:            # s81 = LDS address of the tip table
+                out += ["ds_read_b128 v[%d:%d], v%d" % (dst + 8 * s, dst + 8 * s + 3, self.r.tmp + s),
+                        "ds_read_b128 v[%d:%d], v%d offset:16" % (dst + 8 * s + 4, dst + 8 * s + 7, self.r.tmp + s)]
         return out
 
     def table_entry(self, dst):
@@ -196,8 +202,9 @@ class Gen:
         cherry = self.tip_column(U, r.sa, tip_a) + self.tip_column(X, r.sb, tip_b)
         add(["; cherry", "s_bfe_u32 s88, s68, 0x50004", "s_cmp_eq_u32 s88, 0", "s_cbranch_scc1 lh_walk_cherry_np"])
         add(self.push_block("lh_walk_cherry"))
-        add(cherry + ["s_waitcnt lgkmcnt(0)"] + PREFETCH + self.product(U, X) + self.states(70, 71) + ["s_branch lh_walk_tail"])
-        add(["lh_walk_cherry_np:"] + cherry + ["s_waitcnt lgkmcnt(0)"] + ROTATE + PREFETCH + self.product(U, X) + self.states(70, 71) +
+        tipwait = "s_waitcnt vmcnt(0) lgkmcnt(0)" if self.gtips else "s_waitcnt lgkmcnt(0)"
+        add(cherry + [tipwait] + PREFETCH + self.product(U, X) + self.states(70, 71) + ["s_branch lh_walk_tail"])
+        add(["lh_walk_cherry_np:"] + cherry + [tipwait] + ROTATE + PREFETCH + self.product(U, X) + self.states(70, 71) +
             ["s_branch lh_walk_tail"])
         # cherry table x tip column
         ctip = self.table_entry(U) + self.tip_column(X, r.sc, tip_c)
@@ -212,7 +219,9 @@ class Gen:
         mv = self.matvec(X)
         half = len(mv) // 2
         add(["; tip into accumulator", "lh_walk_tip:"] + self.p_load() + self.tip_column(U, r.sa, tip_a) + ["s_waitcnt lgkmcnt(0)"] +
-            ROTATE + weave(mv[:half], P_ADV + PREFETCH + st_a) + st_bc + mv[half:] + self.product(U, X) + ["s_branch lh_walk_tail"])
+            ROTATE + weave(mv[:half], P_ADV + PREFETCH + st_a) + st_bc + mv[half:] +
+            # (global tip columns: they are older than the next op's state loads, of which at least S are in flight)
+            (["s_waitcnt vmcnt(%d)" % S] if self.gtips else []) + self.product(U, X) + ["s_branch lh_walk_tail"])
         # cherry table into accumulator: a = table * (P a)
         add(["; cherry table into accumulator", "lh_walk_ctab:"] + self.p_load() + self.table_entry(U) + ["s_waitcnt lgkmcnt(0)"] + ROTATE +
             weave(mv, P_ADV + PREFETCH, 4) + ["s_waitcnt vmcnt(0)"] + self.product(U, X) + self.states(70, 71) + ["s_branch lh_walk_tail"])
@@ -253,18 +262,21 @@ class Gen:
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outdir = os.environ.get("LH_ASM_OUT") or os.path.join(root, "linearham_amd", "csrc")
-    for S in (2, 4):
-        g = Gen(S)
+    for S, gtips in ((2, False), (4, False), (2, True)):
+        g = Gen(S, gtips)
         lines = g.generate()
-        out = os.path.join(outdir, "lh_prune_walk_asm_s%d.inc" % S)
+        out = os.path.join(outdir, "lh_prune_walk_asm_s%d%s.inc" % (S, "g" if gtips else ""))
         with open(out, "w") as f:
             f.write("// GENERATED by tools/gen_walk_asm.py (register map and rationale there) -- do not edit by hand.\n")
-            f.write("// gfx950 assembly of K1's schedule walk, %d sites per lane, alignments without N: the body of one asm statement.\n" % S)
+            f.write("// gfx950 assembly of K1's schedule walk, %d sites per lane, alignments without N%s: the body of one asm statement.\n" %
+                    (S, ", tip columns from the scratch region" if gtips else ""))
             f.write("// Vector registers v5 .. v%d (lh_prune_walk_clobbers_s%d.inc lists them for the statement).\n" % (g.r.last, S))
             for ln in lines:
                 ln = ln.replace("%%", "%")
                 ln = re.sub(r"(lh_walk_\w+)", r"\1_%=", ln)   # one copy of the labels per instantiation of the statement
                 f.write('"%s\\n"\n' % ln)
+        if gtips:
+            continue   # (same registers as the LDS form)
         with open(os.path.join(outdir, "lh_prune_walk_clobbers_s%d.inc" % S), "w") as f:
             f.write("// GENERATED by tools/gen_walk_asm.py: registers the %d-site walk statement clobbers.\n" % S)
             regs = ['"v%d"' % i for i in range(5, g.r.last + 1)] + ['"s%d"' % i for i in range(36, 100)]
