@@ -49,3 +49,18 @@ def test_corrupted_schedule_in_a_larger_tree():
         bad = _run("tip", env, n_leaves=60)
         assert "malformed schedule" in bad["status"] and bad["ll"][2] is None
         assert all(x is not None for i, x in enumerate(bad["ll"]) if i != 2)
+
+
+@pytest.mark.gpu
+def test_large_tree_forms_agree():
+    """A 200-leaf family (tip table 25 KB per rate: the launcher's 'large tree' case) through the segmented
+    register-stack kernels (default) and through the cherry-table form with its tip table in the scratch region
+    (LH_K1_TIPS_SCRATCH=1, assembly walk lh_prune_walk_asm_s2g.inc): the same log-likelihoods to rounding, and a corrupted
+    schedule is caught in both."""
+    a = _run("none", {}, n_leaves=200)
+    b = _run("none", {"LH_K1_TIPS_SCRATCH": "1"}, n_leaves=200)
+    assert a["status"] == "" and b["status"] == ""
+    for x, y in zip(a["ll"], b["ll"]):
+        assert x is not None and y is not None and abs(x - y) <= 1e-10 * abs(x), (x, y)
+    bad = _run("node", {"LH_K1_TIPS_SCRATCH": "1"}, n_leaves=200)
+    assert "malformed schedule" in bad["status"] and bad["ll"][2] is None
