@@ -829,6 +829,9 @@ __device__ __forceinline__ void prune_body(int sample, int slot, int n2, int til
           if (kind == OP_POP_ACC) ok = ok && !push && k > 0 && op.y >= T && op.y < nodes && op.z >= T && op.z < nodes;
           if (push || kind == OP_POP_ACC) ok = ok && op.w >= 0 && op.w < kDepth;
           if (kind != OP_CHERRY) ok = ok && rank + (kind == OP_POP_ACC ? 2 : 1) <= T - 3;
+#ifdef LH_EXP_NO_K1_CHECK  // timing experiment: what the in-prologue schedule check costs
+          ok = true;
+#endif
           if (!ok) {
             bad = true;
             continue;
@@ -846,12 +849,14 @@ __device__ __forceinline__ void prune_body(int sample, int slot, int n2, int til
           // entry `it` of the list must name an op that claims it (an entry nobody wrote holds whatever LDS held)
           const int code = mat_list[it], k = min(code >> 1, n_ops - 1);
           const int4 op = op_ptr[k];
+#ifndef LH_EXP_NO_K1_CHECK
           {
             const int kind = op.x & 15;
             if ((code >> 1) >= n_ops || op.x < 0 || kind == OP_CHERRY || kind > OP_POP_ACC || ((code & 1) && kind != OP_POP_ACC) ||
                 (op.x >> OP_RANK_SHIFT) + (code & 1) != it)
               bad = true;
           }
+#endif
           const int node = min(max((code & 1) ? op.y : op.z, 0), nodes - 1);
           compute_pmatrix(e, bl[node] * rt, P);
           double* o = pw + (size_t)k * 32 + (code & 1) * 16;
