@@ -1031,16 +1031,20 @@ __device__ __forceinline__ void matvec_v(const double (&p)[16], const double (&a
   x[3] = fma(p[15], a[3], fma(p[14], a[2], fma(p[13], a[1], p[12] * a[0])));
 }
 
-// K0c: one wave per sample checks the schedule (kinds, node ranges, stack discipline: everything K1 indexes with) and
+// K0c: checks a sample's schedule (kinds, node ranges, stack discipline: everything K1 indexes with) and
 // -- rewrite != 0 -- writes the walk descriptors (WalkOp above; lh_device.h), the branch length of every P-matrix the
 // walk consumes (in that order) and the list of cherry tables.  A malformed schedule gets an empty walk, hdr.w = 1 (K1
 // then leaves NaN) and sets *err_flag, which lh_family_status reports: device-resident schedules are not trusted.
-// The check is a serial walk over the T - 2 ops, so it is organised around latency: the wave copies the sample's ops
-// into LDS (coalesced; ops_in_lds == 0: trees too large for that, read from global memory), walks them on the scalar unit
-// and notes the NODE of every matrix in LDS, then all lanes fetch those nodes' branch lengths side by side.  (One thread
-// per sample, loading each branch length where it was needed: 0.86 ms per 6144 samples of a 501-tip tree; this form:
-// profiles/r03_config4.txt.)
-// Dynamic LDS: [ops_in_lds ? n_ops : 0] int4 | [n_ops] int matrix nodes | [tabs_stride] int table nodes | [4 + 16] int.
+// The check is a serial walk over the T - 2 ops; two organisations, chosen by the batch size (launch_prune):
+//  * kWave (small batches: latency): one WAVE per sample.  It copies the sample's ops into LDS (coalesced; ops_in_lds ==
+//    0: trees too large for that, read from global memory), walks them on the scalar unit and notes the NODE of every
+//    matrix in LDS, then all lanes fetch those nodes' branch lengths side by side.  60 us per 2048 samples of a 101-tip
+//    tree (the ancestral-sequence step's batch); but a CU has ONE scalar unit: 0.73 ms per 49 152.
+//    Dynamic LDS: [ops_in_lds ? n_ops : 0] int4 | [n_ops] int matrix nodes | [tabs_stride] int table nodes | [4 + 16] int.
+//  * !kWave (large batches: throughput): one THREAD per sample, every lane its own walk, each branch length loaded where
+//    it is needed: 0.19 ms per 49 152 samples of a 101-tip tree, but the same 0.2-0.9 ms for a few thousand samples
+//    (n_ops dependent round trips to memory).
+template <bool kWave>
 __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int max_depth, int tabs_stride, int use_tables,
                                                             int rewrite, int ops_in_lds,
                                                             const int32_t* __restrict__ ops,
@@ -1048,28 +1052,52 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
                                                             double* __restrict__ wlen, int4* __restrict__ tabs,
                                                             int4* __restrict__ hdr, int32_t* err_flag) {
   extern __shared__ int4 k0c_lds[];
-  const int smp = blockIdx.x;
   const int lane = threadIdx.x;
+  const int smp = kWave ? (int)blockIdx.x : (int)blockIdx.x * 64 + lane;
+  if (!kWave && smp >= n) return;
   const int n_ops = T - 2, nodes = 2 * T - 2;
   const int4* __restrict__ og = reinterpret_cast<const int4*>(ops) + (size_t)smp * n_ops;
-  int* mnode = reinterpret_cast<int*>(k0c_lds + (ops_in_lds ? n_ops : 0));
+  int* mnode = reinterpret_cast<int*>(k0c_lds + (ops_in_lds ? n_ops : 0));  // (kWave only, as the three below)
   int* tnode = mnode + n_ops;
-  int* verdict = tnode + tabs_stride;  // [4]: n_w, n_mat, n_tab, bad (for the lanes' second phase)
-  int* pend = verdict + 4;             // [16] per stack slot of the rewritten walk: where the pushed subtree's matrix sits in the walk's list
-  if (ops_in_lds) {
+  int* verdict = tnode + tabs_stride;
+  int* pend_lds = verdict + 4;  // [16] per stack slot of the rewritten walk: where the pushed subtree's matrix sits in the walk's list
+  int pend_own[16];             // (the same, !kWave)
+  if (kWave && ops_in_lds) {
     for (int k = lane; k < n_ops; k += 64) k0c_lds[k] = og[k];
     __syncthreads();
   }
   int2* wo = wops + (size_t)smp * n_ops;
   int4* tl = tabs + (size_t)smp * tabs_stride;
-  // The walk itself is the same in every lane and written so that the compiler keeps it on the scalar unit: every op
+  double* ml = wlen + (size_t)smp * n_ops;
+  const double* __restrict__ bl = brlen + (size_t)smp * nodes;
+  // kWave: the walk is the same in every lane and written so that the compiler keeps it on the scalar unit: every op
   // field passes through readfirstlane, all branches are uniform; lane 0 alone stores.
-  const bool first = lane == 0;
+  const bool first = !kWave || lane == 0;
   auto load_op = [&](int k) {
-    const int4 v = ops_in_lds ? k0c_lds[k] : og[k];
-    return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
-                     __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+    if constexpr (kWave) {
+      const int4 v = ops_in_lds ? k0c_lds[k] : og[k];
+      return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
+                       __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+    } else {
+      return og[k];
+    }
   };
+  // where matrix i of the walk's list comes from: noted (kWave) or fetched on the spot
+  auto set_mnode = [&](int i, int node) {
+    if constexpr (kWave) {
+      if (first) mnode[i] = node;
+    } else {
+      if (rewrite) ml[i] = bl[node];
+    }
+  };
+  auto set_pend = [&](int d, int i) {
+    if constexpr (kWave) {
+      if (first) pend_lds[d] = i;
+    } else {
+      pend_own[d] = i;
+    }
+  };
+  auto get_pend = [&](int d) { return kWave ? pend_lds[d] : pend_own[d]; };
   int depth = 0, n_w = 0, n_mat = 0, n_tab = 0;
   int bdepth = 0;  // stack depth of the schedule as written (depth: of the rewritten walk, which pushes less)
   bool bad = false;
@@ -1096,9 +1124,9 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
                  inner_ok(nx.z) && n_tab < tabs_stride) {
         // the cherry is the whole second subtree: the first one stays in the accumulator, nothing is pushed
         w = make_int2(W_CTAB_ACC | WOP_MATRIX | WOP_HAS_B | (op.y << 16), op.z | (1 << 16));
+        set_mnode(n_mat, nx.y);
         if (first) {
-          mnode[n_mat] = nx.y;
-          tnode[n_tab] = nx.z;
+          if (kWave) tnode[n_tab] = nx.z;
           if (rewrite) tl[n_tab] = make_int4(op.y, op.z, nx.z, 0);
         }
         ++n_mat, ++n_tab;
@@ -1107,13 +1135,13 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
         int pushbits = 0;
         if (push) {  // the accumulator is set aside as P_first a: the matrix's node is named by the matching pop
           pushbits = WOP_MATRIX | ((depth + 1) << WOP_PUSH_SHIFT);
-          if (first) pend[depth] = n_mat;
+          set_pend(depth, n_mat);
           ++n_mat, ++depth, ++bdepth;
         }
         if (use_tables && has_next && nk == OP_TIP_ACC && nx_plain && tip_ok(nx.y) && inner_ok(nx.z) && n_tab < tabs_stride) {
           w = make_int2(W_CTIP | pushbits | WOP_HAS_B | WOP_HAS_C | (op.y << 16), op.z | (nx.y << 16));
           if (first) {
-            tnode[n_tab] = nx.z;
+            if (kWave) tnode[n_tab] = nx.z;
             if (rewrite) tl[n_tab] = make_int4(op.y, op.z, nx.z, 0);
           }
           ++n_tab;
@@ -1127,7 +1155,7 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
         bad = true;
       } else {
         w = make_int2(W_TIP_ACC | WOP_MATRIX | (op.y << 16), 1 | (1 << 16));
-        if (first) mnode[n_mat] = op.z;
+        set_mnode(n_mat, op.z);
         ++n_mat;
       }
     } else if (kind == OP_POP_ACC) {
@@ -1136,10 +1164,8 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
       } else {
         --depth, --bdepth;
         w = make_int2(W_POP | WOP_MATRIX | (depth << WOP_POP_SHIFT) | (1 << 16), 1 | (1 << 16));
-        if (first) {
-          mnode[pend[depth]] = op.y;  // the popped child: its matrix was applied at the push
-          mnode[n_mat] = op.z;        // the child whose CLV is in the accumulator
-        }
+        set_mnode(get_pend(depth), op.y);  // the popped child: its matrix was applied at the push
+        set_mnode(n_mat, op.z);            // the child whose CLV is in the accumulator
         ++n_mat;
       }
     } else {
@@ -1162,13 +1188,15 @@ __global__ void __launch_bounds__(64) schedule_check_kernel(int n, int T, int ma
     }
   }
   if (!rewrite || bad) return;
-  __syncthreads();
   // branch length of every inner-branch matrix K1's prologue computes, in the order it stores them: the walk's matrices
   // in walk order, then the cherry branches' (table c at n_mat + c)
-  double* ml = wlen + (size_t)smp * n_ops;
-  const double* __restrict__ bl = brlen + (size_t)smp * nodes;
-  for (int i = lane; i < n_mat; i += 64) ml[i] = bl[mnode[i]];
-  for (int c = lane; c < n_tab; c += 64) ml[n_mat + c] = bl[tnode[c]];
+  if constexpr (kWave) {
+    __syncthreads();
+    for (int i = lane; i < n_mat; i += 64) ml[i] = bl[mnode[i]];
+    for (int c = lane; c < n_tab; c += 64) ml[n_mat + c] = bl[tnode[c]];
+  } else {
+    for (int c = 0; c < n_tab; ++c) ml[n_mat + c] = bl[tl[c].z];  // (the thread's own stores)
+  }
 }
 
 // The register-stack kernels for large trees (segmented tip table) walk the schedule as lh_schedule_tree wrote it; what
@@ -1554,12 +1582,19 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
     (void)hipMemcpyToSymbol(HIP_SYMBOL(lh_dbg_max_ops), &m, sizeof(m));
   }
 #endif
-  // K0c: one wave per sample; the sample's ops staged in LDS while they fit (16 bytes per op)
+  // K0c: a wave per sample (its ops staged in LDS while they fit, 16 bytes per op) for batches the scalar units get through
+  // quickly, a thread per sample from 12 288 samples on (see the kernel)
   auto launch_k0c = [&](bool use_tables, bool rewrite) {
     const size_t n_ops_k = (size_t)std::max(T - 2, 1);
+    if (n >= 12288) {
+      hipLaunchKernelGGL(schedule_check_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, stream, n, T, max_depth,
+                         (int)sizes.tabs_per_sample, use_tables ? 1 : 0, rewrite ? 1 : 0, 0, ops, brlen, ws.wops, ws.wlen, ws.tabs,
+                         ws.hdr, ws.err_flag);
+      return;
+    }
     const size_t tail = (n_ops_k + sizes.tabs_per_sample + 20) * sizeof(int);
     const bool in_lds = n_ops_k * 16 + tail <= 48 * 1024;
-    hipLaunchKernelGGL(schedule_check_kernel, dim3(n), dim3(64), (in_lds ? n_ops_k * 16 : 0) + tail, stream, n, T, max_depth,
+    hipLaunchKernelGGL(schedule_check_kernel<true>, dim3(n), dim3(64), (in_lds ? n_ops_k * 16 : 0) + tail, stream, n, T, max_depth,
                        (int)sizes.tabs_per_sample, use_tables ? 1 : 0, rewrite ? 1 : 0, in_lds ? 1 : 0, ops, brlen, ws.wops,
                        ws.wlen, ws.tabs, ws.hdr, ws.err_flag);
   };
