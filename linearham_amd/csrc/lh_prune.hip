@@ -775,7 +775,7 @@ __device__ __forceinline__ void prune_body(int sample, int slot, int n2, int til
   const int wave = kFused ? wave_all - rate * wpr : wave_all;  // within the rate
   const int nthr = kFused ? wpr * 64 : (int)blockDim.x;       // threads working on this rate
   const int rtid = kFused ? tid - rate * nthr : tid;
-  if (hdr != nullptr && hdr[sample].w != 0) {  // K0c rejected the schedule (uniform per workgroup): no number may look like a result
+  if (hdr != nullptr && hdr[sample].w != 0) {  // rejected by the check kernel in front (uniform per workgroup): no number may look like a result
     const int planes = kFused ? 1 : R, plane = kFused ? 0 : rate;
     const int t0 = blockIdx.x * tile, t1 = min(t0 + tile, L);
     for (int site = t0 + tid; site < t1; site += blockDim.x) {
@@ -813,29 +813,13 @@ __device__ __forceinline__ void prune_body(int sample, int slot, int n2, int til
       // barrier thread t of a rate takes items t, t + nthr, ... of [inner matrices | tips]: no lane idles on a
       // cherry, none computes two matrices while its neighbours compute one.
       uint16_t* mat_list = reinterpret_cast<uint16_t*>(reinterpret_cast<double*>(smem2) + (size_t)R * T * 16);
-      int* bad_flag = reinterpret_cast<int*>(mat_list + ((T + 1) & ~1));  // (the launcher sizes the list's slot for both)
       const int nodes = 2 * T - 2;
-      bool bad = false;
-      if (tid == 0) *bad_flag = 0;
+      // (the schedule has been checked by schedule_ranks_kernel: fields in range, ranks = the running matrix count, so the
+      // list is written completely and within its T - 3 entries; a rejected sample never gets here)
       if (rate == 0) {
         for (int k = rtid; k < n_ops; k += nthr) {
           const int4 op = op_ptr[k];
           const int kind = op.x & 15, rank = op.x >> OP_RANK_SHIFT;
-          const bool push = (op.x & OP_PUSH_FLAG) != 0;
-          // the op's fields: everything the walk indexes with (tips: MSA rows and tip-table entries; slots: registers)
-          bool ok = op.x >= 0 && (op.x & 0xe0) == 0 && kind <= OP_POP_ACC;
-          if (kind == OP_CHERRY) ok = ok && op.y >= 1 && op.y < T && op.z >= 1 && op.z < T && push == (k != 0);
-          if (kind == OP_TIP_ACC) ok = ok && !push && k > 0 && op.y >= 1 && op.y < T && op.z >= T && op.z < nodes;
-          if (kind == OP_POP_ACC) ok = ok && !push && k > 0 && op.y >= T && op.y < nodes && op.z >= T && op.z < nodes;
-          if (push || kind == OP_POP_ACC) ok = ok && op.w >= 0 && op.w < kDepth;
-          if (kind != OP_CHERRY) ok = ok && rank + (kind == OP_POP_ACC ? 2 : 1) <= T - 3;
-#ifdef LH_EXP_NO_K1_CHECK  // timing experiment: what the in-prologue schedule check costs
-          ok = true;
-#endif
-          if (!ok) {
-            bad = true;
-            continue;
-          }
           if (kind == OP_CHERRY) continue;
           mat_list[rank] = (uint16_t)(2 * k);          // the accumulator child's matrix: node op.z, slot [k][0]
           if (kind == OP_POP_ACC) mat_list[rank + 1] = (uint16_t)(2 * k + 1);  // the popped child's: node op.y, slot [k][1]
@@ -846,17 +830,8 @@ __device__ __forceinline__ void prune_body(int sample, int slot, int n2, int til
       const int n_inner = T - 3;
       for (int it = rtid; it < n_inner + T; it += nthr) {
         if (it < n_inner) {
-          // entry `it` of the list must name an op that claims it (an entry nobody wrote holds whatever LDS held)
           const int code = mat_list[it], k = min(code >> 1, n_ops - 1);
           const int4 op = op_ptr[k];
-#ifndef LH_EXP_NO_K1_CHECK
-          {
-            const int kind = op.x & 15;
-            if ((code >> 1) >= n_ops || op.x < 0 || kind == OP_CHERRY || kind > OP_POP_ACC || ((code & 1) && kind != OP_POP_ACC) ||
-                (op.x >> OP_RANK_SHIFT) + (code & 1) != it)
-              bad = true;
-          }
-#endif
           const int node = min(max((code & 1) ? op.y : op.z, 0), nodes - 1);
           compute_pmatrix(e, bl[node] * rt, P);
           double* o = pw + (size_t)k * 32 + (code & 1) * 16;
@@ -874,7 +849,6 @@ __device__ __forceinline__ void prune_body(int sample, int slot, int n2, int til
             for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
         }
       }
-      if (bad) atomicOr(bad_flag, 1);
     } else {
     const int half = nthr >= 128 ? (nthr / 128) * 64 : 0;  // whole waves on either side
     const bool do_ops = half == 0 || rtid < half;
@@ -925,20 +899,6 @@ __device__ __forceinline__ void prune_body(int sample, int slot, int n2, int til
   __syncthreads();
   LH_K1_PHASE(3)
 
-  if constexpr (kFused) {
-    // the prologue's verdict on the schedule (uniform: every thread reads the flag behind the barrier)
-    const int* bad_flag = reinterpret_cast<const int*>(
-        reinterpret_cast<const uint16_t*>(reinterpret_cast<double*>(smem2) + (size_t)R * T * 16) + ((T + 1) & ~1));
-    if (*bad_flag != 0) {
-      const int t0 = blockIdx.x * tile, t1 = min(t0 + tile, L);
-      for (int site = t0 + tid; site < t1; site += blockDim.x) {
-        for (int b = 0; b < 5; ++b) site_lik[((size_t)sample * 5 + b) * (size_t)L + site] = __builtin_nan("");
-        site_scal[(size_t)sample * (size_t)L + site] = 0;
-      }
-      if (tid == 0) atomicOr(err_flag, 1);
-      return;
-    }
-  }
   // P-matrices in schedule order (addresses depend on the op number only), readable from here on; a workgroup that
   // works through several samples has read these addresses before (the scalar cache may still hold the last sample's lines)
   if (slot != sample) asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1222,6 +1182,49 @@ __global__ void __launch_bounds__(256) schedule_fields_kernel(int n, int T, int 
   if (!ok) {
     hdr[smp].w = 1;
     atomicOr(err_flag, 1);
+  }
+}
+
+// The register-stack kernels with all rates in one workgroup place their P-matrices by the RANK each op carries (the
+// running count of inner-branch matrices lh_schedule_tree leaves in the descriptor).  One wave per sample checks, 64 ops
+// at a time, every field the kernel indexes with and -- a prefix sum across the wave -- that each op's rank is that
+// running count and the total T - 3; hdr[smp] = (0, 0, 0, verdict) for every sample.  (Round 3 first made these checks
+// inside K1's prologue: their scalars cost the walk registers -- K1 5.63 -> 5.93 ms on one box -- so they moved here:
+// 49 152 samples of a 101-tip tree in ~20 us.)
+__global__ void __launch_bounds__(64) schedule_ranks_kernel(int T, int slots, const int32_t* __restrict__ ops,
+                                                            int4* __restrict__ hdr, int32_t* err_flag) {
+  const int smp = blockIdx.x, lane = threadIdx.x;
+  const int n_ops = T - 2, nodes = 2 * T - 2;
+  const int4* __restrict__ o = reinterpret_cast<const int4*>(ops) + (size_t)smp * n_ops;
+  int carry = 0;
+  bool bad = false;
+  for (int k0 = 0; k0 < n_ops; k0 += 64) {
+    const int k = k0 + lane;
+    const bool in = k < n_ops;
+    const int4 op = in ? o[k] : make_int4(OP_CHERRY, 1, 1, 0);
+    const int kind = op.x & 15, rank = op.x >> OP_RANK_SHIFT;
+    const bool push = (op.x & OP_PUSH_FLAG) != 0;
+    bool ok = op.x >= 0 && (op.x & 0xe0) == 0 && kind <= OP_POP_ACC;
+    if (kind == OP_CHERRY) ok = ok && op.y >= 1 && op.y < T && op.z >= 1 && op.z < T && push == (k != 0);
+    if (kind == OP_TIP_ACC) ok = ok && !push && k > 0 && op.y >= 1 && op.y < T && op.z >= T && op.z < nodes;
+    if (kind == OP_POP_ACC) ok = ok && !push && k > 0 && op.y >= T && op.y < nodes && op.z >= T && op.z < nodes;
+    if (push || kind == OP_POP_ACC) ok = ok && op.w >= 0 && op.w < slots;
+    const int m = !in || !ok ? 0 : kind == OP_TIP_ACC ? 1 : kind == OP_POP_ACC ? 2 : 0;
+    int incl = m;  // inclusive prefix sum over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    if (in && kind != OP_CHERRY && rank != carry + incl - m) ok = false;
+    if (in && !ok) bad = true;
+    carry += __shfl(incl, 63);
+  }
+  if (carry != T - 3) bad = true;
+  const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+  if (lane == 0) {
+    hdr[smp] = make_int4(0, 0, 0, any_bad ? 1 : 0);
+    if (any_bad) atomicOr(err_flag, 1);
   }
 }
 
@@ -1653,11 +1656,13 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   // eight workgroups per CU put 64 MB in flight per XCD, and every tip and table gather comes from beyond L2.
   const bool tips_g = dbg.k1_tips_scratch && big && !seg_env && !fam.msa_mixed_n && !cxx_walk && T >= kTipsInScratchFrom;
   const bool seg = max_depth <= 4 && !fused && (big || seg_env) && !dbg.k1_no_segments && !tips_g;
-  // the register-stack form with all rates in one workgroup checks its schedules in its own prologue; everything else
+  // the register-stack form with all rates in one workgroup runs behind schedule_ranks_kernel (fields and ranks); everything else
   // runs behind K0c
   const bool stack_fused = fused && max_depth <= 4 && !tables_env && !no_tables && !s4;
   // (the register-stack kernels for large trees walk the schedule as written: a field check is all they need)
-  if (seg && allow_fused) {
+  if (stack_fused) {
+    hipLaunchKernelGGL(schedule_ranks_kernel, dim3(n), dim3(64), 0, stream, T, max_depth <= 3 ? 3 : 4, ops, ws.hdr, ws.err_flag);
+  } else if (seg && allow_fused) {
     (void)hipMemsetAsync(ws.hdr, 0, sizeof(int4) * (size_t)n, stream);
     const size_t total = (size_t)n * (size_t)(T - 2);
     hipLaunchKernelGGL(schedule_fields_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, n, T, 4, ops, ws.hdr,
@@ -1706,11 +1711,11 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
 #define LH_LAUNCH_STACK(D, N)                                          \
   {                                                                    \
     if (lds_waves >= 6 && D == 3)                                      \
-      LH_LAUNCH_K((prune_kernel_w6<D, N>), (const int4*)nullptr)       \
+      LH_LAUNCH_K((prune_kernel_w6<D, N>), ws.hdr)                     \
     else if (lds_waves >= 5)                                           \
-      LH_LAUNCH_K((prune_kernel_w5<D, N>), (const int4*)nullptr)       \
+      LH_LAUNCH_K((prune_kernel_w5<D, N>), ws.hdr)                     \
     else                                                               \
-      LH_LAUNCH_K((prune_kernel_w4<D, N>), (const int4*)nullptr)       \
+      LH_LAUNCH_K((prune_kernel_w4<D, N>), ws.hdr)                     \
   }
     if (max_depth <= 3 && !fam.msa_mixed_n)
       LH_LAUNCH_STACK(3, false)

@@ -1,7 +1,7 @@
 """Device-resident schedules are not trusted (lh_eval_batch_device): a malformed op must come back as a status code
 and NaN for that sample, never as an out-of-bounds access on the GPU.  The reference checks nothing here
 (src/PhyloHMM.cpp:421 uses the parsed tree unchecked); this is the C ABI's own contract (include/linearham_amd.h).
-Both forms of K1 are exercised: the register-stack form checks schedules in its prologue, the cherry-table form
+Both forms of K1 are exercised: the register-stack form runs behind schedule_ranks_kernel, the cherry-table form
 (LH_K1_TABLES=1) behind K0c (schedule_check_kernel)."""
 import json
 import os
