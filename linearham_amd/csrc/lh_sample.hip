@@ -20,8 +20,9 @@
 //    the dense matrices hold.
 // One WAVE per sample.  The sums of a draw are sequential by definition (a + b + c in IEEE arithmetic is an
 // order), but its weights are not: lane l forms the weight of left gene l (64 genes at a time, coalesced reads of
-// the tables and of the forward row), the wave then adds the 64 values in lane order through v_readlane -- a
-// chain of uniform adds with nothing but registers in it.  Zero weights need no skipping: x + 0 = x, and a zero
+// the tables and of the forward row), the wave then adds the 64 values in lane order: they go through 512 bytes of
+// LDS and every lane runs the same chain of adds on broadcast reads (round 3; the first form fetched each value with
+// two v_readlane: three vector instructions per element instead of one, 3.4 -> 2.8 ms per 49 152 samples).  Zero weights need no skipping: x + 0 = x, and a zero
 // weight never satisfies the lower_bound test its predecessor failed.  The quotients weight / sum of the second
 // pass are again one division per lane.  (First version: one thread per sample, 5 ms for 2048 samples; this one:
 // see DESIGN.md section 6.)
@@ -34,9 +35,10 @@ namespace {
 
 #pragma clang fp contract(off)
 
-struct Draw {  // this sample's slice of the engine's output stream
+struct Draw {  // this sample's slice of the engine's output stream, and the wave's 1 KB of LDS (wave_draw)
   const uint32_t* words;
   int next;
+  double* lds;  // [128]: 64 weights or quotients, 64 partial sums
 };
 
 // std::generate_canonical<double, 53>(std::mt19937&) (bits/random.tcc): two 32-bit outputs
@@ -53,11 +55,6 @@ __device__ inline double canonical(Draw& d) {
   return r;
 }
 
-__device__ inline double lane_value(double v, int lane) {  // v of `lane`, in every lane (lane is wave-uniform)
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
 
 // std::discrete_distribution<int> over the weights  pre[0..n_pre) | lane_weight(0..n_mid) | post[0..n_post)
 // (this is the order of the states in the dense vector; everything the vector holds besides is zero).
@@ -66,18 +63,38 @@ __device__ inline double lane_value(double v, int lane) {  // v of `lane`, in ev
 // 0 whatever it holds (a uniform of exactly 0, or a vector of fewer than two weights, which is not drawn from and
 // takes nothing from the engine).  `n_dense`: size of the dense vector.
 constexpr int kPastEnd = -1, kFirst = -2;
+
+// The 64 values the lanes hold, added to `acc` in lane order: every lane performs the same chain of adds on values it
+// reads back from LDS (uniform addresses: broadcast reads), so the result is uniform and no lane-to-scalar traffic is
+// needed -- 64 vector adds where the v_readlane form took 64 x (2 v_readlane + 1 add).  Lanes beyond the chunk hold 0.
+__device__ inline double add_in_lane_order(double acc, double mine, double* buf) {
+  buf[threadIdx.x & 63] = mine;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const double2* b2 = reinterpret_cast<const double2*>(buf);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const double2 v = b2[j];
+    acc += v.x;
+    acc += v.y;
+  }
+  __builtin_amdgcn_wave_barrier();  // (the buffer is rewritten by the next chunk)
+  return acc;
+}
+
 template <typename F>
 __device__ int wave_draw(int n_dense, const double* pre, int n_pre, int n_mid, F&& lane_weight, const double* post,
                          int n_post, Draw& d) {
   if (n_dense < 2) return kFirst;
   const int lane = threadIdx.x & 63;
+  double* wbuf = d.lds;
+  double* cbuf = d.lds + 64;
   double sum = 0.0;
   for (int a = 0; a < n_pre; ++a) sum += pre[a];
   for (int c = 0; c < n_mid; c += 64) {
     const double w = (c + lane < n_mid) ? lane_weight(c + lane) : 0.0;
     if (__builtin_amdgcn_ballot_w64(w != 0.0) == 0) continue;
-    const int m = min(64, n_mid - c);
-    for (int j = 0; j < m; ++j) sum += lane_value(w, j);
+    sum = add_in_lane_order(sum, w, wbuf);
   }
   for (int a = 0; a < n_post; ++a) sum += post[a];
   const double p = canonical(d);
@@ -94,14 +111,34 @@ __device__ int wave_draw(int n_dense, const double* pre, int n_pre, int n_mid, F
   for (int c = 0; c < n_mid; c += 64) {
     const double w = (c + lane < n_mid) ? lane_weight(c + lane) : 0.0;
     if (__builtin_amdgcn_ballot_w64(w != 0.0) == 0) continue;
-    const double q = w / sum;
-    const int m = min(64, n_mid - c);
-    int found = -1;
-    for (int j = 0; j < m; ++j) {
-      cum += lane_value(q, j);
-      if (found < 0 && cum >= p) found = j;
+    // the chunk's partial sums, in lane order: lane 0 runs the chain (quotients read back from LDS) and leaves partial
+    // sum j at cbuf[j]; then every lane compares its own with the uniform and the first hit is the answer
+    wbuf[lane] = w / sum;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      const double2* b2 = reinterpret_cast<const double2*>(wbuf);
+      double2* c2 = reinterpret_cast<double2*>(cbuf);
+      double run = cum;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const double2 v = b2[j];
+        double2 o;
+        run += v.x;
+        o.x = run;
+        run += v.y;
+        o.y = run;
+        c2[j] = o;
+      }
     }
-    if (found >= 0) return n_pre + c + found;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double mine = cbuf[lane];
+    cum = cbuf[63];  // (lanes beyond the chunk added zeros)
+    const int m = min(64, n_mid - c);
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < m && mine >= p);
+    __builtin_amdgcn_wave_barrier();
+    if (hit != 0) return n_pre + c + (int)__builtin_ctzll(hit);
   }
   pos = n_pre + n_mid;
   for (int a = 0; a < n_post; ++a, ++pos) {
@@ -242,7 +279,8 @@ __global__ void __launch_bounds__(64 * kSampleWaves)
   if (s >= n) return;
   const bool writer = (threadIdx.x & 63) == 0;
   const double* fwd = fwd_all + (size_t)s * forward_size;
-  Draw d{words_all + (size_t)s * words_per_sample, 0};
+  __shared__ double wave_lds[kSampleWaves][128];
+  Draw d{words_all + (size_t)s * words_per_sample, 0, wave_lds[threadIdx.x >> 6]};
   const DevSampleJunction& VD = smp.vd;
   const DevSampleJunction& DJ = smp.dj;
   const int nV = smp.n_v, nD = smp.n_d, nJ = smp.n_j;
