@@ -49,8 +49,13 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+BRLEN_MEAN = None              # --brlen-mean (development runs on families with fewer site patterns)
+
+
 def preset_spec(preset, batch):
     from tools import synth_family as sf
+    if preset == "config2" and BRLEN_MEAN is not None:
+        return sf.Spec(n_samples=max(batch, 256), brlen_mean=BRLEN_MEAN)
     if preset == "config2":     # the batch is drawn from >= batch distinct tree samples
         return sf.Spec(n_samples=max(batch, 256))
     if preset == "config3":
@@ -61,7 +66,8 @@ def preset_spec(preset, batch):
 
 
 def family_dir(preset, spec):
-    return os.path.join(tempfile.gettempdir(), "lh_bench_%s_n%d_v%d" % (preset, spec.n_samples, GEN_VERSION))
+    tag = "" if spec.brlen_mean == 0.01 else "_bl%g" % spec.brlen_mean
+    return os.path.join(tempfile.gettempdir(), "lh_bench_%s_n%d_v%d%s" % (preset, spec.n_samples, GEN_VERSION, tag))
 
 
 def prepare_family(preset, batch, may_generate, wait_s=600):
@@ -276,6 +282,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="tree samples per GPU per step (weak-scaling presets)")
     ap.add_argument("--preset", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--brlen-mean", type=float, default=None,
+                    help="development only (not the headline workload): mean branch length of the synthetic truth tree "
+                         "(default 0.01: 253 site patterns for config2; 0.002 gives a family with ~100 patterns)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true",
                     help="also time the host-pointer entry point (PCIe-inclusive rate; its launch groups are "
@@ -293,6 +302,8 @@ def parse_args():
                     help="collective backend; gloo (through host copies) only to rehearse the multi-rank path on "
                          "a box with fewer GPUs than ranks -- ranks then share devices (LOCAL_RANK modulo)")
     args = ap.parse_args()
+    global BRLEN_MEAN
+    BRLEN_MEAN = args.brlen_mean
     if args.batch is None:
         args.batch = {"config2": DEFAULT_BATCH, "config3": 0, "config4": 6144, "small": 64}[args.preset]
     return args

@@ -29,7 +29,7 @@ class Spec:
 
     def __init__(self, n_leaves=100, n_sites=400, n_v=200, n_d=30, n_j=12, len_v=296, len_d=(11, 37),
                  len_j=(48, 63), v_l_width=3, v_r_width=10, n_samples=256, n_nni=4, seed=20261004,
-                 v_ancestors=7, d_ancestors=4, j_ancestors=3, divergence=0.05, locus="igh"):
+                 v_ancestors=7, d_ancestors=4, j_ancestors=3, divergence=0.05, locus="igh", brlen_mean=0.01):
         self.__dict__.update(locals())
         del self.__dict__["self"]
         v_r = (len_v - v_r_width, len_v)
@@ -197,7 +197,7 @@ def make_germline_set(spec, outdir, rng):
 # trees and sequence evolution
 # --------------------------------------------------------------------------------------------------
 
-def random_unrooted_tree(n_tips, rng):
+def random_unrooted_tree(n_tips, rng, brlen_mean=0.01):
     """Uniform stepwise addition.  Returns edges as dict edge_id -> [a, b, length]; tips 0..n-1."""
     edges = {0: [0, n_tips, 0.0], 1: [1, n_tips, 0.0], 2: [2, n_tips, 0.0]}
     nxt_node, nxt_edge = n_tips + 1, 3
@@ -210,7 +210,7 @@ def random_unrooted_tree(n_tips, rng):
         nxt_node += 1
         nxt_edge += 2
     for e in edges.values():
-        e[2] = max(float(rng.exponential(0.01)), 1e-6)
+        e[2] = max(float(rng.exponential(brlen_mean)), 1e-6)
     return edges
 
 
@@ -336,7 +336,7 @@ def generate(spec, outdir):
     T = spec.n_leaves + 1
     labels = ["naive"] + ["s%d" % i for i in range(spec.n_leaves)]
     tree_rng = np.random.default_rng(spec.seed)
-    edges = random_unrooted_tree(T, tree_rng)
+    edges = random_unrooted_tree(T, tree_rng, spec.brlen_mean)
     er0 = rng_s.dirichlet(np.ones(6))
     pi0 = rng_s.dirichlet(np.ones(4) * 5)
     cat_rates = np.array([0.136954, 0.476752, 1.0, 2.386294])
