@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "device_schedule_worker.py")
 
 
-def _run(mode, env_extra, n_leaves=12):
-    r = subprocess.run([sys.executable, WORKER, mode, str(n_leaves)], capture_output=True, text=True, timeout=300,
+def _run(mode, env_extra, n_leaves=12, repeat=1):
+    r = subprocess.run([sys.executable, WORKER, mode, str(n_leaves), str(repeat)], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, **env_extra))
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -64,3 +64,17 @@ def test_large_tree_forms_agree():
         assert x is not None and y is not None and abs(x - y) <= 1e-10 * abs(x), (x, y)
     bad = _run("node", {"LH_K1_TIPS_SCRATCH": "1"}, n_leaves=200)
     assert "malformed schedule" in bad["status"] and bad["ll"][2] is None
+
+
+@pytest.mark.gpu
+def test_large_batch_takes_the_thread_per_sample_check():
+    """From 12 288 samples on K0c runs a thread per sample instead of a wave per sample (launch_prune): the same batch of
+    six samples 2100 times over, cherry-table form, one corrupted schedule -- only that sample is NaN, every copy of the
+    others has the bits of the small batch."""
+    small = _run("none", {"LH_K1_TABLES": "1"})
+    big = _run("tip", {"LH_K1_TABLES": "1"}, repeat=2100)
+    assert big["n"] == 12600 and "malformed schedule" in big["status"]
+    assert big["nan_at"] == [2] and big["copies_agree"]
+    for i, (a, b) in enumerate(zip(big["ll"], small["ll"])):
+        if i != 2:
+            assert a == b, (i, a, b)
