@@ -19,6 +19,7 @@ const DebugOptions& debug_options() {
     auto set = [](const char* name) { return std::getenv(name) != nullptr; };
     auto num = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
     o.chunk = std::max(256, num("LH_CHUNK", o.chunk));
+    o.host_sub = std::max(256, num("LH_HOST_SUB", o.host_sub));
     o.k2b_no_pair = set("LH_K2B_NO_PAIR");
     o.k2b_vd_single = set("LH_K2B_VD_SINGLE");
     o.sample_timing = set("LH_SAMPLE_TIMING");
@@ -1170,7 +1171,7 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
   char* dst[5] = {(char*)d_ops, (char*)d_brlen, (char*)d_er, (char*)d_pi, (char*)d_alpha};
   size_t per_sample = 0;
   for (size_t b : bytes) per_sample += b;
-  constexpr int kSub = 6144;  // whole rounds of all kernels for configs[2]-like shapes
+  const int kSub = lh::debug_options().host_sub;  // (default 12 288: whole rounds of all kernels for configs[2]-like shapes)
   const int sub = std::min<int>(n, kSub);
   HostPipe& hp = f->pipe;
   if (!hp.copy) {
@@ -1206,28 +1207,22 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
       }
     }
     std::atomic<bool> bad{false};
-    auto work = [&](int lo, int hi) {
-      for (int i = lo; i < hi; ++i)
-        if (!valid_schedule(ops + ((size_t)off + i) * n_ops * 4, T, (int)nodes, max_depth)) {
-          bad = true;
-          return;
-        }
+    const int nw = std::max(1, std::min(n_workers, m / 256));
+    auto in_threads = [&](auto&& fn) {
+      if (nw == 1) {
+        fn(0, m);
+      } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nw; ++t)
+          pool.emplace_back(fn, (int)((long long)m * t / nw), (int)((long long)m * (t + 1) / nw));
+        for (std::thread& th : pool) th.join();
+      }
+    };
+    // the sub-chunk's inputs into the pinned slot ...
+    in_threads([&](int lo, int hi) {
       for (int a = 0; a < 5; ++a)
         memcpy(part[a] + bytes[a] * lo, src[a] + bytes[a] * ((size_t)off + lo), bytes[a] * (size_t)(hi - lo));
-    };
-    const int nw = std::max(1, std::min(n_workers, m / 256));
-    if (nw == 1) {
-      work(0, m);
-    } else {
-      std::vector<std::thread> pool;
-      for (int t = 0; t < nw; ++t)
-        pool.emplace_back(work, (int)((long long)m * t / nw), (int)((long long)m * (t + 1) / nw));
-      for (std::thread& th : pool) th.join();
-    }
-    if (bad) {
-      rc = fail("lh_eval_batch: malformed schedule op (use lh_schedule_tree)");
-      break;
-    }
+    });
     for (int a = 0; a < 5; ++a)
       if (hipMemcpyAsync(dst[a] + bytes[a] * off, part[a], bytes[a] * m, hipMemcpyHostToDevice, hp.copy) !=
           hipSuccess)
@@ -1244,6 +1239,18 @@ int lh_eval_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, const i
                               (const double*)(dst[1] + bytes[1] * off), (const double*)(dst[2] + bytes[2] * off),
                               (const double*)(dst[3] + bytes[3] * off), (const double*)(dst[4] + bytes[4] * off), R,
                               (double*)d_ll + off, &o, hp.comp);
+    if (rc) break;
+    // ... and its schedules checked on the host while the device works on them (the kernels make the same checks: a
+    // malformed op is a NaN and an error code there, never an out-of-bounds access; a refused batch hands nothing back)
+    in_threads([&](int lo, int hi) {
+      for (int i = lo; i < hi && !bad; ++i)
+        if (!valid_schedule(ops + ((size_t)off + i) * n_ops * 4, T, (int)nodes, max_depth)) bad = true;
+    });
+    if (bad) {
+      (void)hipDeviceSynchronize();
+      (void)check_async_error(f, "lh_eval_batch");  // (the device found it too: one report is enough)
+      rc = fail("lh_eval_batch: malformed schedule op (use lh_schedule_tree)");
+    }
   }
   if (hipDeviceSynchronize() != hipSuccess && !rc) rc = fail("lh_eval_batch: device synchronisation failed");
   if (!rc && check_async_error(f, "lh_eval_batch")) rc = 1;  // K0c's verdict on the schedules as the device saw them

@@ -240,6 +240,7 @@ size_t forward_lds_bytes(const DevFamily& fam);
 // product behaviour.
 struct DebugOptions {
   int chunk = 49152;           // LH_CHUNK=<n>: tree samples per launch group (tests: several groups inside one small call)
+  int host_sub = 12288;        // LH_HOST_SUB=<n>: tree samples per staging sub-chunk of lh_eval_batch (host pointers)
   // (LH_K2A_DIRECT -- K2a walks every gene factor by factor, no consensus form -- is a property of a family and is read
   // when one is created: upload_consensus, lh_capi.hip)
   bool k2b_no_pair = false;    // LH_K2B_NO_PAIR: K2b with one sample per wave
