@@ -41,7 +41,7 @@ WORKLOADS = {
                "germline set, R=4 rate categories (not the headline workload)",
     "small": "small synthetic family (development only, not the headline workload)",
 }
-PMC_PROFILE = {"config2": "r03_bench_pmc_per_launch.json", "config4": "r02_config4_pmc_per_launch.json"}
+PMC_PROFILE = {"config2": "r03_bench_pmc_per_launch.json", "config4": "r03_config4_pmc_per_launch.json"}
 GEN_VERSION = 2                # bump when tools/synth_family.py changes what it writes
 
 
