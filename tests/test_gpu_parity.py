@@ -512,3 +512,18 @@ def test_full_size_forward_arrays_match_dense_oracle(hip, tmp_path, preset):
                 np.testing.assert_allclose(ex[k], r[k], rtol=1e-8, atol=0, err_msg="%d %s" % (i, k))
         checked += 1
     assert checked >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_leaves", [2, 3])
+def test_minimal_trees(hip, tmp_path, n_leaves):
+    """The smallest trees the reference accepts: two sequences + naive (T = 3: ONE schedule op, a cherry, no
+    inner-branch matrix at all) and three (T = 4)."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_leaves=n_leaves, n_samples=4, seed=5), out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    desc, ll, res, ref = run_family(hip, h, rows, 4)
+    assert h.msa.shape[0] + 1 == n_leaves + 1
+    compare(h, desc, ll, res, ref)
