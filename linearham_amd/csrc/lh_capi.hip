@@ -31,6 +31,7 @@ const DebugOptions& debug_options() {
     o.k1_segments = set("LH_K1_SEGMENTS");
     o.k1_no_segments = set("LH_K1_NO_SEGMENTS");
     o.k1_tips_scratch = set("LH_K1_TIPS_SCRATCH");
+    o.k1_ct_segments = set("LH_K1_CT_SEGMENTS");
     o.k1_seg_waves = num("LH_K1_SEG_WAVES", o.k1_seg_waves);
     o.k1_no_fuse = set("LH_K1_NO_FUSE");
     o.k1_persist = num("LH_K1_PERSIST", 0);

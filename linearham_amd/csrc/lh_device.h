@@ -252,6 +252,7 @@ struct DebugOptions {
   bool k1_tables = false;      // LH_K1_TABLES: the cherry-table form for the fused shapes too
   bool k1_no_tables = false;   // LH_K1_NO_TABLES: the cherry-table form's kernels without tables
   bool k1_segments = false;    // LH_K1_SEGMENTS: the segmented tip table (large trees) on small trees too
+  bool k1_ct_segments = false;   // LH_K1_CT_SEGMENTS: large trees through the table-less assembly walk, a schedule segment at a time
   bool k1_tips_scratch = false;  // LH_K1_TIPS_SCRATCH: large trees through the cherry-table form with the tip table in the scratch region
   bool k1_no_segments = false; // LH_K1_NO_SEGMENTS: large trees through the cherry-table form (whole tip table in LDS)
   int k1_seg_waves = 4;        // LH_K1_SEG_WAVES=<4|5>: register budget of the segmented kernels

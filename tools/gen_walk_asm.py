@@ -82,10 +82,15 @@ PREFETCH = [                                       # the descriptor two ops ahea
 
 
 class Gen:
-    def __init__(self, S, gtips=False):
+    def __init__(self, S, gtips=False, seg=False):
         self.r = Regs(S)
         self.S = S
         self.gtips = gtips   # tip columns gathered from the scratch region (large trees) instead of the LDS tip table
+        # seg: the statement walks ONE SEGMENT of the schedule (large trees, walk without tables): the LDS table holds the
+        # tip matrices of this segment only, slot 2 j for tip A and 2 j + 1 for tip B of the segment's op j (= s82); the
+        # walk's state (a, scaler counts, stack slot 0, matrix offset) is loaded from / stored to the private array %[out]
+        # so that the C++ caller can refill the table between two statements (it initialises the array for the first one)
+        self.seg = seg
 
     def matvec(self, dst):
         """dst <- P a for all sites, rows interleaved (4 S independent chains), in the order of lh::matvec:
@@ -111,6 +116,9 @@ class Gen:
 
     def tip_column(self, dst, st, tip_expr):
         """dst <- tip-table columns of the tip whose number `tip_expr` leaves in s87, for the states in v<st>.."""
+        if self.seg:   # the tip's slot in the segment's table instead of its number
+            which = 1 if "s69, 0xffff" in tip_expr[0] else 0   # (a third tip -- table x tip ops -- does not occur without tables)
+            tip_expr = ["s_lshl_b32 s87, s82, 1"] + (["s_or_b32 s87, s87, 1"] if which else [])
         out = tip_expr + ["s_lshl_b32 s87, s87, 7", "s_add_i32 s87, s87, s81"]
         out += ["v_lshl_add_u32 v%d, v%d, 5, s87" % (self.r.tmp + s, st + s) for s in range(self.S)]
         for s in range(self.S):
@@ -188,6 +196,14 @@ class Gen:
         add(["v_mov_b32_e32 v%d, 0" % (r.scal + i) for i in range((S + 1) // 2)])
         for i in range(4 * S):
             add(["v_mov_b32_e32 v%d, 0" % (A + 2 * i), "v_mov_b32_e32 v%d, 0x3ff00000" % (A + 2 * i + 1)])
+        if self.seg:
+            off_st0, off_pm = 32 * S + 16, 64 * S + 16   # (16-byte aligned behind the packed scaler counts)
+            # (always: the caller initialises the array to the walk's start -- a = 1, counts 0, matrix offset 0)
+            add(["scratch_load_dwordx4 v[%d:%d], %%[out], off offset:%d" % (A + 4 * i, A + 4 * i + 3, 16 * i) for i in range(2 * S)])
+            add(["scratch_load_dword v%d, %%[out], off offset:%d" % (r.scal + i, 32 * S + 4 * i) for i in range((S + 1) // 2)])
+            add(["scratch_load_dwordx4 v[%d:%d], %%[out], off offset:%d" % (ST0 + 4 * i, ST0 + 4 * i + 3, off_st0 + 16 * i) for i in range(2 * S)])
+            add(["scratch_load_dword v%d, %%[out], off offset:%d" % (r.tmp, off_pm), "s_waitcnt vmcnt(0)",
+                 "v_readfirstlane_b32 s77, v%d" % r.tmp])
         add(["s_cmp_lt_i32 s83, 1", "s_cbranch_scc1 lh_walk_end",
              "s_lshl_b32 s98, s83, 3", "s_add_i32 s98, s98, -8",
              "s_load_dwordx2 s[68:69], s[84:85], 0x0", "s_min_u32 s87, s98, 8", "s_load_dwordx2 s[72:73], s[84:85], s87",
@@ -255,6 +271,9 @@ class Gen:
              "lh_walk_end:", "s_waitcnt vmcnt(0) lgkmcnt(0)"])
         add(["scratch_store_dwordx4 %%[out], v[%d:%d], off offset:%d" % (A + 4 * i, A + 4 * i + 3, 16 * i) for i in range(2 * S)])
         add(["scratch_store_dword %%[out], v%d, off offset:%d" % (r.scal + i, 32 * S + 4 * i) for i in range((S + 1) // 2)])
+        if self.seg:
+            add(["scratch_store_dwordx4 %%[out], v[%d:%d], off offset:%d" % (ST0 + 4 * i, ST0 + 4 * i + 3, off_st0 + 16 * i) for i in range(2 * S)])
+            add(["v_mov_b32_e32 v%d, s77" % r.tmp, "scratch_store_dword %%[out], v%d, off offset:%d" % (r.tmp, off_pm)])
         add(["s_waitcnt vmcnt(0)"])
         return L
 
@@ -262,20 +281,20 @@ class Gen:
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outdir = os.environ.get("LH_ASM_OUT") or os.path.join(root, "linearham_amd", "csrc")
-    for S, gtips in ((2, False), (4, False), (2, True)):
-        g = Gen(S, gtips)
+    for S, gtips, seg in ((2, False, False), (4, False, False), (2, True, False), (2, False, True)):
+        g = Gen(S, gtips, seg)
         lines = g.generate()
-        out = os.path.join(outdir, "lh_prune_walk_asm_s%d%s.inc" % (S, "g" if gtips else ""))
+        out = os.path.join(outdir, "lh_prune_walk_asm_s%d%s.inc" % (S, "g" if gtips else "seg" if seg else ""))
         with open(out, "w") as f:
             f.write("// GENERATED by tools/gen_walk_asm.py (register map and rationale there) -- do not edit by hand.\n")
             f.write("// gfx950 assembly of K1's schedule walk, %d sites per lane, alignments without N%s: the body of one asm statement.\n" %
-                    (S, ", tip columns from the scratch region" if gtips else ""))
+                    (S, ", tip columns from the scratch region" if gtips else ", one schedule segment per statement" if seg else ""))
             f.write("// Vector registers v5 .. v%d (lh_prune_walk_clobbers_s%d.inc lists them for the statement).\n" % (g.r.last, S))
             for ln in lines:
                 ln = ln.replace("%%", "%")
                 ln = re.sub(r"(lh_walk_\w+)", r"\1_%=", ln)   # one copy of the labels per instantiation of the statement
                 f.write('"%s\\n"\n' % ln)
-        if gtips:
+        if gtips or seg:
             continue   # (same registers as the LDS form)
         with open(os.path.join(outdir, "lh_prune_walk_clobbers_s%d.inc" % S), "w") as f:
             f.write("// GENERATED by tools/gen_walk_asm.py: registers the %d-site walk statement clobbers.\n" % S)
