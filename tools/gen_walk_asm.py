@@ -136,9 +136,10 @@ class Gen:
         r = self.r
         out = ["v_lshl_add_u32 v%d, v%d, 2, v%d" % (r.tmp + s, r.sa + s, r.sb + s) for s in range(self.S)]
         out += ["v_lshl_add_u32 v%d, v%d, 5, %s" % (r.tmp + s, r.tmp + s, toff) for s in range(self.S)]
+        pol = " nt" if "tabnt" in OPTS else " sc1" if "tabsc1" in OPTS else " sc0 sc1" if "tabsc" in OPTS else ""   # cache-policy experiments
         for s in range(self.S):
-            out += ["global_load_dwordx4 v[%d:%d], v%d, s[74:75]" % (dst + 8 * s, dst + 8 * s + 3, r.tmp + s),
-                    "global_load_dwordx4 v[%d:%d], v%d, s[74:75] offset:16" % (dst + 8 * s + 4, dst + 8 * s + 7, r.tmp + s)]
+            out += ["global_load_dwordx4 v[%d:%d], v%d, s[74:75]%s" % (dst + 8 * s, dst + 8 * s + 3, r.tmp + s, pol),
+                    "global_load_dwordx4 v[%d:%d], v%d, s[74:75] offset:16%s" % (dst + 8 * s + 4, dst + 8 * s + 7, r.tmp + s, pol)]
         return out + ["s_add_i32 s76, s76, 0x200"]
 
     def states(self, dx, dy, split=False):
@@ -157,6 +158,9 @@ class Gen:
             o += ["global_load_ubyte v%d, v%d, s[78:79]" % (dst + s, r.tmp + s) for s in range(S)]
             return o
         part_a = ["s_lshr_b32 s87, s%d, 16" % dx] + loads(r.sa)
+        if "allstates" in OPTS:   # experiment: tips B and C always (K0c fills unused tip fields with tip 1), no branches
+            part_bc = ["s_and_b32 s87, s%d, 0xffff" % dy] + loads(r.sb) + ["s_lshr_b32 s87, s%d, 16" % dy] + loads(r.sc)
+            return (part_a, part_bc) if split else part_a + part_bc
         part_bc = (["s_bitcmp1_b32 s%d, 13" % dx, "s_cbranch_scc0 1f", "s_and_b32 s87, s%d, 0xffff" % dy] + loads(r.sb) +
                    ["1:", "s_bitcmp1_b32 s%d, 14" % dx, "s_cbranch_scc0 2f", "s_lshr_b32 s87, s%d, 16" % dy] + loads(r.sc) + ["2:"])
         if split:
