@@ -143,6 +143,13 @@ int lh_family_info(const lh_family* fam, int32_t* n_patterns, int32_t* n_unique_
  * turns the form off. */
 int lh_family_consensus_sets(const lh_family* fam);
 
+/* Diagnostic: the pruning-kernel form the handle's last evaluation ran, as "<kernel><stack depth, N-aware[, all rates
+ * in one workgroup, assembly walk]>" -- e.g. "w6<3,false>", "seg4<4,true>", "ct6<16,false,false,true>" -- or "" before
+ * the first one.  Which form a family takes is a function of its shape (tips, site patterns, rates, stack depth, N
+ * inside alignment columns); the parity tests assert that every form is reached by a family that is compared with the
+ * oracle.  The string lives as long as the handle and changes with the next evaluation. */
+const char* lh_family_prune_form(const lh_family* fam);
+
 /* Opt-in extended-range mode (default off = the reference's arithmetic, overflows included).  The reference
  * loses a tree sample in two places: exp(lnL - log pi) underflows to 0 when a column's likelihood is below
  * 1e-308 (src/PhyloHMM.cpp:237), and the 2^(256 d) equalisation of a region's emission products to the LARGEST
@@ -262,6 +269,8 @@ int lh_forward_batch(lh_family* fam, int32_t n, const double* em, double* loglik
  *                        running weight sum exceeds u * total
  *   anc    [n][T-2][L]   state 0..3 of inner node T + i (lh_schedule_tree numbering) at every site
  *   rate_choice [n][L]   drawn category per site (may be NULL)
+ * A sample whose (device-resident) schedule is rejected gets 0xff in every byte of its anc and rate_choice rows --
+ * bytes have no NaN -- and raises the handle's error word (lh_family_status).
  * The extra root node that ape::root(..., resolve.root = TRUE) puts on the naive branch (:53) lies at
  * distance 0 from naive's neighbour and has that node's state.  Tips keep their observed characters. */
 int lh_asr_batch(lh_family* fam, int32_t n, int32_t n_tips, int32_t max_depth, const int32_t* ops,

@@ -29,7 +29,8 @@ def build_hip(verbose=False, force=False):
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "liblinearham_hip.so")
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "lh_device.h"), os.path.join(ROOT, "include", "linearham_amd.h")]
+    deps = srcs + [os.path.join(CSRC, "lh_device.h"), os.path.join(ROOT, "include", "linearham_amd.h")] + \
+        sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc"))  # the generated assembly walk
     if not force and not _stale(out, deps):
         return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

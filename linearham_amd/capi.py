@@ -45,7 +45,7 @@ EXPORTS = ["lh_last_error", "lh_device_count", "lh_family_create", "lh_family_de
            "lh_eval_batch_device", "lh_forward_batch", "lh_asr_batch", "lh_asr_batch_device",
            "lh_profile_enable", "lh_profile_read", "lh_asr_profile_read", "lh_family_set_extended_range", "lh_warmup", "lh_host_alloc", "lh_host_free", "lh_family_set_sampler",
            "lh_sample_words", "lh_sample_states", "lh_eval_sample_batch", "lh_set_device", "lh_family_status",
-           "lh_eval_sample_batch_device"]
+           "lh_eval_sample_batch_device", "lh_family_prune_form"]
 
 
 def library_path():
@@ -74,6 +74,8 @@ class HipLibrary:
         lib.lh_family_info.restype = C.c_int
         lib.lh_family_consensus_sets.argtypes = [C.c_void_p]
         lib.lh_family_consensus_sets.restype = C.c_int
+        lib.lh_family_prune_form.argtypes = [C.c_void_p]
+        lib.lh_family_prune_form.restype = C.c_char_p
         lib.lh_schedule_tree.argtypes = [C.c_int32, c_i32p, C.c_int32, c_i32p, c_i32p]
         lib.lh_eval_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f64p, c_f64p,
                                       c_f64p, c_f64p, C.c_int32, c_f64p, C.POINTER(_EvalOutputs)]
@@ -272,6 +274,16 @@ class Family:
         self.hip.check(self.hip.lib.lh_eval_batch_device(
             self.handle, n, n_tips, max_depth, ops_ptr, brlen_ptr, er_ptr, pi_ptr, alpha_ptr, num_rates,
             loglik_ptr, None, stream))
+
+    def info(self):
+        """(distinct alignment columns, distinct (naive base, column) pairs in use): lh_family_info."""
+        a, b = C.c_int32(), C.c_int32()
+        self.hip.check(self.hip.lib.lh_family_info(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def k1_form(self):
+        """The pruning-kernel form of the handle's last evaluation (diagnostic, lh_family_prune_form)."""
+        return self.hip.lib.lh_family_prune_form(self.handle).decode()
 
     def status(self):
         """Synchronise the device and raise if a launch since the last call met a malformed (device-resident) schedule."""

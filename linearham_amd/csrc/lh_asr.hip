@@ -246,13 +246,22 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
                                                   const AsrOp* __restrict__ desc, const double* __restrict__ brlen,
                                                   const double* __restrict__ rates, const double* __restrict__ eig,
                                                   const double* __restrict__ pi,
-                                                  const uint8_t* __restrict__ choice_g,
+                                                  uint8_t* __restrict__ choice_g,
                                                   const uint8_t* __restrict__ naive, uint64_t seed, uint64_t sample0,
-                                                  double2* clv, int Lp, uint8_t* __restrict__ anc, int dbg_mode,
+                                                  double2* clv, int Lp, uint8_t* __restrict__ anc,
                                                   const int4* __restrict__ hdr) {
   extern __shared__ double2 asr_smem[];
-  if (hdr[blockIdx.y].w != 0) return;  // malformed schedule (reported through lh_family_status)
   const int n_ops = T - 2;
+  if (hdr[blockIdx.y].w != 0) {
+    // malformed schedule (reported through lh_family_status): states are bytes and have no NaN, so the sample's rows get
+    // the sentinel 0xff -- no stale byte of the caller's buffers may look like a draw (include/linearham_amd.h)
+    if (blockIdx.x == 0) {
+      uint8_t* a = anc + (size_t)blockIdx.y * n_ops * (size_t)L;
+      for (size_t i = threadIdx.x; i < (size_t)n_ops * L; i += blockDim.x) a[i] = 0xff;
+      for (int i = threadIdx.x; i < L; i += blockDim.x) choice_g[(size_t)blockIdx.y * L + i] = 0xff;
+    }
+    return;
+  }
   const int NP = n_prune + 1;  // patterns, the all-N one (id n_prune) included
   double* tiptab = reinterpret_cast<double*>(asr_smem);           // [T][4][4]
   double* pin = tiptab + (size_t)T * 16;                          // [n_ops][4][4] (entry n_ops-1 unused)
@@ -346,7 +355,7 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
   }
   __syncthreads();
   const int cnt = misc[0], base = misc[1], cntp = misc[2];
-  if (cnt == 0 || dbg_mode == 1) return;  // no site of this sample drew this category (uniform)
+  if (cnt == 0) return;  // no site of this sample drew this category (uniform)
 
   const double* __restrict__ p4 = pi + (size_t)sample * 4;
   const uint8_t* __restrict__ nv = naive + (size_t)sample * L;
@@ -442,7 +451,6 @@ __global__ void __launch_bounds__(256) asr_kernel(int R, int T, int L, int n_pru
       }
     }
   }
-  if (dbg_mode == 2) return;
   // the sites' lanes below read CLVs that other lanes and waves of this workgroup stored above
   __threadfence_block();
   __syncthreads();
@@ -543,10 +551,9 @@ int launch_asr(const DevFamily& fam, int n, int R, int T, const int32_t* ops, co
                      fam.n_prune, fam.site_pat, site_lik, site_scal, naive, seed, sample0, rate_choice);
   const size_t sched_lds = (size_t)(T - 2) * (sizeof(int4) + 2 * sizeof(int32_t));
   hipLaunchKernelGGL(asr_sched_kernel, dim3(n), dim3(64), sched_lds, stream, T, ops, hdr, static_cast<AsrOp*>(desc));
-  static const int dbg = debug_options().asr_dbg;  // phase-timing hook
   hipLaunchKernelGGL(asr_kernel, dim3(R, n), dim3(256), lds, stream, R, T, L, fam.n_prune, fam.msa, fam.site_pat,
-                     static_cast<const AsrOp*>(desc), brlen, rates, eig, pi, (const uint8_t*)rate_choice, naive, seed,
-                     sample0, reinterpret_cast<double2*>(clv), (int)asr_slots(L, R), anc, dbg, hdr);
+                     static_cast<const AsrOp*>(desc), brlen, rates, eig, pi, rate_choice, naive, seed,
+                     sample0, reinterpret_cast<double2*>(clv), (int)asr_slots(L, R), anc, hdr);
   return 0;
 }
 

@@ -25,18 +25,11 @@ const DebugOptions& debug_options() {
     o.sample_timing = set("LH_SAMPLE_TIMING");
     o.k1_tile_cap = num("LH_K1_TILE_CAP", 0);
     o.k1_cxx_walk = set("LH_K1_CXX_WALK");
-    o.k1_s4 = set("LH_K1_S4");
     o.k1_tables = set("LH_K1_TABLES");
     o.k1_no_tables = set("LH_K1_NO_TABLES");
     o.k1_segments = set("LH_K1_SEGMENTS");
-    o.k1_no_segments = set("LH_K1_NO_SEGMENTS");
-    o.k1_tips_scratch = set("LH_K1_TIPS_SCRATCH");
-    o.k1_ct_segments = set("LH_K1_CT_SEGMENTS");
     o.k1_seg_waves = num("LH_K1_SEG_WAVES", o.k1_seg_waves);
     o.k1_no_fuse = set("LH_K1_NO_FUSE");
-    o.k1_persist = num("LH_K1_PERSIST", 0);
-    o.dbg_maxops = num("LH_DBG_MAXOPS", o.dbg_maxops);
-    o.asr_dbg = num("LH_ASR_DBG", 0);
     return o;
   }();
   return opts;
@@ -129,6 +122,7 @@ struct lh_family {
   } smp;
   int32_t n_ucol_used = 0;  // (naive base, pattern) pairs some xMSA column has (lh_family_info)
   int32_t* err_flag = nullptr;  // device word (arena): K0c sets it when a schedule is malformed (lh_family_status)
+  std::string k1_form;          // the K1 kernel form of the last evaluation (lh_family_prune_form)
   std::vector<EventSet> events;
   double ms[3] = {0, 0, 0};
   int64_t launches = 0;
@@ -751,6 +745,8 @@ void lh_family_destroy(lh_family* f) {
 
 int64_t lh_forward_size(const lh_family* f) { return f ? f->host.forward_size : 0; }
 
+const char* lh_family_prune_form(const lh_family* f) { return f ? f->k1_form.c_str() : ""; }
+
 int lh_family_consensus_sets(const lh_family* f) {
   if (!f) return 0;
   const lh::DevFamily& h = f->host;
@@ -1045,6 +1041,7 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
   if (T < 3) return fail("lh_eval_batch: need at least 3 tips");
   if (R < 1 || R > 64) return fail("lh_eval_batch: num_rates out of range");
   if (max_depth < 0 || max_depth > 16) return fail("lh_eval_batch: max_depth out of range");
+  // (launch_prune checks the LDS need of the form it takes -- trees this large with a stack deeper than four slots do not fit)
   if ((size_t)T * 128 > 160 * 1024) return fail("lh_eval_batch: too many tips for the LDS tip table");
   if (!ops || !brlen || !er || !pi || !alpha || !loglik) return fail("lh_eval_batch: null array");
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
@@ -1070,6 +1067,8 @@ int lh_eval_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
     const int planes = lh::launch_prune(f->host, m, R, T, max_depth, ops + (size_t)off * n_ops * 4,
                                         brlen + (size_t)off * nodes, rates, w.eig, w.prune, pi + (size_t)off * 4,
                                         w.site_lik, w.site_scal, stream);
+    if (planes < 0) return fail(std::string("lh_eval_batch: ") + lh::prune_last_error());
+    f->k1_form = lh::prune_last_form();
     if (f->profile) LH_HIP(hipEventRecord(es.e[2], stream));
     if (run_forward(f, m, planes, w.site_lik, w.site_scal, pi + (size_t)off * 4, nullptr, em_out, loglik + off, outs, off,
                     stream))
@@ -1100,8 +1099,10 @@ static bool valid_op(const int32_t* op, int T, int nodes, int max_depth) {
 // lh_schedule_tree leaves there (a tip-accumulate op takes one, a pop-accumulate op two, a cherry none; T - 3 in all) --
 // the fused K1 prologue files its matrices by that number.  (The kernels check the same thing again on the device:
 // schedules may also arrive in device memory.)
+// And the stack discipline: a push goes to slot = the number of pending siblings, a pop takes the last one, none is left at
+// the end (a schedule that breaks it within the slot range computes a finite, wrong likelihood; the device checks repeat this).
 static bool valid_schedule(const int32_t* ops, int T, int nodes, int max_depth) {
-  int count = 0;
+  int count = 0, depth = 0;
   for (int k = 0; k < T - 2; ++k) {
     const int32_t* op = ops + (size_t)k * 4;
     if (!valid_op(op, T, nodes, max_depth)) return false;
@@ -1109,12 +1110,14 @@ static bool valid_schedule(const int32_t* ops, int T, int nodes, int max_depth) 
     if (kind == lh::OP_CHERRY) {
       if (rank != 0 && rank != count) return false;
       if (((op[0] & lh::OP_PUSH_FLAG) != 0) != (k != 0)) return false;  // the first op has no accumulator to set aside, every later cherry does
+      if (k != 0 && op[3] != depth++) return false;
     } else {
       if (rank != count) return false;
       count += kind == lh::OP_POP_ACC ? 2 : 1;
+      if (kind == lh::OP_POP_ACC && op[3] != --depth) return false;
     }
   }
-  return count == T - 3;
+  return count == T - 3 && depth == 0;
 }
 
 // All schedules of a batch; a few threads when the batch is large (0.19 us per op on one core: 0.4 ms per 2048 samples of
@@ -1443,6 +1446,8 @@ int lh_asr_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_depth, c
     // per-rate planes: K1 must not mix the categories here
     const int planes = lh::launch_prune(f->host, m, R, T, max_depth, ops_m, bl_m, r_m, w.eig, w.prune, pi_m,
                                         w.site_lik, w.site_scal, stream, false);
+    if (planes < 0) return fail(std::string("lh_asr_batch: ") + lh::prune_last_error());
+    f->k1_form = lh::prune_last_form();
     if (planes != R && f->host.n_prune > 0) return fail("lh_asr_batch: internal error (rate planes were mixed)");
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (f->profile) {

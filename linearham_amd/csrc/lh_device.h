@@ -203,6 +203,10 @@ void launch_model_setup(int n, int R, const double* er, const double* pi, const 
 int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const int32_t* ops,
                  const double* brlen, const double* rates, const double* eig, const PruneWs& ws, const double* pi,
                  double* site_lik, int32_t* site_scal, hipStream_t stream, bool allow_fused = true);
+// the kernel form the calling thread's last launch_prune chose ("w6<3,false>", "seg4<4,true>", "ct6<16,false,false,true>":
+// kernel<depth, N-aware, all rates in one workgroup, assembly walk>) and, after a -1, why it failed
+const char* prune_last_form();
+const char* prune_last_error();
 
 // GTR eigendecomposition only (K0a's last role): eig[n][36]
 void launch_gtr_setup(int n, const double* er, const double* pi, double* eig, hipStream_t stream);
@@ -235,8 +239,9 @@ void launch_forward(const DevFamily& fam, const DevFamily* fam_dev, int n, int R
                     bool extended, hipStream_t stream);
 size_t forward_lds_bytes(const DevFamily& fam);
 
-// Every environment switch of the device library in one place: test hooks and experiments, none of them part of the
-// C ABI.  Read once per process (the first call of debug_options(), lh_capi.hip); a switch that is not set leaves the
+// Every environment switch of the device library in one place: hooks that tests/ use to push a family onto a kernel
+// form another shape takes by itself (timing experiments are built from a copy of csrc/, tools/build_asm_variant.sh);
+// none of them part of the C ABI.  Read once per process (the first call of debug_options(), lh_capi.hip); a switch that is not set leaves the
 // product behaviour.
 struct DebugOptions {
   int chunk = 49152;           // LH_CHUNK=<n>: tree samples per launch group (tests: several groups inside one small call)
@@ -248,18 +253,11 @@ struct DebugOptions {
   bool sample_timing = false;  // LH_SAMPLE_TIMING: stage times of every lh_eval_sample_batch call on stderr
   int k1_tile_cap = 0;         // LH_K1_TILE_CAP=<sites>: small K1 tiles, so that small families run the multi-tile path
   bool k1_cxx_walk = false;    // LH_K1_CXX_WALK: the cherry-table form with its C++ walk instead of the assembly one
-  bool k1_s4 = false;          // LH_K1_S4: the assembly walk with four sites per lane (three waves per SIMD)
   bool k1_tables = false;      // LH_K1_TABLES: the cherry-table form for the fused shapes too
   bool k1_no_tables = false;   // LH_K1_NO_TABLES: the cherry-table form's kernels without tables
   bool k1_segments = false;    // LH_K1_SEGMENTS: the segmented tip table (large trees) on small trees too
-  bool k1_ct_segments = false;   // LH_K1_CT_SEGMENTS: large trees through the table-less assembly walk, a schedule segment at a time
-  bool k1_tips_scratch = false;  // LH_K1_TIPS_SCRATCH: large trees through the cherry-table form with the tip table in the scratch region
-  bool k1_no_segments = false; // LH_K1_NO_SEGMENTS: large trees through the cherry-table form (whole tip table in LDS)
   int k1_seg_waves = 4;        // LH_K1_SEG_WAVES=<4|5>: register budget of the segmented kernels
   bool k1_no_fuse = false;     // LH_K1_NO_FUSE: one workgroup per (sample, rate)
-  int k1_persist = 0;          // LH_K1_PERSIST=<workgroups> (builds with -DLH_EXP_K1_PERSIST only)
-  int dbg_maxops = 1 << 30;    // LH_DBG_MAXOPS=<m> (builds with -DLH_DEBUG_WALK only): the walk stops after m ops
-  int asr_dbg = 0;             // LH_ASR_DBG=<phase>: K3 stops after a phase (timing hook)
 };
 const DebugOptions& debug_options();
 

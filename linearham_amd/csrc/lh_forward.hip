@@ -37,15 +37,6 @@
 
 namespace lh {
 
-// -DLH_EXP_K2A_STAMPS: cycle counter at K2a's phase boundaries for workgroups 20000..21023 of the third launch,
-// means printed on stderr (an instrument for experiments; never in the shipped build).
-#ifdef LH_EXP_K2A_STAMPS
-__device__ unsigned long long k2a_stamps[1024][12];
-#define LH_STAMP(i) \
-  if (threadIdx.x == 0 && blockIdx.x >= 20000 && blockIdx.x < 21024) k2a_stamps[blockIdx.x - 20000][i] = __builtin_readcyclecounter();
-#else
-#define LH_STAMP(i)
-#endif
 constexpr int kFwdThreads = 256;
 constexpr int kFwdWaves = kFwdThreads / 64;
 constexpr int kJunctionWaves = 4;  // samples per K2b workgroup
@@ -360,7 +351,6 @@ __device__ static int fill_consensus(const DevSegments& seg, const double* em, i
     cons_pk[j0 + 1] = p1.k;
   }
   __syncthreads();
-  LH_STAMP(9)
 
   double v[kG];
   int c[kG];
@@ -454,7 +444,6 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
   double* cons_pv = cons_inv + cons_cap;                                    // [cap + 4]
   int* cons_pk = reinterpret_cast<int*>(cons_pv + cons_cap + 4);            // [cap + 4]
   int* ems = cons_pk + (cons_cap ? cons_cap + 4 : 0);                       // [C + 1] (kExt only): 2^-256 counts
-  LH_STAMP(0)
   if (tid == 0) *em_bad = 0;
   bool my_bad = false;
 
@@ -513,10 +502,8 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
     };
     Mixed first;
     if (tid < NP) first = mix(tid);
-    LH_STAMP(10)
     if (tid < 5) inv_pi[tid] = tid < 4 ? 1.0 / pi[s * 4 + tid] : 1.0;
     __syncthreads();
-    LH_STAMP(11)
     if (tid < NP) finish(tid, first);
     for (int pat = tid + kFwdThreads; pat < NP; pat += kFwdThreads) finish(pat, mix(pat));
     if (tid < 5) {
@@ -542,11 +529,9 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
   // The consensus form of the germline products needs every emission in (0, 1] (see fill_consensus) and its
   // reciprocal finite; a sample with a zero or nearly subnormal emission (underflow), a NaN or an emission above 1
   // walks its products factor by factor as the reference does.
-  LH_STAMP(1)
   if (my_bad) *em_bad = 1;
   if (tid == 0) em[C] = 1.0;
   __syncthreads();
-  LH_STAMP(2)
   if (em_out) {  // the caller's view: one value per xMSA column
     const int CX = fam.n_xmsa;
     for (int c = tid; c < CX; c += kFwdThreads) {
@@ -588,11 +573,8 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
       return fill_consensus<kG, kByteOff>(seg, em, tid, out, redi, phase, cons_inv, cons_pv, cons_pk, cons_cap);
     return fill_segments<kG, kByteOff>(seg, em, tid, out, redi, phase);
   };
-  LH_STAMP(3)
   int cv = fill(fam.vpadding, gem, 0);
-  LH_STAMP(4)
   cv += fill(fam.vgerm, gem + nV, 1);
-  LH_STAMP(5)
   int cd = 0, cj;
   if (!kExt && nD <= 64 && nJ <= 64 &&
       (direct || (fam.dgerm.cons_sites == 0 && fam.jgerm.cons_sites == 0 && fam.jpadding.cons_sites == 0))) {
@@ -608,14 +590,10 @@ __global__ void __launch_bounds__(kFwdThreads) __attribute__((amdgpu_num_sgpr(80
     __syncthreads();
     cd = redi[1];
     cj = redi[2] + redi[3];
-    LH_STAMP(8)
   } else if (fam.has_d) {
     cd = fill(fam.dgerm, gem + 2 * (size_t)nV, 0);
-    LH_STAMP(6)
     cj = fill(fam.jgerm, gem + 2 * (size_t)nV + nD, 1);
-    LH_STAMP(7)
     cj += fill(fam.jpadding, gem + 2 * (size_t)nV + nD + nJ, 0);
-    LH_STAMP(8)
   } else {
     cj = fill(fam.jgerm, gem + 2 * (size_t)nV, 0);
     cj += fill(fam.jpadding, gem + 2 * (size_t)nV + nJ, 1);
@@ -1792,26 +1770,6 @@ void launch_forward(const DevFamily& fam, const DevFamily* fam_dev, int n, int R
   else
     launch_emission_g<4>(LH_ARGS);
 #undef LH_ARGS
-#ifdef LH_EXP_K2A_STAMPS
-  {
-    static int calls = 0;
-    if (++calls == 3) {
-      (void)hipDeviceSynchronize();
-      static unsigned long long h[1024][12];
-      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(k2a_stamps), sizeof(h));
-      double acc[12] = {0};
-      const int m = std::min(std::max(n - 20000, 0), 1024);
-      for (int b = 0; b < m; ++b)
-        for (int i = 1; i < 12; ++i) acc[i] += (double)(h[b][i] - h[b][0]);
-      const char* names[10] = {"start", "emissions done", "barrier", "jem written", "vpadding", "vgerm", "dgerm", "jgerm",
-                               "jpadding", "vgerm scan done"};
-      fprintf(stderr, "[K2a stamps, cycles since kernel start, mean of %d workgroups]", m);
-      for (int i = 1; i < 10; ++i) fprintf(stderr, " %s %.0f;", names[i], acc[i] / std::max(m, 1));
-      fprintf(stderr, " [plane loads issued %.0f; 1/pi barrier passed %.0f]", acc[10] / std::max(m, 1), acc[11] / std::max(m, 1));
-      fprintf(stderr, "\n");
-    }
-  }
-#endif
   const int ga = (fam.vgerm.n_genes + 63) / 64;
   const int gb = (std::max(fam.dgerm.n_genes, fam.jgerm.n_genes) + 63) / 64;
 #define LH_ARGS gb, fam, n, gem, gcnt, jem, jrs, dxf, dxc, loglik, forward_out, scaler_out, ext, stream

@@ -51,6 +51,24 @@ def main(mode, n_leaves, repeat=1):
     elif mode == "slot":         # a stack slot beyond the depth the kernel was built for
         k_pop = next(k for k in range(ops.shape[1]) if (ops[victim, k, 0] & 15) == 2)
         ops[victim, k_pop, 3] = 40
+    elif mode in ("popslot", "pushslot", "unbalanced"):
+        # Stack discipline broken with every field IN RANGE: nothing would index out of bounds, the kernel would return a
+        # finite, wrong likelihood.  popslot: a pop takes another slot than the last one pushed; pushslot: a push goes
+        # over a live slot / skips one; unbalanced: the last pop becomes a tip-into-accumulator op (a sibling is left).
+        kinds = ops[victim, :, 0] & 15
+        pushes = [k for k in range(ops.shape[1]) if ops[victim, k, 0] & 16]
+        pops = [k for k in range(ops.shape[1]) if kinds[k] == 2]
+        assert pushes and pops, "the victim's tree has no pending sibling at all"
+        if mode == "popslot":
+            k = pops[0]
+            ops[victim, k, 3] = 1 if ops[victim, k, 3] == 0 else 0
+        elif mode == "pushslot":
+            k = pushes[0]
+            ops[victim, k, 3] = 1 if ops[victim, k, 3] == 0 else 0
+        else:
+            k = pops[-1]
+            ops[victim, k, 0] = (ops[victim, k, 0] & ~15) | 1
+            ops[victim, k, 1] = 1                      # a tip where the popped node was (fields in range)
     dev = torch.device("cuda", 0)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
     d_ops, d_brl = t(ops, np.int32), t(np.stack(brl), np.float64)
@@ -78,15 +96,25 @@ def main(mode, n_leaves, repeat=1):
     except RuntimeError as e:
         host_error = str(e)
     ll_out = [None if not np.isfinite(x) else float(x) for x in got]
+    form = fam.k1_form()
+    oracle = []
+    if mode == "none":       # the clean run is compared with the oracle by the caller, not only with other runs of itself
+        for r in rows[:len(rows) // repeat]:
+            h.initialize_phylo_parameters(r["tree"], r["er"], r["pi"], r["alpha"], 4, is_path=False)
+            h.initialize_phylo_emission()
+            oracle.append(float(h.log_likelihood()))
     if repeat > 1:       # a digest instead of the whole vector: which samples are NaN, and whether the copies agree
         base = len(ll_out) // repeat
         agree = all(ll_out[i] == ll_out[i % base] for i in range(len(ll_out)) if i % base != victim)
         print(json.dumps({"status": status, "second": second, "host_error": host_error, "n": len(ll_out),
                           "nan_at": [i for i, x in enumerate(ll_out) if x is None][:8], "copies_agree": agree,
-                          "ll": ll_out[:base]}))
+                          "ll": ll_out[:base], "form": form, "oracle": oracle}))
     else:
-        print(json.dumps({"status": status, "second": second, "host_error": host_error, "ll": ll_out}))
+        print(json.dumps({"status": status, "second": second, "host_error": host_error, "ll": ll_out, "form": form,
+                          "oracle": oracle}))
     fam.close()
+    import shutil
+    shutil.rmtree(out, ignore_errors=True)
 
 
 if __name__ == "__main__":

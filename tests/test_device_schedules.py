@@ -1,8 +1,9 @@
 """Device-resident schedules are not trusted (lh_eval_batch_device): a malformed op must come back as a status code
 and NaN for that sample, never as an out-of-bounds access on the GPU.  The reference checks nothing here
 (src/PhyloHMM.cpp:421 uses the parsed tree unchecked); this is the C ABI's own contract (include/linearham_amd.h).
-Both forms of K1 are exercised: the register-stack form runs behind schedule_ranks_kernel, the cherry-table form
-(LH_K1_TABLES=1) behind K0c (schedule_check_kernel)."""
+Both forms of K1 are exercised: the register-stack form runs behind schedule_stack_check_kernel (fields, stack
+discipline, ranks), the cherry-table form (LH_K1_TABLES=1) behind K0c (schedule_check_kernel).  Every clean run is
+compared with the numpy oracle too, so that "the neighbours keep the bits of the clean run" means the right bits."""
 import json
 import os
 import subprocess
@@ -18,16 +19,22 @@ def _run(mode, env_extra, n_leaves=12, repeat=1):
     r = subprocess.run([sys.executable, WORKER, mode, str(n_leaves), str(repeat)], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, **env_extra))
     assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    if mode == "none":       # clean schedules: the kernel form's numbers against the oracle's (north star 1e-6; asserted 1e-10)
+        assert len(res["oracle"]) == len(res["ll"]) // repeat
+        for got, want in zip(res["ll"], res["oracle"]):
+            assert got is not None and abs(got - want) <= 1e-10 * abs(want), (res["form"], got, want)
+    return res
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("form", ["stack", "tables"])
-@pytest.mark.parametrize("mode", ["tip", "kind", "node", "rank", "slot"])
+@pytest.mark.parametrize("mode", ["tip", "kind", "node", "rank", "slot", "popslot", "pushslot", "unbalanced"])
 def test_corrupted_device_schedule_gets_a_status_code(mode, form):
     env = {"LH_K1_TABLES": "1"} if form == "tables" else {}
     good = _run("none", env)
     assert good["status"] == "" and good["host_error"] == "" and all(x is not None for x in good["ll"])
+    assert good["form"].startswith("ct" if form == "tables" else "w"), good["form"]
     bad = _run(mode, env)
     # lh_eval_batch (host pointers) refuses the batch whatever the kernel form -- rank bits zeroed (ops built against the
     # round-1 ABI) included: the rank of every op must be the running matrix count
@@ -52,18 +59,18 @@ def test_corrupted_schedule_in_a_larger_tree():
 
 
 @pytest.mark.gpu
-def test_large_tree_forms_agree():
-    """A 200-leaf family (tip table 25 KB per rate: the launcher's 'large tree' case) through the segmented
-    register-stack kernels (default) and through the cherry-table form with its tip table in the scratch region
-    (LH_K1_TIPS_SCRATCH=1, assembly walk lh_prune_walk_asm_s2g.inc): the same log-likelihoods to rounding, and a corrupted
-    schedule is caught in both."""
+def test_large_tree_form_checks_fields_and_discipline():
+    """A 200-leaf family (tip table 25 KB per rate: the launcher's 'large tree' case, the segmented register-stack
+    kernels behind the same wave-per-sample check without ranks): clean schedules match the oracle, a node out of range and
+    a pop from the wrong slot are both caught."""
     a = _run("none", {}, n_leaves=200)
-    b = _run("none", {"LH_K1_TIPS_SCRATCH": "1"}, n_leaves=200)
-    assert a["status"] == "" and b["status"] == ""
-    for x, y in zip(a["ll"], b["ll"]):
-        assert x is not None and y is not None and abs(x - y) <= 1e-10 * abs(x), (x, y)
-    bad = _run("node", {"LH_K1_TIPS_SCRATCH": "1"}, n_leaves=200)
-    assert "malformed schedule" in bad["status"] and bad["ll"][2] is None
+    assert a["status"] == "" and a["form"].startswith("seg4"), a["form"]
+    for mode in ("node", "popslot"):
+        bad = _run(mode, {}, n_leaves=200)
+        assert "malformed schedule" in bad["status"] and bad["ll"][2] is None, (mode, bad["status"])
+        for i, (x, y) in enumerate(zip(bad["ll"], a["ll"])):
+            if i != 2:
+                assert x == y, (mode, i, x, y)
 
 
 @pytest.mark.gpu

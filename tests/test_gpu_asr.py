@@ -57,17 +57,25 @@ def _run(hip, h, rows, R, seed, first_sample, rng, naive_with_n=True):
     return mism, n * L, anc, choice
 
 
-@pytest.mark.parametrize("preset", ["small", "medium", "igk", "rates1", "rates8"])
+@pytest.mark.parametrize("preset", ["small", "medium", "igk", "rates1", "rates8", "mixed_n", "mixed_n_deep"])
 def test_asr_matches_oracle(hip, tmp_path, preset):
     from tools import synth_family as sf
     out = str(tmp_path / "fam")
     spec = {"small": sf.Spec.small(n_samples=5), "medium": sf.Spec.small(n_leaves=40, n_samples=3, seed=11),
             "igk": sf.Spec.small(locus="igk", n_samples=3, seed=5), "rates1": sf.Spec.small(n_samples=2, seed=8),
-            "rates8": sf.Spec.small(n_samples=2, n_leaves=17, seed=9)}[preset]
+            "rates8": sf.Spec.small(n_samples=2, n_leaves=17, seed=9),
+            # N inside alignment columns (ragged reads, ambiguous bases): K1's N-aware unfused planes, K3's tip handling of
+            # state 4 in the MSA on the way up and down; the second on a balanced tree (stack depth >= 5)
+            "mixed_n": sf.Spec.small(n_leaves=20, n_samples=3, seed=42, ragged=6, ambiguous=0.02),
+            "mixed_n_deep": sf.Spec.small(n_leaves=64, n_samples=2, seed=49, tree_shape="balanced", n_nni=0, ragged=6,
+                                          ambiguous=0.01)}[preset]
     R = {"rates1": 1, "rates8": 8}.get(preset, 4)
     sf.generate(spec, out)
     h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
     rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    if preset.startswith("mixed_n"):
+        n_n = (h.msa == 4).sum(axis=0)
+        assert ((n_n > 0) & (n_n < h.msa.shape[0])).sum() > 10
     mism, total, anc, choice = _run(hip, h, rows, R, seed=20261004, first_sample=7, rng=np.random.default_rng(3))
     assert mism <= max(1, total // 200000), (mism, total)
     assert choice.max() < R

@@ -75,6 +75,9 @@ def expand_forward(h, fam_desc, fwd, sco):
     return out
 
 
+LAST_RUN = {}
+
+
 def run_family(hip, h, samples, num_rates, extended=False):
     """samples: list of dict(tree=newick, er, pi, alpha). Returns (gpu results, oracle results)."""
     import linearham_amd
@@ -107,6 +110,7 @@ def run_family(hip, h, samples, num_rates, extended=False):
             v = getattr(h, k)
             r[k] = v.copy() if isinstance(v, np.ndarray) else v
         ref.append(r)
+    LAST_RUN.update(form=fam.k1_form(), max_depth=depth, n_patterns=fam.info()[0])   # (tests/forms_worker.py reports these)
     fam.close()
     return desc, ll, res, ref
 

@@ -188,3 +188,39 @@ def test_newick_export_is_libpll_order(data_dir, tmp_path):
     t1 = orc.parse_newick(host.newick_roundtrip(rooted, ["naive", "a", "b", "c"]))
     t2 = orc.parse_newick(rooted)
     assert abs(sum(l for a in t1.adj for _, l in a) - sum(l for a in t2.adj for _, l in a)) < 1e-5
+
+
+def test_shm_indel_sequences_come_from_indel_reversed_seqs(tmp_path):
+    """src/HMM.cpp:74-79: a sequence flagged has_shm_indels is read from indel_reversed_seqs, not input_seqs (which then
+    holds the read as sequenced -- here one base short, not alignable as it stands).  Host and oracle build the same MSA
+    as for the unflagged family, and the xMSA structures that follow from it."""
+    from tools import synth_family as sf
+    plain, flagged = str(tmp_path / "plain"), str(tmp_path / "flagged")
+    sf.generate(sf.Spec.small(seed=44), plain)
+    sf.generate(sf.Spec.small(seed=44, shm_indels=3), flagged)
+    import yaml
+    ev = yaml.safe_load(open(os.path.join(flagged, "cluster.yaml")))["events"][0]
+    assert ev["has_shm_indels"][:4] == [True, True, True, False]
+    assert len(ev["input_seqs"][0]) == len(ev["naive_seq"]) - 1 and len(ev["indel_reversed_seqs"][0]) == len(ev["naive_seq"])
+    ref = host.PhyloHMM(os.path.join(plain, "cluster.yaml"), 0, os.path.join(plain, "hmm_params"), 0).dump(1 | 8)
+    h = host.PhyloHMM(os.path.join(flagged, "cluster.yaml"), 0, os.path.join(flagged, "hmm_params"), 0).dump(1 | 8)
+    o = orc.PhyloHMM(os.path.join(flagged, "cluster.yaml"), 0, os.path.join(flagged, "hmm_params"), 0)
+    assert h["msa"] == ref["msa"] == o.msa.tolist()
+    assert h["xmsa"] == ref["xmsa"] == o.xmsa.tolist()
+
+
+@pytest.mark.parametrize("kw", [dict(ragged=6, ambiguous=0.02), dict(locus="igk", ragged=5, ambiguous=0.02)])
+def test_n_inside_alignment_columns_host_matches_oracle(tmp_path, kw):
+    """Ragged reads / ambiguous bases (N inside alignment columns; src/HMM.cpp:69-83, src/utils.cpp:155-164): the host's
+    MSA, xMSA (naive base x column pairs, N rows included) and index arrays equal the oracle's."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_leaves=20, seed=42, **kw), out)
+    yaml_path, pdir = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params")
+    o = orc.PhyloHMM(yaml_path, 0, pdir, 0)
+    n_n = (o.msa == 4).sum(axis=0)
+    assert ((n_n > 0) & (n_n < o.msa.shape[0])).sum() >= 10          # columns that mix N with bases
+    d = host.PhyloHMM(yaml_path, 0, pdir, 0).dump(1 | 8)
+    assert d["msa"] == o.msa.tolist() and d["xmsa"] == o.xmsa.tolist() and d["xmsa_seqs"] == o.xmsa_seqs
+    for k in ["vpadding_xmsa_inds", "vgerm_xmsa_inds", "vd_junction_xmsa_inds", "jgerm_xmsa_inds", "jpadding_xmsa_inds"]:
+        assert d[k] == np.asarray(getattr(o, k)).tolist(), k

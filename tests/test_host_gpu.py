@@ -76,15 +76,26 @@ def test_phylo_hmm(goldens, data_dir, case, params, R):
             assert s[k] == want[k], k
 
 
-@pytest.mark.parametrize("locus,n_rows", [("igh", 9), ("igk", 9), ("igh", 150), ("igh", 1), ("igk", 2)])
-def test_run_pipeline_matches_oracle(tmp_path, locus, n_rows):
+@pytest.mark.parametrize("locus,n_rows,kw", [
+    ("igh", 9, {}), ("igk", 9, {}), ("igh", 150, {}), ("igh", 1, {}), ("igk", 2, {}),
+    # ragged reads and ambiguous bases: N inside alignment columns (src/HMM.cpp:69-83, src/PhyloHMM.cpp:368-370)
+    ("igh", 12, dict(n_leaves=20, seed=42, ragged=6, ambiguous=0.02)),
+    ("igk", 12, dict(n_leaves=12, seed=43, ragged=5, ambiguous=0.02)),
+    # more than 64 alleles per segment: the sampled STATES of K4's multi-chunk loops against the oracle's draws, not
+    # only against the host sampler (src/HMM.cpp:1222-1353)
+    ("igh", 50, dict(n_v=300, n_d=70, n_j=5, seed=21)),
+    ("igk", 30, dict(n_v=150, n_j=70, seed=22)),
+    # sequences flagged has_shm_indels are read from indel_reversed_seqs (src/HMM.cpp:74-79)
+    ("igh", 6, dict(seed=44, shm_indels=3)),
+], ids=["igh9", "igk9", "igh150", "igh1", "igk2", "igh_mixed_n", "igk_mixed_n", "many_alleles", "many_alleles_igk", "shm_indels"])
+def test_run_pipeline_matches_oracle(tmp_path, locus, n_rows, kw):
     """PhyloHMM::RunPipeline (src/PhyloHMM.cpp:393-446) on a synthetic RevBayes table: batched GPU
-    evaluation + host sampling must reproduce the row-by-row oracle, including the RNG stream -- also when the
-    rows are sampled by several worker threads, each on a copy of the engine advanced to its first row (150
-    rows: every core of the box samples a share)."""
+    evaluation + sampling (device sampler K4; first and last row re-drawn by the host sampler) must reproduce the
+    row-by-row oracle, including the RNG stream -- also when the rows are formatted by several worker threads (150
+    rows: every core of the box takes a share)."""
     from tools import synth_family as sf
     out = str(tmp_path / "fam")
-    sf.generate(sf.Spec.small(n_samples=n_rows, locus=locus), out)
+    sf.generate(sf.Spec.small(n_samples=n_rows, locus=locus, **kw), out)
     yaml_path, pdir, tsv = os.path.join(out, "cluster.yaml"), os.path.join(out, "hmm_params"), os.path.join(out, "trees.tsv")
     h = host.PhyloHMM(yaml_path, 0, pdir, 3)
     res = os.path.join(out, "lh.tsv")
@@ -261,6 +272,8 @@ SAMPLER_FAMILIES = {
     # more than 64 alleles per segment: K4's multi-chunk loops over the left genes (lh_sample.hip: 64 genes at a time)
     "many_alleles": dict(kind="small", n_rows=1500, kw=dict(n_samples=32, seed=21, n_v=300, n_d=70, n_j=5)),
     "many_alleles_igk": dict(kind="small", n_rows=1500, kw=dict(n_samples=32, seed=22, locus="igk", n_v=150, n_j=70)),
+    # N inside alignment columns (ragged reads, ambiguous bases): K1's N-aware kernels feed the forward arrays K4 draws from
+    "mixed_n": dict(kind="small", n_rows=3000, kw=dict(n_samples=32, seed=42, n_leaves=20, ragged=6, ambiguous=0.02)),
     # BASELINE.json configs[2] at full size: 100 leaves x 400 sites, 200 V (four chunks) / 30 D / 12 J
     "config2": dict(kind="full", n_rows=256, kw=dict(n_samples=256)),
 }

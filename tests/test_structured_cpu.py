@@ -112,3 +112,21 @@ def test_library_exports_every_declared_symbol():
     lib = linearham_amd.load_library().lib
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def test_generated_assembly_walk_is_reproducible():
+    """linearham_amd/csrc/lh_prune_walk_asm_s2.inc and its clobber list are GENERATED text (tools/gen_walk_asm.py): the
+    committed files must be what the committed generator writes, byte for byte -- a walk edited by hand, or a generator
+    edited without regenerating, would leave the product library out of step with its source (build.py lists the .inc
+    files among the library's dependencies)."""
+    import os
+    from tools import gen_walk_asm as g
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body, clob, _ = g.render(2)
+    csrc = os.path.join(root, "linearham_amd", "csrc")
+    assert open(os.path.join(csrc, "lh_prune_walk_asm_s2.inc")).read() == body
+    assert open(os.path.join(csrc, "lh_prune_walk_clobbers_s2.inc")).read() == clob
+    assert sorted(f for f in os.listdir(csrc) if f.endswith(".inc")) == ["lh_prune_walk_asm_s2.inc", "lh_prune_walk_clobbers_s2.inc"]
+    from linearham_amd import build
+    import inspect
+    assert ".inc" in inspect.getsource(build.build_hip)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Writes linearham_amd/csrc/lh_prune_walk_asm_s2.inc, _s4.inc and _s2g.inc (+ clobber lists): the gfx950 assembly of K1's
-schedule walk for two and for four sites per lane (alignments without N tips), and for two sites per lane with the tip
-columns gathered from the scratch region instead of LDS (large trees), used by prune_wave_asm through one inline-asm
-statement.  The text is generated because the 4x4 mat-vec and the element-wise products are the same row
+"""Writes linearham_amd/csrc/lh_prune_walk_asm_s2.inc (+ its clobber list): the gfx950 assembly of K1's schedule walk for
+two sites per lane (alignments without N tips), used by prune_wave_asm through one inline-asm statement.  (Round 3 also
+generated a four-sites-per-lane walk, one with the tip columns gathered from the scratch region and one that walks a
+schedule segment per statement; all three were measured slower and left the product with round 4 -- git 0b72f3b has them.)
+tests/test_structured_cpu.py checks that this script reproduces the committed file byte for byte.  The text is generated because the 4x4 mat-vec and the element-wise products are the same row
 pattern over four register blocks and S sites; everything else is written out below once.  Run from the repo root
 after editing:    python tools/gen_walk_asm.py
 
@@ -23,7 +24,7 @@ Register map inside the statement, S sites per lane (clobbers v5 .. v<tmp+S-1> a
   s86 offset of the descriptor to prefetch   s98 offset of the last descriptor   s87..s93, s99 temporaries
   s[94:95] exec save   s96 0x2ff00000 (high word of 2^-256)   s97 256
 S = 2: usite v5-6, scal v7, a v[8:23], st0 v[24:39], x v[40:55], u v[56:71], states v72-77, tmp v78-79 (80 registers: six
-waves per SIMD); S = 4: through v155 (three waves per SIMD).
+waves per SIMD).
 """
 import os
 import re
@@ -82,15 +83,9 @@ PREFETCH = [                                       # the descriptor two ops ahea
 
 
 class Gen:
-    def __init__(self, S, gtips=False, seg=False):
+    def __init__(self, S=2):
         self.r = Regs(S)
         self.S = S
-        self.gtips = gtips   # tip columns gathered from the scratch region (large trees) instead of the LDS tip table
-        # seg: the statement walks ONE SEGMENT of the schedule (large trees, walk without tables): the LDS table holds the
-        # tip matrices of this segment only, slot 2 j for tip A and 2 j + 1 for tip B of the segment's op j (= s82); the
-        # walk's state (a, scaler counts, stack slot 0, matrix offset) is loaded from / stored to the private array %[out]
-        # so that the C++ caller can refill the table between two statements (it initialises the array for the first one)
-        self.seg = seg
 
     def matvec(self, dst):
         """dst <- P a for all sites, rows interleaved (4 S independent chains), in the order of lh::matvec:
@@ -116,18 +111,11 @@ class Gen:
 
     def tip_column(self, dst, st, tip_expr):
         """dst <- tip-table columns of the tip whose number `tip_expr` leaves in s87, for the states in v<st>.."""
-        if self.seg:   # the tip's slot in the segment's table instead of its number
-            which = 1 if "s69, 0xffff" in tip_expr[0] else 0   # (a third tip -- table x tip ops -- does not occur without tables)
-            tip_expr = ["s_lshl_b32 s87, s82, 1"] + (["s_or_b32 s87, s87, 1"] if which else [])
         out = tip_expr + ["s_lshl_b32 s87, s87, 7", "s_add_i32 s87, s87, s81"]
         out += ["v_lshl_add_u32 v%d, v%d, 5, s87" % (self.r.tmp + s, st + s) for s in range(self.S)]
-        for s in range(self.S):
-            if self.gtips:   # s81 = byte offset of the tip table in the scratch region s[74:75]
-                out += ["global_load_dwordx4 v[%d:%d], v%d, s[74:75]" % (dst + 8 * s, dst + 8 * s + 3, self.r.tmp + s),
-                        "global_load_dwordx4 v[%d:%d], v%d, s[74:75] offset:16" % (dst + 8 * s + 4, dst + 8 * s + 7, self.r.tmp + s)]
-            else:            # s81 = LDS address of the tip table
-                out += ["ds_read_b128 v[%d:%d], v%d" % (dst + 8 * s, dst + 8 * s + 3, self.r.tmp + s),
-                        "ds_read_b128 v[%d:%d], v%d offset:16" % (dst + 8 * s + 4, dst + 8 * s + 7, self.r.tmp + s)]
+        for s in range(self.S):   # s81 = LDS address of the tip table
+            out += ["ds_read_b128 v[%d:%d], v%d" % (dst + 8 * s, dst + 8 * s + 3, self.r.tmp + s),
+                    "ds_read_b128 v[%d:%d], v%d offset:16" % (dst + 8 * s + 4, dst + 8 * s + 7, self.r.tmp + s)]
         return out
 
     def table_entry(self, dst):
@@ -200,14 +188,6 @@ class Gen:
         add(["v_mov_b32_e32 v%d, 0" % (r.scal + i) for i in range((S + 1) // 2)])
         for i in range(4 * S):
             add(["v_mov_b32_e32 v%d, 0" % (A + 2 * i), "v_mov_b32_e32 v%d, 0x3ff00000" % (A + 2 * i + 1)])
-        if self.seg:
-            off_st0, off_pm = 32 * S + 16, 64 * S + 16   # (16-byte aligned behind the packed scaler counts)
-            # (always: the caller initialises the array to the walk's start -- a = 1, counts 0, matrix offset 0)
-            add(["scratch_load_dwordx4 v[%d:%d], %%[out], off offset:%d" % (A + 4 * i, A + 4 * i + 3, 16 * i) for i in range(2 * S)])
-            add(["scratch_load_dword v%d, %%[out], off offset:%d" % (r.scal + i, 32 * S + 4 * i) for i in range((S + 1) // 2)])
-            add(["scratch_load_dwordx4 v[%d:%d], %%[out], off offset:%d" % (ST0 + 4 * i, ST0 + 4 * i + 3, off_st0 + 16 * i) for i in range(2 * S)])
-            add(["scratch_load_dword v%d, %%[out], off offset:%d" % (r.tmp, off_pm), "s_waitcnt vmcnt(0)",
-                 "v_readfirstlane_b32 s77, v%d" % r.tmp])
         add(["s_cmp_lt_i32 s83, 1", "s_cbranch_scc1 lh_walk_end",
              "s_lshl_b32 s98, s83, 3", "s_add_i32 s98, s98, -8",
              "s_load_dwordx2 s[68:69], s[84:85], 0x0", "s_min_u32 s87, s98, 8", "s_load_dwordx2 s[72:73], s[84:85], s87",
@@ -222,7 +202,7 @@ class Gen:
         cherry = self.tip_column(U, r.sa, tip_a) + self.tip_column(X, r.sb, tip_b)
         add(["; cherry", "s_bfe_u32 s88, s68, 0x50004", "s_cmp_eq_u32 s88, 0", "s_cbranch_scc1 lh_walk_cherry_np"])
         add(self.push_block("lh_walk_cherry"))
-        tipwait = "s_waitcnt vmcnt(0) lgkmcnt(0)" if self.gtips else "s_waitcnt lgkmcnt(0)"
+        tipwait = "s_waitcnt lgkmcnt(0)"
         add(cherry + [tipwait] + PREFETCH + self.product(U, X) + self.states(70, 71) + ["s_branch lh_walk_tail"])
         add(["lh_walk_cherry_np:"] + cherry + [tipwait] + ROTATE + PREFETCH + self.product(U, X) + self.states(70, 71) +
             ["s_branch lh_walk_tail"])
@@ -240,8 +220,7 @@ class Gen:
         half = len(mv) // 2
         add(["; tip into accumulator", "lh_walk_tip:"] + self.p_load() + self.tip_column(U, r.sa, tip_a) + ["s_waitcnt lgkmcnt(0)"] +
             ROTATE + weave(mv[:half], P_ADV + PREFETCH + st_a) + st_bc + mv[half:] +
-            # (global tip columns: they are older than the next op's state loads, of which at least S are in flight)
-            (["s_waitcnt vmcnt(%d)" % S] if self.gtips else []) + self.product(U, X) + ["s_branch lh_walk_tail"])
+            self.product(U, X) + ["s_branch lh_walk_tail"])
         # cherry table into accumulator: a = table * (P a)
         add(["; cherry table into accumulator", "lh_walk_ctab:"] + self.p_load() + self.table_entry(U) + ["s_waitcnt lgkmcnt(0)"] + ROTATE +
             weave(mv, P_ADV + PREFETCH, 4) + ["s_waitcnt vmcnt(0)"] + self.product(U, X) + self.states(70, 71) + ["s_branch lh_walk_tail"])
@@ -275,38 +254,39 @@ class Gen:
              "lh_walk_end:", "s_waitcnt vmcnt(0) lgkmcnt(0)"])
         add(["scratch_store_dwordx4 %%[out], v[%d:%d], off offset:%d" % (A + 4 * i, A + 4 * i + 3, 16 * i) for i in range(2 * S)])
         add(["scratch_store_dword %%[out], v%d, off offset:%d" % (r.scal + i, 32 * S + 4 * i) for i in range((S + 1) // 2)])
-        if self.seg:
-            add(["scratch_store_dwordx4 %%[out], v[%d:%d], off offset:%d" % (ST0 + 4 * i, ST0 + 4 * i + 3, off_st0 + 16 * i) for i in range(2 * S)])
-            add(["v_mov_b32_e32 v%d, s77" % r.tmp, "scratch_store_dword %%[out], v%d, off offset:%d" % (r.tmp, off_pm)])
         add(["s_waitcnt vmcnt(0)"])
         return L
+
+
+def render(S=2):
+    """(text of lh_prune_walk_asm_s<S>.inc, text of lh_prune_walk_clobbers_s<S>.inc, summary line)"""
+    g = Gen(S)
+    lines = g.generate()
+    body = ["// GENERATED by tools/gen_walk_asm.py (register map and rationale there) -- do not edit by hand.\n",
+            "// gfx950 assembly of K1's schedule walk, %d sites per lane, alignments without N: the body of one asm statement.\n" % S,
+            "// Vector registers v5 .. v%d (lh_prune_walk_clobbers_s%d.inc lists them for the statement).\n" % (g.r.last, S)]
+    for ln in lines:
+        ln = ln.replace("%%", "%")
+        ln = re.sub(r"(lh_walk_\w+)", r"\1_%=", ln)   # one copy of the labels per instantiation of the statement
+        body.append('"%s\\n"\n' % ln)
+    clob = ["// GENERATED by tools/gen_walk_asm.py: registers the %d-site walk statement clobbers.\n" % S]
+    regs = ['"v%d"' % i for i in range(5, g.r.last + 1)] + ['"s%d"' % i for i in range(36, 100)]
+    for i in range(0, len(regs), 16):
+        clob.append(", ".join(regs[i:i + 16]) + (",\n" if i + 16 < len(regs) else "\n"))
+    n_v = sum(1 for l in lines if l.startswith("v_"))
+    return "".join(body), "".join(clob), "%d lines (%d vector instructions in the text), v5..v%d" % (len(lines), n_v, g.r.last)
 
 
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outdir = os.environ.get("LH_ASM_OUT") or os.path.join(root, "linearham_amd", "csrc")
-    for S, gtips, seg in ((2, False, False), (4, False, False), (2, True, False), (2, False, True)):
-        g = Gen(S, gtips, seg)
-        lines = g.generate()
-        out = os.path.join(outdir, "lh_prune_walk_asm_s%d%s.inc" % (S, "g" if gtips else "seg" if seg else ""))
-        with open(out, "w") as f:
-            f.write("// GENERATED by tools/gen_walk_asm.py (register map and rationale there) -- do not edit by hand.\n")
-            f.write("// gfx950 assembly of K1's schedule walk, %d sites per lane, alignments without N%s: the body of one asm statement.\n" %
-                    (S, ", tip columns from the scratch region" if gtips else ", one schedule segment per statement" if seg else ""))
-            f.write("// Vector registers v5 .. v%d (lh_prune_walk_clobbers_s%d.inc lists them for the statement).\n" % (g.r.last, S))
-            for ln in lines:
-                ln = ln.replace("%%", "%")
-                ln = re.sub(r"(lh_walk_\w+)", r"\1_%=", ln)   # one copy of the labels per instantiation of the statement
-                f.write('"%s\\n"\n' % ln)
-        if gtips or seg:
-            continue   # (same registers as the LDS form)
-        with open(os.path.join(outdir, "lh_prune_walk_clobbers_s%d.inc" % S), "w") as f:
-            f.write("// GENERATED by tools/gen_walk_asm.py: registers the %d-site walk statement clobbers.\n" % S)
-            regs = ['"v%d"' % i for i in range(5, g.r.last + 1)] + ['"s%d"' % i for i in range(36, 100)]
-            for i in range(0, len(regs), 16):
-                f.write(", ".join(regs[i:i + 16]) + (",\n" if i + 16 < len(regs) else "\n"))
-        n_v = sum(1 for l in lines if l.startswith("v_"))
-        print("wrote %s: %d lines (%d vector instructions in the text), v5..v%d" % (out, len(lines), n_v, g.r.last))
+    body, clob, summary = render(2)
+    out = os.path.join(outdir, "lh_prune_walk_asm_s2.inc")
+    with open(out, "w") as f:
+        f.write(body)
+    with open(os.path.join(outdir, "lh_prune_walk_clobbers_s2.inc"), "w") as f:
+        f.write(clob)
+    print("wrote %s: %s" % (out, summary))
 
 
 if __name__ == "__main__":

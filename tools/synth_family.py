@@ -29,7 +29,15 @@ class Spec:
 
     def __init__(self, n_leaves=100, n_sites=400, n_v=200, n_d=30, n_j=12, len_v=296, len_d=(11, 37),
                  len_j=(48, 63), v_l_width=3, v_r_width=10, n_samples=256, n_nni=4, seed=20261004,
-                 v_ancestors=7, d_ancestors=4, j_ancestors=3, divergence=0.05, locus="igh", brlen_mean=0.01):
+                 v_ancestors=7, d_ancestors=4, j_ancestors=3, divergence=0.05, locus="igh", brlen_mean=0.01,
+                 ragged=0, ambiguous=0.0, tree_shape="stepwise", shm_indels=0):
+        # ragged: reads of unequal extent -- every sequence gets its first a and last b sites replaced by N, a and b
+        #   uniform in [0, ragged] (partis pads such reads with N: src/HMM.cpp:69-83 takes them as they come and libpll
+        #   encodes N as 1111, src/PhyloHMM.cpp:368-370); ambiguous: fraction of the remaining cells set to N.
+        # tree_shape: "stepwise" (uniform stepwise addition: ladder-like, schedule stack depth 3-4), "balanced" (a
+        #   perfectly balanced tree over the leaves with naive on a branch of its own: stack depth ~log2(n_leaves)).
+        # shm_indels: the first k sequences are flagged has_shm_indels -- their aligned form goes to indel_reversed_seqs and
+        #   input_seqs holds the read as sequenced (one base missing: not alignable as it stands), src/HMM.cpp:74-79.
         self.__dict__.update(locals())
         del self.__dict__["self"]
         v_r = (len_v - v_r_width, len_v)
@@ -214,6 +222,32 @@ def random_unrooted_tree(n_tips, rng, brlen_mean=0.01):
     return edges
 
 
+def balanced_unrooted_tree(n_tips, rng, brlen_mean=0.01):
+    """Tip 0 (naive) and two perfectly balanced subtrees over tips 1..n-1 around one inner node: the shape whose
+    post-order schedule needs the deepest stack for its size (~log2 n pending siblings).  Same edge dict as above."""
+    edges, nxt = {}, [n_tips]
+
+    def build(tips):
+        if len(tips) == 1:
+            return tips[0]
+        node = nxt[0]
+        nxt[0] += 1
+        h = len(tips) // 2
+        for kid in (build(tips[:h]), build(tips[h:])):
+            edges[len(edges)] = [kid, node, 0.0]
+        return node
+
+    rest = list(range(1, n_tips))
+    centre = nxt[0]
+    nxt[0] += 1
+    h = len(rest) // 2
+    for kid in (0, build(rest[:h]), build(rest[h:])):
+        edges[len(edges)] = [kid, centre, 0.0]
+    for e in edges.values():
+        e[2] = max(float(rng.exponential(brlen_mean)), 1e-6)
+    return edges
+
+
 def _adjacency(edges):
     adj = {}
     for a, b, l in edges.values():
@@ -336,13 +370,28 @@ def generate(spec, outdir):
     T = spec.n_leaves + 1
     labels = ["naive"] + ["s%d" % i for i in range(spec.n_leaves)]
     tree_rng = np.random.default_rng(spec.seed)
-    edges = random_unrooted_tree(T, tree_rng, spec.brlen_mean)
+    if spec.tree_shape == "balanced":
+        edges = balanced_unrooted_tree(T, tree_rng, spec.brlen_mean)
+    else:
+        edges = random_unrooted_tree(T, tree_rng, spec.brlen_mean)
     er0 = rng_s.dirichlet(np.ones(6))
     pi0 = rng_s.dirichlet(np.ones(4) * 5)
     cat_rates = np.array([0.136954, 0.476752, 1.0, 2.386294])
     site_rates = cat_rates[rng_s.integers(0, 4, size=L)]
     seqs = evolve(edges, T, 0, naive, er0, pi0, site_rates, rng_s)
     to_str = lambda a: "".join("N" if x < 0 else BASES[x] for x in a)
+    if spec.ragged or spec.ambiguous:
+        # N inside alignment columns (the leaves only; naive_seq stays as the rearrangement made it)
+        mrng = np.random.default_rng(spec.seed + 4)
+        L_used = int(np.max(np.where(naive >= 0)[0])) + 1   # sites behind it are all-N padding already
+        for i in range(1, T):
+            s_i = seqs[i] = seqs[i].copy()
+            if spec.ragged:
+                a, b = (int(x) for x in mrng.integers(0, spec.ragged + 1, size=2))
+                s_i[:a] = -1
+                s_i[max(L_used - b, 0):L_used] = -1
+            if spec.ambiguous:
+                s_i[mrng.random(L) < spec.ambiguous] = -1
     # relpos per allele, consistent with the constraints of SURVEY.md 8.1
     relpos = {}
     for name, seq, rp_ in genes["V"]:
@@ -354,12 +403,15 @@ def generate(spec, outdir):
     for name, seq, rp_ in genes["J"]:
         relpos[name] = rp_
         assert rp_ <= fb["j_l"][1]
+    aligned = [to_str(seqs[i]) for i in range(1, T)]
+    n_ind = min(int(spec.shm_indels), spec.n_leaves)
     cluster = {
         "germline-info": {"locus": spec.locus},
         "events": [{
-            "input_seqs": [to_str(seqs[i]) for i in range(1, T)],
+            "input_seqs": [a[:L // 2] + a[L // 2 + 1:] if i < n_ind else a for i, a in enumerate(aligned)],
+            "indel_reversed_seqs": [a if i < n_ind else "" for i, a in enumerate(aligned)],
             "naive_seq": to_str(naive),
-            "has_shm_indels": [False] * spec.n_leaves,
+            "has_shm_indels": [i < n_ind for i in range(spec.n_leaves)],
             "linearham-info": {"relpos": relpos, "flexbounds": {k: list(v) for k, v in fb.items()}},
             "unique_ids": labels[1:],
         }],
