@@ -40,6 +40,8 @@ WORKLOADS = {
     "config4": "BASELINE.json configs[4] shape: synthetic 500-leaf random tree, 600-site MSA, full V/D/J "
                "germline set, R=4 rate categories (not the headline workload)",
     "small": "small synthetic family (development only, not the headline workload)",
+    "config2_ragged": "the configs[2] family with ragged reads: every sequence N-padded by 0-30 sites at either end, i.e. N "
+                      "inside alignment columns (not the headline workload; its rate is the extra key mixed_n_evals_per_s)",
 }
 PMC_PROFILE = {"config2": "r03_bench_pmc_per_launch.json", "config4": "r03_config4_pmc_per_launch.json"}
 GEN_VERSION = 2                # bump when tools/synth_family.py changes what it writes
@@ -58,6 +60,8 @@ def preset_spec(preset, batch):
         return sf.Spec(n_samples=max(batch, 256), brlen_mean=BRLEN_MEAN)
     if preset == "config2":     # the batch is drawn from >= batch distinct tree samples
         return sf.Spec(n_samples=max(batch, 256))
+    if preset == "config2_ragged":   # (2048 distinct tree samples, cycled through the batch)
+        return sf.Spec(n_samples=2048, ragged=30)
     if preset == "config3":
         return sf.Spec(n_samples=10000)
     if preset == "config4":
@@ -270,8 +274,65 @@ def extra_rates(args, lib, fam_handle, hmm, d, T, depth, R, n, dev, stream, fam_
                 if int((anc_ref != a[i]).sum()):
                     raise SystemExit("parity failure: ancestral-sequence draws differ from oracle/asr_oracle.py")
             res["asr_samples_checked"] = 2
-    except RuntimeError as e:      # (a tree too large for K3's LDS tables: the step does not exist for this shape)
+    except RuntimeError as e:
+        # a tree too large for K3's LDS tables: the step does not exist for this shape; anything else is a failure of
+        # the product path and must not vanish from the line
+        if "too large for the sampling kernel" not in str(e) and "too many tips" not in str(e):
+            raise
         res["asr_note"] = "not run: %s" % e
+    # ---- the same workload with N inside alignment columns (ragged reads) ----
+    if args.preset == "config2" and not args.no_mixed_n:
+        res.update(mixed_n_rate(args, lib, T, R, n, dev, stream))
+    return res
+
+
+def mixed_n_rate(args, lib, T, R, n, dev, stream):
+    """mixed_n_evals_per_s: K0-K2 on the configs[2] family with RAGGED READS (every sequence N-padded by 0-30 sites at
+    either end: N inside alignment columns, libpll's 1111 tips -- src/HMM.cpp:69-83, src/PhyloHMM.cpp:368-370), inputs
+    resident, measured OUTSIDE the `value` region.  Such alignments run K1's N-aware instantiation (row sums of a tip's
+    matrix formed on the spot; no assembly walk); two rows are checked against the dense C oracle."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from linearham_amd import host
+    fam_dir, spec = prepare_family("config2_ragged", n, may_generate=True)
+    hmm = host.PhyloHMM(os.path.join(fam_dir, "cluster.yaml"), 0, os.path.join(fam_dir, "hmm_params"), 0)
+    flat = hmm.flatten_tsv(os.path.join(fam_dir, "trees.tsv"), n)
+    assert flat["n_tips"] == T
+    d = {k: torch.from_numpy(np.ascontiguousarray(flat[k][:n])).to(dev) for k in ("ops", "brlen", "er", "pi", "alpha")}
+    ll = torch.zeros(n, dtype=torch.float64, device=dev)
+    fam = C.c_void_p(flat["family"])
+
+    def step():
+        lib.check(lib.lib.lh_eval_batch_device(fam, n, T, flat["max_depth"], d["ops"].data_ptr(), d["brlen"].data_ptr(),
+                                               d["er"].data_ptr(), d["pi"].data_ptr(), d["alpha"].data_ptr(), R,
+                                               ll.data_ptr(), None, C.c_void_p(stream)))
+    step()
+    torch.cuda.synchronize()
+    lib.check(lib.lib.lh_profile_enable(fam, 1))
+    k = max(1, min(args.steps, 5))
+    t = time.perf_counter()
+    for _ in range(k):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    ms = [C.c_double() for _ in range(3)]
+    groups = C.c_int64()
+    lib.check(lib.lib.lh_profile_read(fam, C.byref(ms[0]), C.byref(ms[1]), C.byref(ms[2]), C.byref(groups)))
+    lib.check(lib.lib.lh_profile_enable(fam, 0))
+    n_pat = C.c_int32()
+    lib.check(lib.lib.lh_family_info(fam, C.byref(n_pat), None))
+    res = {"mixed_n_evals_per_s": n * k / dt,
+           "mixed_n_note": "configs[2] with ragged reads (N inside alignment columns; tools/synth_family.py ragged=30), %d tree "
+                           "samples per step (%d distinct), %d site patterns; K1 form %s, K1 %.3f ms per step; outside `value`"
+                           % (n, flat["n_rows"], n_pat.value, lib.lib.lh_family_prune_form(fam).decode(), ms[1].value / k)}
+    if not args.no_check:
+        got = ll[:2].cpu().numpy()
+        ref, _ = cpu_oracle(fam_dir, [0, 1])
+        rel = max(abs(got[i] - ref[i]) / abs(ref[i]) for i in (0, 1))
+        res["mixed_n_delta_logl_vs_cpu_max_rel"] = rel
+        if not (rel <= 1e-6):
+            raise SystemExit("parity failure on the ragged-read family against the CPU oracle: max rel %.3e" % rel)
     return res
 
 
@@ -296,6 +357,8 @@ def parse_args():
                     help="evaluations of the CPU baseline sample (also the rows the parity check covers)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys measured outside the `value` region (pipeline_rows_per_s, asr_tree_samples_per_s)")
+    ap.add_argument("--no-mixed-n", action="store_true",
+                    help="skip the extra key mixed_n_evals_per_s (the configs[2] family with ragged reads, outside `value`)")
     ap.add_argument("--timeout-s", type=float, default=1500.0,
                     help="--gpus N without a launcher: stop the rank processes after this many seconds (exit status 124)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -305,7 +368,7 @@ def parse_args():
     global BRLEN_MEAN
     BRLEN_MEAN = args.brlen_mean
     if args.batch is None:
-        args.batch = {"config2": DEFAULT_BATCH, "config3": 0, "config4": 6144, "small": 64}[args.preset]
+        args.batch = {"config2": DEFAULT_BATCH, "config2_ragged": DEFAULT_BATCH, "config3": 0, "config4": 6144, "small": 64}[args.preset]
     return args
 
 
@@ -464,7 +527,7 @@ def worker(args, rank, local_rank, world):
         # their own rocprofv3 runs; gfx950 correction: FETCH_SIZE counts wide coalesced reads at half).
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", PMC_PROFILE.get(args.preset, "-"))
-        if world == 1 and per_launch == args.batch and os.path.exists(pmc_file):
+        if world == 1 and per_launch == args.batch and os.path.exists(pmc_file) and BRLEN_MEAN is None:
             with open(pmc_file) as f:
                 pmc = json.load(f)
             if pmc.get("_evals_per_launch", per_launch) == per_launch:
@@ -497,7 +560,7 @@ def worker(args, rank, local_rank, world):
                                             "same command (2 x FETCH_SIZE + WRITE_SIZE); counters cannot be collected inside "
                                             "this run, so this one figure is NOT measured by it" % PMC_PROFILE.get(args.preset))
                          if traffic else None,
-                         "hbm_measured_gbs": (traffic / (prune_ms * 1e-3) / 1e9) if traffic else None,
+                         "hbm_gbs_from_profile": (traffic / (prune_ms * 1e-3) / 1e9) if traffic else None,
                          "flop_per_launch": k1_flops, "evals_per_launch": per_launch, "avg_launch_ms": prune_ms,
                          "peak_source": "half the 157.3 TFLOP/s FP32 vector peak of MI355X_MICROARCH.md (FP64 FMAs "
                                         "issue at half rate; the guide lists no FP64 figure)",

@@ -34,6 +34,15 @@ def specs():
     }
 
 
+# Bounds other than compare()'s 1e-8 on emissions / forward entries.  mixed_500, first tree sample: the reference
+# algorithm itself is conditioned no better -- its two CPU restatements (numpy and C, same operations, another summation
+# order) differ there by 6.4e-9 on emissions and 3.5e-8 on the V germline forward vector (products of ~290 emissions; a
+# 501-tip tree with N tips leaves some columns to a handful of 1e-6 branches, whose off-diagonal P entries carry 1e-9
+# relative rounding); the second sample agrees to 1e-10.  Measured here: 4.8e-9 / 2.1e-8.  Log-likelihood 1e-10 and exact
+# ScaleMatrix counts hold as everywhere.
+TOLERANCE = {"mixed_500": dict(em_rtol=2e-8, fwd_rtol=1e-7)}
+
+
 def main(argv):
     import numpy as np
     from oracle import linearham_oracle as orc
@@ -65,7 +74,23 @@ def main(argv):
             else:
                 desc, ll, res, ref = tp.run_family(hip, h, rows, 4)
                 assert all(np.isfinite(r["loglik"]) for r in ref), "the family should evaluate finitely in the reference"
-                tp.compare(h, desc, ll, res, ref)
+                if "--report" in argv:   # development: the largest deviations instead of the assertions
+                    dev = {"loglik": 0.0, "emission": 0.0}
+                    for i, r in enumerate(ref):
+                        dev["loglik"] = max(dev["loglik"], abs(ll[i] - r["loglik"]) / abs(r["loglik"]))
+                        e = np.abs(res["xmsa_emission"][i] - r["xmsa_emission"]) / np.abs(r["xmsa_emission"])
+                        dev["emission"] = max(dev["emission"], float(np.nanmax(e)))
+                        ex = tp.expand_forward(h, desc, res["forward"][i], res["scaler_counts"][i])
+                        for k in ex:
+                            if k.endswith("_forward"):
+                                a_, b_ = np.asarray(ex[k], float), np.asarray(r[k], float)
+                                m = b_ != 0
+                                dev[k] = max(dev.get(k, 0.0), float(np.max(np.abs(a_[m] - b_[m]) / np.abs(b_[m]))) if m.any() else 0.0)
+                            else:
+                                dev[k] = dev.get(k, True) and bool(np.array_equal(np.asarray(ex[k]), np.asarray(r[k])))
+                    info["deviation"] = dev
+                else:
+                    tp.compare(h, desc, ll, res, ref, **TOLERANCE.get(name, {}))
                 info.update(tp.LAST_RUN, loglik=[float(x) for x in ll])
             report[name] = info
         finally:

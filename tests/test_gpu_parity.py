@@ -115,19 +115,19 @@ def run_family(hip, h, samples, num_rates, extended=False):
     return desc, ll, res, ref
 
 
-def compare(h, desc, ll, res, ref, rtol=1e-10):
+def compare(h, desc, ll, res, ref, rtol=1e-10, em_rtol=1e-8, fwd_rtol=1e-8):
     # Emissions and forward entries: 1e-8.  An emission dominated by off-diagonal P entries of a 1e-6
     # branch (~1e-8 each, formed as 1 + U expm1 U^-1 with ~1e-17 absolute rounding) is only that well
     # conditioned; a 60-seed sweep of random families stayed below 1.2e-9.
     for i, r in enumerate(ref):
         assert abs(ll[i] - r["loglik"]) <= rtol * abs(r["loglik"]), (i, ll[i], r["loglik"])
         np.testing.assert_allclose(res["rates"][i], r["rates"], rtol=1e-9)
-        np.testing.assert_allclose(res["xmsa_emission"][i], r["xmsa_emission"], rtol=1e-8)
+        np.testing.assert_allclose(res["xmsa_emission"][i], r["xmsa_emission"], rtol=em_rtol)
         ex = expand_forward(h, desc, res["forward"][i], res["scaler_counts"][i])
         for k in [k for k in ex if "scaler" in k]:
             assert ex[k] == r[k], (i, k, ex[k], r[k])
         for k in [k for k in ex if k.endswith("_forward")]:
-            np.testing.assert_allclose(ex[k], r[k], rtol=1e-8, atol=0, err_msg="%d %s" % (i, k))
+            np.testing.assert_allclose(ex[k], r[k], rtol=fwd_rtol, atol=0, err_msg="%d %s" % (i, k))
 
 
 @pytest.mark.parametrize("case,params,R", TOY)

@@ -26,10 +26,14 @@ def test_c_oracle_on_reference_fixtures(goldens, data_dir, case, params, R):
     assert catch_approx(got[0], goldens["PhyloHMM:" + case]["vars"]["loglikelihood"])
 
 
-def test_c_oracle_on_synthetic_family(tmp_path):
+@pytest.mark.parametrize("kw", [dict(n_leaves=40, n_samples=4, seed=11),
+                                dict(n_leaves=20, n_samples=3, seed=42, ragged=6, ambiguous=0.02),    # N inside columns
+                                dict(n_leaves=64, n_samples=2, seed=47, tree_shape="balanced", n_nni=0)],
+                         ids=["medium", "mixed_n", "balanced"])
+def test_c_oracle_on_synthetic_family(tmp_path, kw):
     from tools import synth_family as sf
     out = str(tmp_path / "fam")
-    sf.generate(sf.Spec.small(n_leaves=40, n_samples=4, seed=11), out)
+    sf.generate(sf.Spec.small(**kw), out)
     h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
     fam = oracle_c.COracleFamily(h, 4)
     rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
