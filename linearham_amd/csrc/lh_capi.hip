@@ -610,6 +610,20 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
       h.n_ucol = (int32_t)u_pat.size();
       pat_of_site_all = pat_of_site;
       rc = rc || upload(f, pmsa.data(), pmsa.size(), &h.msa);
+      h.msa_planes = nullptr;
+      if (!h.msa_mixed_n && h.n_prune > 0) {  // (every state is 0..3: two bits)
+        const size_t np = h.n_prune, nb = (np + 127) / 128;
+        std::vector<uint64_t> planes(N * nb * 4, 0);
+        for (size_t i = 0; i < N; ++i)
+          for (size_t b = 0; b < nb; ++b)
+            for (size_t s2 = 0; s2 < 2; ++s2)
+              for (size_t l = 0; l < 64; ++l) {
+                const uint8_t st = pmsa[i * np + std::min(128 * b + 64 * s2 + l, np - 1)];
+                planes[(i * nb + b) * 4 + 2 * s2] |= (uint64_t)(st & 1) << l;
+                planes[(i * nb + b) * 4 + 2 * s2 + 1] |= (uint64_t)((st >> 1) & 1) << l;
+              }
+        rc = rc || upload(f, planes.data(), planes.size(), &h.msa_planes);
+      }
       rc = rc || upload(f, pat_of_site.data(), pat_of_site.size(), &h.site_pat);
       rc = rc || upload(f, u_pat.data(), u_pat.size(), &h.u_pat);
       rc = rc || upload(f, u_base.data(), u_base.size(), &h.u_base);
@@ -624,6 +638,7 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
     h.n_ucol = (int32_t)C;
     f->n_ucol_used = (int32_t)C;
     rc = rc || upload<uint8_t>(f, nullptr, 0, &h.msa);
+    h.msa_planes = nullptr;
     rc = rc || upload<int32_t>(f, nullptr, 0, &h.site_pat);
     rc = rc || upload<int32_t>(f, nullptr, 0, &h.u_pat);
     rc = rc || upload<uint8_t>(f, nullptr, 0, &h.u_base);

@@ -43,13 +43,16 @@ def _expect(report, family, pattern, **conds):
 # kernel<depth, N-aware>                     register-stack form: w6 / w5 / w4 (all rates in one workgroup), seg4 / seg5
 # kernel<depth, N-aware, fused, assembly>    cherry-table form: ct6 / ct5 / ct4
 def test_default_forms_without_n():
-    rep = _run({}, ["small_igh", "mid60x400", "balanced64", "wide100x600"])
+    rep = _run({}, ["small_igh", "mid60x400", "balanced64", "wide100x600", "wide100x600_r8"])
     _expect(rep, "small_igh", r"w[456]<[34],false>")                      # one one-site wave per rate, fused
     _expect(rep, "mid60x400", r"w[456]<[34],false>", n_patterns=("gt", 128))            # two-site waves, fused (configs[2]'s form)
     # a perfectly balanced 64-leaf tree: five pending siblings, i.e. slots beyond the register slot live in scratch memory
     _expect(rep, "balanced64", r"ct[456]<16,false,true,true>", max_depth=("ge", 5))
-    # more than 256 patterns: R x waves > 8, one workgroup per (sample, rate), the assembly walk over cherry tables
-    _expect(rep, "wide100x600", r"ct[456]<4,false,false,true>", n_patterns=("gt", 256))
+    # more than 256 patterns: three two-site waves per rate, all four rates in one workgroup of twelve waves
+    _expect(rep, "wide100x600", r"w[456]<[34],false>", n_patterns=("gt", 256))
+    # the same family with eight rate categories: 24 waves do not fit one workgroup -- a workgroup per (sample, rate), the
+    # assembly walk over cherry tables, K2a mixing the rates
+    _expect(rep, "wide100x600_r8", r"ct[456]<4,false,false,true>", n_patterns=("gt", 256))
 
 
 def test_default_forms_with_n_inside_columns():
@@ -62,7 +65,7 @@ def test_default_forms_with_n_inside_columns():
     _expect(rep, "mixed_small", r"w[456]<[34],true>")
     _expect(rep, "mixed_igk", r"w[456]<[34],true>")
     _expect(rep, "mixed_120", r"seg4<4,true>")                                            # 121 tips: segmented tip table
-    _expect(rep, "mixed_60x400", r"(w[456]<[34],true>|ct[456]<4,true,(true|false),false>)")
+    _expect(rep, "mixed_60x400", r"w[456]<[34],true>", n_patterns=("gt", 256))          # twelve waves per workgroup
     _expect(rep, "mixed_balanced64", r"ct[456]<16,true,true,false>", max_depth=("ge", 5))
     _expect(rep, "mixed_500", r"seg4<4,true>")                                            # 11 segments
 
@@ -74,7 +77,7 @@ def test_default_forms_with_n_inside_columns():
     # its C++ walk instead of the assembly one
     ({"LH_K1_TABLES": "1", "LH_K1_CXX_WALK": "1"}, {"small_igh": r"ct[456]<4,false,true,false>",
                                                    "mid60x400": r"ct[456]<4,false,true,false>",
-                                                   "wide100x600": r"ct[456]<4,false,false,false>"}),
+                                                   "wide100x600_r8": r"ct[456]<4,false,false,false>"}),
     # the same kernels walking the schedule without tables (every cherry its own op)
     ({"LH_K1_NO_TABLES": "1"}, {"small_igh": r"ct[456]<4,false,true,true>", "mid60x400": r"ct[456]<4,false,true,true>",
                                 "mixed_small": r"ct[456]<4,true,true,false>"}),

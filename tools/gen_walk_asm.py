@@ -10,27 +10,40 @@ after editing:    python tools/gen_walk_asm.py
 Why assembly: the compiler's loop carried ~145 instructions per op (copies at joins, flag juggling, spills) where
 ~85 are needed, and with four sites per lane it spilled 50 registers; here every register is placed by hand.
 
-Register map inside the statement, S sites per lane (clobbers v5 .. v<tmp+S-1> and s36-s99):
-  usite  S regs from v5        clamped site numbers of the lane's sites (64 apart)
+Register map inside the statement, S sites per lane (clobbers v5 .. v<tmp+S-1>, s8-s31 and s36-s99):
+  (v5 .. v5+S-1 unused since round 4: the lanes' site numbers, which addressed the MSA bytes; the map below is unchanged)
   scal   (S+1)/2 regs          scaler counts, two sites per register (16 bits each)
   a      8S regs (even base)   running CLV: site s in 8 consecutive registers (four doubles)
   st0    8S                    pending sibling of stack slot 0 (already multiplied by its branch matrix)
   x      8S                    P a, or a tip column
   u      8S                    tip column / table entry / deep-slot sibling
-  sa sb sc  S each             tip states            tmp  S   temporaries (addresses, per-site maxima)
+  t2 t3     S each             temporaries of the state -> address arithmetic;  c128 c256  the constants 128, 256
+  tmp  S                       temporaries (addresses, per-site maxima)
+  s[8:15] s[16:23] s[24:31]    tip states of the op's tips A, B, C as BIT PLANES: per tip the wave's 128 sites take 32 bytes of
+                               the family's 2-bit MSA (lh_family_create: planes[tip][block of 128 sites][site set s][bit]),
+                               one s_load_dwordx8 per tip and op; lane l's state of site set s is bit l of the two 64-bit
+                               masks s[.. + 4 s : .. + 4 s + 1] (bit 0) and s[.. + 4 s + 2 : .. + 4 s + 3] (bit 1)
   s[36:67] P (row-major)      s[68:69] this op's descriptor      s[70:71] the next op's      s[72:73] the one after (in flight)
   s[74:75] scratch region (P-matrices at 0, tables at ctoff)   s76 next table offset   s77 next matrix offset
-  s[78:79] msa - L   s80 L   s81 LDS address of the tip table   s82 op counter   s83 op count   s[84:85] descriptors
+  s[78:79] state planes of the wave's block, tip 0   s80 bytes per tip   s81 LDS address of the tip table   s82 op counter   s83 op count   s[84:85] descriptors
   s86 offset of the descriptor to prefetch   s98 offset of the last descriptor   s87..s93, s99 temporaries
   s[94:95] exec save   s96 0x2ff00000 (high word of 2^-256)   s97 256
-S = 2: usite v5-6, scal v7, a v[8:23], st0 v[24:39], x v[40:55], u v[56:71], states v72-77, tmp v78-79 (80 registers: six
-waves per SIMD).
+S = 2: v5-6 unused, scal v7, a v[8:23], st0 v[24:39], x v[40:55], u v[56:71], t2 v72-73, t3 v74-75, c128 v76, c256 v77,
+tmp v78-79 (80 registers: six waves per SIMD).
+Round 4: the tip states come through the SCALAR memory path.  Round 3's walk fetched them with one global_load_ubyte per
+site and tip child; with them replaced by arithmetic the walk ran 12.5 % faster although it issued 9 % more vector
+instructions (profiles/r03_k1_state_loads.txt): the byte loads' issue through the CU's one vector-memory address unit,
+not their latency, was the cost.  An alignment without N needs 2 bits per state, the wave's sites are 128 consecutive
+patterns, and the tip is wave-uniform: 32 bytes per tip and op, fetched into SGPRs, from which a lane takes its bits with
+v_cndmask (the mask operand IS the 64-bit plane).  The only vector-memory instructions left in the walk are the cherry-table
+gathers and the rare deep stack slot.
 """
 import os
 import re
 
 OPTS = set(os.environ.get("LH_ASM_OPTS", "").split(","))   # timing experiments (variants are built into lib_exp/, never the product)
 P = 36
+SA, SB, SC = 8, 16, 24       # first SGPR of the state planes of the op's tips A, B, C (eight registers each; s32 is the stack pointer)
 
 
 class Regs:
@@ -45,10 +58,11 @@ class Regs:
         self.ST0 = self.A + 8 * S
         self.X = self.ST0 + 8 * S
         self.U = self.X + 8 * S
-        self.sa = self.U + 8 * S
-        self.sb = self.sa + S
-        self.sc = self.sb + S
-        self.tmp = self.sc + S
+        self.t2 = self.U + 8 * S
+        self.t3 = self.t2 + S
+        self.c128 = self.t3 + S
+        self.c256 = self.c128 + 1
+        self.tmp = self.c128 + S
         self.last = self.tmp + S - 1
 
 
@@ -109,10 +123,20 @@ class Gen:
                     "s_load_dwordx16 s[52:67], s[74:75], s92 offset:0x40"]
         return ["s_load_dwordx16 s[36:51], s[74:75], s77 offset:0x0", "s_load_dwordx16 s[52:67], s[74:75], s77 offset:0x40"]
 
+    @staticmethod
+    def plane(st, s, bit):
+        """The 64-bit mask of bit `bit` of site set s in the state planes that start at SGPR `st`."""
+        return "s[%d:%d]" % (st + 4 * s + 2 * bit, st + 4 * s + 2 * bit + 1)
+
     def tip_column(self, dst, st, tip_expr):
-        """dst <- tip-table columns of the tip whose number `tip_expr` leaves in s87, for the states in v<st>.."""
+        """dst <- tip-table columns of the tip whose number `tip_expr` leaves in s87, for the states in the planes s<st>..:
+        LDS address = table + 128 tip + 32 state."""
+        r = self.r
         out = tip_expr + ["s_lshl_b32 s87, s87, 7", "s_add_i32 s87, s87, s81"]
-        out += ["v_lshl_add_u32 v%d, v%d, 5, s87" % (self.r.tmp + s, st + s) for s in range(self.S)]
+        for s in range(self.S):
+            out += ["v_cndmask_b32_e64 v%d, 0, 32, %s" % (r.tmp + s, self.plane(st, s, 0)),
+                    "v_cndmask_b32_e64 v%d, 0, 64, %s" % (r.t2 + s, self.plane(st, s, 1)),
+                    "v_add3_u32 v%d, v%d, v%d, s87" % (r.tmp + s, r.tmp + s, r.t2 + s)]
         for s in range(self.S):   # s81 = LDS address of the tip table
             out += ["ds_read_b128 v[%d:%d], v%d" % (dst + 8 * s, dst + 8 * s + 3, self.r.tmp + s),
                     "ds_read_b128 v[%d:%d], v%d offset:16" % (dst + 8 * s + 4, dst + 8 * s + 7, self.r.tmp + s)]
@@ -122,8 +146,14 @@ class Gen:
         """dst <- entry (sa, sb) of the next cherry table (global memory, written by this workgroup's prologue)."""
         toff = "%[ctoff]" if "tabhit" in OPTS else "s76"   # tabhit: every look-up in table 0 (results wrong)
         r = self.r
-        out = ["v_lshl_add_u32 v%d, v%d, 2, v%d" % (r.tmp + s, r.sa + s, r.sb + s) for s in range(self.S)]
-        out += ["v_lshl_add_u32 v%d, v%d, 5, %s" % (r.tmp + s, r.tmp + s, toff) for s in range(self.S)]
+        out = []
+        for s in range(self.S):   # byte offset = table + 128 state A + 32 state B
+            out += ["v_cndmask_b32_e64 v%d, 0, 32, %s" % (r.tmp + s, self.plane(SB, s, 0)),
+                    "v_cndmask_b32_e64 v%d, 0, 64, %s" % (r.t2 + s, self.plane(SB, s, 1)),
+                    "v_add3_u32 v%d, v%d, v%d, %s" % (r.tmp + s, r.tmp + s, r.t2 + s, toff),
+                    "v_cndmask_b32_e64 v%d, 0, v%d, %s" % (r.t2 + s, r.c128, self.plane(SA, s, 0)),
+                    "v_cndmask_b32_e64 v%d, 0, v%d, %s" % (r.t3 + s, r.c256, self.plane(SA, s, 1)),
+                    "v_add3_u32 v%d, v%d, v%d, v%d" % (r.tmp + s, r.tmp + s, r.t2 + s, r.t3 + s)]
         pol = " nt" if "tabnt" in OPTS else " sc1" if "tabsc1" in OPTS else " sc0 sc1" if "tabsc" in OPTS else ""   # cache-policy experiments
         for s in range(self.S):
             out += ["global_load_dwordx4 v[%d:%d], v%d, s[74:75]%s" % (dst + 8 * s, dst + 8 * s + 3, r.tmp + s, pol),
@@ -131,26 +161,16 @@ class Gen:
         return out + ["s_add_i32 s76, s76, 0x200"]
 
     def states(self, dx, dy, split=False):
-        """Tip states of the op whose descriptor is s<dx>, s<dy>: tip A always, B and C on their flags."""
-        r, S = self.r, self.S
-        if "nostate" in OPTS:   # states from arithmetic, no memory (results wrong)
-            out = ["s_lshr_b32 s87, s%d, 16" % dx]
-            for s in range(S):
-                out += ["v_add_u32_e32 v%d, s87, v%d" % (r.sa + s, r.usite + s), "v_and_b32_e32 v%d, 3, v%d" % (r.sa + s, r.sa + s),
-                        "v_mov_b32_e32 v%d, v%d" % (r.sb + s, r.sa + s), "v_mov_b32_e32 v%d, v%d" % (r.sc + s, r.sa + s)]
-            return (out, []) if split else out
+        """Tip states of the op whose descriptor is s<dx>, s<dy>, as bit planes into s[8:31]: tip A always, B and C on
+        their flags.  Scalar loads: they are complete behind the s_waitcnt lgkmcnt(0) at the top of the next op."""
+        if "nostate" in OPTS:   # no state traffic at all (the planes keep what they hold; results wrong)
+            return ([], []) if split else []
 
-        def loads(dst):
-            o = ["s_mul_i32 s87, s87, s80"]
-            o += ["v_add_u32_e32 v%d, s87, v%d" % (r.tmp + s, r.usite + s) for s in range(S)]
-            o += ["global_load_ubyte v%d, v%d, s[78:79]" % (dst + s, r.tmp + s) for s in range(S)]
-            return o
-        part_a = ["s_lshr_b32 s87, s%d, 16" % dx] + loads(r.sa)
-        if "allstates" in OPTS:   # experiment: tips B and C always (K0c fills unused tip fields with tip 1), no branches
-            part_bc = ["s_and_b32 s87, s%d, 0xffff" % dy] + loads(r.sb) + ["s_lshr_b32 s87, s%d, 16" % dy] + loads(r.sc)
-            return (part_a, part_bc) if split else part_a + part_bc
-        part_bc = (["s_bitcmp1_b32 s%d, 13" % dx, "s_cbranch_scc0 1f", "s_and_b32 s87, s%d, 0xffff" % dy] + loads(r.sb) +
-                   ["1:", "s_bitcmp1_b32 s%d, 14" % dx, "s_cbranch_scc0 2f", "s_lshr_b32 s87, s%d, 16" % dy] + loads(r.sc) + ["2:"])
+        def load(dst):
+            return ["s_mul_i32 s87, s87, s80", "s_load_dwordx8 s[%d:%d], s[78:79], s87" % (dst, dst + 7)]
+        part_a = ["s_lshr_b32 s87, s%d, 16" % dx] + load(SA)
+        part_bc = (["s_bitcmp1_b32 s%d, 13" % dx, "s_cbranch_scc0 1f", "s_and_b32 s87, s%d, 0xffff" % dy] + load(SB) +
+                   ["1:", "s_bitcmp1_b32 s%d, 14" % dx, "s_cbranch_scc0 2f", "s_lshr_b32 s87, s%d, 16" % dy] + load(SC) + ["2:"])
         if split:
             return part_a, part_bc
         return part_a + part_bc
@@ -169,7 +189,7 @@ class Gen:
         return self.p_load() + ["s_waitcnt lgkmcnt(0)"] + ROTATE + P_ADV + [
             "s_cmp_eq_u32 s88, 1", "s_cbranch_scc0 %s_deep" % label] + self.matvec(self.r.ST0) + ["s_branch %s_pushed" % label,
             "%s_deep:" % label] + self.matvec(self.r.X) + ["s_add_i32 s89, s88, -2"] + self.deep_addr("s89") + \
-            self.block_io("scratch_store_dwordx4", self.r.X) + ["%s_pushed:" % label]
+            self.block_io("scratch_store_dwordx4", self.r.X) + ["s_waitcnt vmcnt(0)", "%s_pushed:" % label]
 
     def generate(self):
         r, S = self.r, self.S
@@ -179,13 +199,10 @@ class Gen:
         add = L.extend
         add(["; ---- set-up -------------------------------------------------------------------------------------------",
              "s_mov_b32 s83, %[nw]", "s_mov_b64 s[84:85], %[wops]", "s_mov_b64 s[74:75], %[pm]", "s_mov_b32 s76, %[ctoff]",
-             "s_mov_b32 s77, 0", "s_mov_b64 s[78:79], %[msa]", "s_mov_b32 s80, %[L]", "s_mov_b32 s81, %[tip]",
-             "s_mov_b32 s96, 0x2ff00000", "s_movk_i32 s97, 0x100",
-             "v_mbcnt_lo_u32_b32 v%d, -1, 0" % r.usite, "v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (r.usite, r.usite),
-             "v_add_u32_e32 v%d, %%[site0], v%d" % (r.usite, r.usite)])
-        add(["v_add_u32_e32 v%d, %d, v%d" % (r.usite + s, 64 * s, r.usite) for s in range(1, S)])
-        add(["v_min_u32_e32 v%d, %%[last], v%d" % (r.usite + s, r.usite + s) for s in range(S)])
+             "s_mov_b32 s77, 0", "s_mov_b64 s[78:79], %[planes]", "s_mov_b32 s80, %[pstride]", "s_mov_b32 s81, %[tip]",
+             "s_mov_b32 s96, 0x2ff00000", "s_movk_i32 s97, 0x100"])
         add(["v_mov_b32_e32 v%d, 0" % (r.scal + i) for i in range((S + 1) // 2)])
+        add(["v_mov_b32_e32 v%d, 0x80" % r.c128, "v_mov_b32_e32 v%d, 0x100" % r.c256])
         for i in range(4 * S):
             add(["v_mov_b32_e32 v%d, 0" % (A + 2 * i), "v_mov_b32_e32 v%d, 0x3ff00000" % (A + 2 * i + 1)])
         add(["s_cmp_lt_i32 s83, 1", "s_cbranch_scc1 lh_walk_end",
@@ -195,11 +212,11 @@ class Gen:
         add(self.states(68, 69))
         add(["s_mov_b32 s82, 0",
              "; ---- one op per iteration ---------------------------------------------------------------------------",
-             "lh_walk_top:", "s_waitcnt vmcnt(0)", "s_and_b32 s87, s68, 7",
+             "lh_walk_top:", "s_waitcnt lgkmcnt(0)", "s_and_b32 s87, s68, 7",
              "s_cmp_eq_u32 s87, 1", "s_cbranch_scc1 lh_walk_tip", "s_cmp_eq_u32 s87, 4", "s_cbranch_scc1 lh_walk_ctab",
              "s_cmp_eq_u32 s87, 2", "s_cbranch_scc1 lh_walk_pop", "s_cmp_eq_u32 s87, 3", "s_cbranch_scc1 lh_walk_ctip"])
         # cherry: a = tipcol_A * tipcol_B (the accumulator pushed first if the op says so)
-        cherry = self.tip_column(U, r.sa, tip_a) + self.tip_column(X, r.sb, tip_b)
+        cherry = self.tip_column(U, SA, tip_a) + self.tip_column(X, SB, tip_b)
         add(["; cherry", "s_bfe_u32 s88, s68, 0x50004", "s_cmp_eq_u32 s88, 0", "s_cbranch_scc1 lh_walk_cherry_np"])
         add(self.push_block("lh_walk_cherry"))
         tipwait = "s_waitcnt lgkmcnt(0)"
@@ -207,7 +224,7 @@ class Gen:
         add(["lh_walk_cherry_np:"] + cherry + [tipwait] + ROTATE + PREFETCH + self.product(U, X) + self.states(70, 71) +
             ["s_branch lh_walk_tail"])
         # cherry table x tip column
-        ctip = self.table_entry(U) + self.tip_column(X, r.sc, tip_c)
+        ctip = self.table_entry(U) + self.tip_column(X, SC, tip_c)
         add(["; cherry table x tip column", "lh_walk_ctip:", "s_bfe_u32 s88, s68, 0x50004", "s_cmp_eq_u32 s88, 0",
              "s_cbranch_scc1 lh_walk_ctip_np"])
         add(self.push_block("lh_walk_ctip"))
@@ -218,7 +235,7 @@ class Gen:
         st_a, st_bc = self.states(70, 71, split=True)
         mv = self.matvec(X)
         half = len(mv) // 2
-        add(["; tip into accumulator", "lh_walk_tip:"] + self.p_load() + self.tip_column(U, r.sa, tip_a) + ["s_waitcnt lgkmcnt(0)"] +
+        add(["; tip into accumulator", "lh_walk_tip:"] + self.p_load() + self.tip_column(U, SA, tip_a) + ["s_waitcnt lgkmcnt(0)"] +
             ROTATE + weave(mv[:half], P_ADV + PREFETCH + st_a) + st_bc + mv[half:] +
             self.product(U, X) + ["s_branch lh_walk_tail"])
         # cherry table into accumulator: a = table * (P a)
@@ -270,7 +287,7 @@ def render(S=2):
         ln = re.sub(r"(lh_walk_\w+)", r"\1_%=", ln)   # one copy of the labels per instantiation of the statement
         body.append('"%s\\n"\n' % ln)
     clob = ["// GENERATED by tools/gen_walk_asm.py: registers the %d-site walk statement clobbers.\n" % S]
-    regs = ['"v%d"' % i for i in range(5, g.r.last + 1)] + ['"s%d"' % i for i in range(36, 100)]
+    regs = ['"v%d"' % i for i in range(5, g.r.last + 1)] + ['"s%d"' % i for i in list(range(SA, SC + 8)) + list(range(36, 100))]
     for i in range(0, len(regs), 16):
         clob.append(", ".join(regs[i:i + 16]) + (",\n" if i + 16 < len(regs) else "\n"))
     n_v = sum(1 for l in lines if l.startswith("v_"))
