@@ -114,6 +114,7 @@ struct lh_family {
   bool extended = false;  // lh_family_set_extended_range
   bool have_sampler = false;
   lh::DevSampler sampler{};  // device pointers inside (arena)
+  const lh::DevSampler* sampler_dev = nullptr;  // its device copy (K4 reads the tables' addresses from memory)
   struct {                   // lh_eval_sample_batch's device buffers (grow-only)
     size_t cap[9] = {0};
     void* ptr[9] = {nullptr};
@@ -969,6 +970,7 @@ int lh_family_set_sampler(lh_family* f, const lh_sampler_desc* desc) {
   }
   s.words_per_sample = 2 * draws;
   f->sampler = s;
+  if (upload(f, &s, 1, &f->sampler_dev)) return 1;
   f->have_sampler = true;
   return 0;
 }
@@ -1304,7 +1306,7 @@ int lh_eval_sample_batch_device(lh_family* f, int32_t n, int32_t T, int32_t max_
   lh_eval_outputs outs{rates, nullptr, (double*)d_fwd, nullptr};
   if (lh_eval_batch_device(f, n, T, max_depth, ops, brlen, er, pi, alpha, R, loglik, &outs, hip_stream)) return 1;
   const lh::DevSampler& smp = f->sampler;
-  lh::launch_sample(smp, n, (const double*)d_fwd, FS, words, smp.words_per_sample, states, stream);
+  lh::launch_sample(smp, f->sampler_dev, n, (const double*)d_fwd, FS, words, smp.words_per_sample, states, stream);
   LH_HIP(hipGetLastError());
   return 0;
 }
@@ -1371,7 +1373,7 @@ int lh_eval_sample_batch(lh_family* f, int32_t n, int32_t T, int32_t max_depth, 
     return 1;
   if (timing) LH_HIP(hipDeviceSynchronize());
   auto t4 = now();
-  lh::launch_sample(smp, n, (const double*)d_fwd, FS, (const uint32_t*)d[5], smp.words_per_sample, (int32_t*)d[8], nullptr);
+  lh::launch_sample(smp, f->sampler_dev, n, (const double*)d_fwd, FS, (const uint32_t*)d[5], smp.words_per_sample, (int32_t*)d[8], nullptr);
   LH_HIP(hipGetLastError());
   if (timing) LH_HIP(hipDeviceSynchronize());
   auto t5 = now();

@@ -169,7 +169,9 @@ struct DevSampler {
 
 // K4: states[n][states_per_sample] from the compact forward arrays fwd[n][forward_size] and each sample's
 // std::mt19937 outputs words[n][words_per_sample].
-void launch_sample(const DevSampler& smp, int n, const double* fwd, size_t forward_size, const uint32_t* words,
+// smp_dev: the device copy of smp (the kernel reads the table addresses from it instead of holding forty of them in
+// scalar registers).
+void launch_sample(const DevSampler& smp, const DevSampler* smp_dev, int n, const double* fwd, size_t forward_size, const uint32_t* words,
                    int words_per_sample, int32_t* states, hipStream_t stream);
 
 // P = I + U expm1(lambda * t*r) Uinv, clamped at 0 (K1's prologue).

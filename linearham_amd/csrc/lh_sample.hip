@@ -18,14 +18,18 @@
 //    the NTI states and the previous germline position of its own gene.  Transition values are rebuilt with the
 //    association FillTransition uses ((landing_out * gene_prob) * landing_in ...), so every weight has the bits
 //    the dense matrices hold.
-// One WAVE per sample.  The sums of a draw are sequential by definition (a + b + c in IEEE arithmetic is an
-// order), but its weights are not: lane l forms the weight of left gene l (64 genes at a time, coalesced reads of
-// the tables and of the forward row), the wave then adds the 64 values in lane order: they go through 512 bytes of
-// LDS and every lane runs the same chain of adds on broadcast reads (round 3; the first form fetched each value with
-// two v_readlane: three vector instructions per element instead of one, 3.4 -> 2.8 ms per 49 152 samples).  Zero weights need no skipping: x + 0 = x, and a zero
-// weight never satisfies the lower_bound test its predecessor failed.  The quotients weight / sum of the second
-// pass are again one division per lane.  (First version: one thread per sample, 5 ms for 2048 samples; this one:
-// see DESIGN.md section 6.)
+// SIXTEEN LANES per sample, four samples per wave (round 4; rounds 2-3: one wave per sample).  The sums of a draw are
+// sequential by definition (a + b + c in IEEE arithmetic is an order), but its weights are not, and neither are different
+// samples: lane l of a sample's group forms the weight of left gene 16 c + l (coalesced 128-byte reads of the tables and of
+// the forward row), the group's sixteen values go through LDS and every lane of the group adds them up in lane order on
+// reads that are broadcast within the group -- one vector add per element and FOUR samples, where the wave-per-sample form
+// spent the same instruction on one.  That form was bound by exactly these chains (about 40 000 instructions per sample,
+// 2.8 ms per 49 152 samples: profiles/r04_pipeline.txt), not by the 88 KB of forward arrays it read.  Everything that was
+// wave-uniform per sample -- the successor state, its table entries, the running sums, the uniform -- is now a per-lane value
+// equal across a group, and nothing branches on it: the single-weight draw of a left gene's predecessor is the general draw
+// with one non-zero weight.  Zero weights need no skipping: x + 0 = x, and a zero weight never satisfies the lower_bound
+// test its predecessor failed.  The quotients weight / sum of the second pass are one division per lane.
+// (First version: one thread per sample, 5 ms for 2048 samples.)
 // No fused multiply-adds in here: the host rounds after every operation.
 #include "lh_device.h"
 
@@ -35,10 +39,14 @@ namespace {
 
 #pragma clang fp contract(off)
 
-struct Draw {  // this sample's slice of the engine's output stream, and the wave's 1 KB of LDS (wave_draw)
+constexpr int kG = 16;  // lanes per sample
+
+struct Draw {  // this sample's slice of the engine's output stream, and its group's two 16-slot areas of the wave's LDS
   const uint32_t* words;
   int next;
-  double* lds;  // [128]: 64 weights or quotients, 64 partial sums
+  double* wbuf;  // [16] weights or quotients of the group's current chunk
+  double* cbuf;  // [16] partial sums
+  int gl;        // lane within the group
 };
 
 // std::generate_canonical<double, 53>(std::mt19937&) (bits/random.tcc): two 32-bit outputs
@@ -55,25 +63,25 @@ __device__ inline double canonical(Draw& d) {
   return r;
 }
 
-
 // std::discrete_distribution<int> over the weights  pre[0..n_pre) | lane_weight(0..n_mid) | post[0..n_post)
-// (this is the order of the states in the dense vector; everything the vector holds besides is zero).
+// (this is the order of the states in the dense vector; everything the vector holds besides is zero), for the sample of
+// the calling lane's group; n_dense, n_pre, n_mid, n_post are the same for every group of the wave, the weights are not.
 // Returns the position drawn; kPastEnd when the uniform lies beyond the last partial sum -- the caller then takes
 // the vector's last element, whose partial sum libstdc++ sets to 1; kFirst when the answer is the vector's element
 // 0 whatever it holds (a uniform of exactly 0, or a vector of fewer than two weights, which is not drawn from and
 // takes nothing from the engine).  `n_dense`: size of the dense vector.
-constexpr int kPastEnd = -1, kFirst = -2;
+constexpr int kPastEnd = -1, kFirst = -2, kNone = -3;
 
-// The 64 values the lanes hold, added to `acc` in lane order: every lane performs the same chain of adds on values it
-// reads back from LDS (uniform addresses: broadcast reads), so the result is uniform and no lane-to-scalar traffic is
-// needed -- 64 vector adds where the v_readlane form took 64 x (2 v_readlane + 1 add).  Lanes beyond the chunk hold 0.
-__device__ inline double add_in_lane_order(double acc, double mine, double* buf) {
-  buf[threadIdx.x & 63] = mine;
+// The 16 values the lanes of a group hold, added to `acc` in lane order: every lane performs the same chain of adds on
+// values it reads back from LDS (the same addresses across the group: broadcast reads), so the result is uniform across the
+// group.  Lanes beyond the chunk hold 0.
+__device__ inline double add_in_group_order(double acc, double mine, const Draw& d) {
+  d.wbuf[d.gl] = mine;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  const double2* b2 = reinterpret_cast<const double2*>(buf);
+  const double2* b2 = reinterpret_cast<const double2*>(d.wbuf);
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
+  for (int j = 0; j < kG / 2; ++j) {
     const double2 v = b2[j];
     acc += v.x;
     acc += v.y;
@@ -82,46 +90,55 @@ __device__ inline double add_in_lane_order(double acc, double mine, double* buf)
   return acc;
 }
 
-template <typename F>
-__device__ int wave_draw(int n_dense, const double* pre, int n_pre, int n_mid, F&& lane_weight, const double* post,
-                         int n_post, Draw& d) {
+// (the successor's own five weights come by value and their place -- before or behind the left genes' block -- as a template
+// argument: with a pointer and run-time counts the array was indexed dynamically, and the build at -O3 faulted on it)
+template <int kPre, int kPost, typename F>
+__device__ int group_draw(int n_dense, const double (&own)[5], int n_mid, F&& lane_weight, Draw& d) {
+  constexpr int n_pre = kPre, n_post = kPost;
+  const double (&pre)[5] = own;
+  const double (&post)[5] = own;
   if (n_dense < 2) return kFirst;
-  const int lane = threadIdx.x & 63;
-  double* wbuf = d.lds;
-  double* cbuf = d.lds + 64;
+  const int gl = d.gl;
+  const int shift = (threadIdx.x & 63) & ~(kG - 1);  // first lane of this group within the wave
   double sum = 0.0;
+#pragma unroll
   for (int a = 0; a < n_pre; ++a) sum += pre[a];
-  for (int c = 0; c < n_mid; c += 64) {
-    const double w = (c + lane < n_mid) ? lane_weight(c + lane) : 0.0;
-    if (__builtin_amdgcn_ballot_w64(w != 0.0) == 0) continue;
-    sum = add_in_lane_order(sum, w, wbuf);
+  for (int c = 0; c < n_mid; c += kG) {
+    const double w = (c + gl < n_mid) ? lane_weight(c + gl) : 0.0;
+    if (__builtin_amdgcn_ballot_w64(w != 0.0) == 0) continue;  // (no group of the wave has a weight here)
+    sum = add_in_group_order(sum, w, d);
   }
+#pragma unroll
   for (int a = 0; a < n_post; ++a) sum += post[a];
   const double p = canonical(d);
-  if (!(p > 0.0)) return kFirst;
+  int result = kNone;
+  if (!(p > 0.0)) result = kFirst;
   // no positive weight at all: every quotient is 0 / 0, no partial sum compares below the uniform, and lower_bound
   // -- which only ever moves left then -- ends on element 0
-  if (!(sum > 0.0)) return kFirst;
+  if (!(sum > 0.0)) result = kFirst;
   double cum = 0.0;
   int pos = 0;
+#pragma unroll
   for (int a = 0; a < n_pre; ++a, ++pos) {
     cum += pre[a] / sum;
-    if (cum >= p) return pos;
+    if (result == kNone && cum >= p) result = pos;
   }
-  for (int c = 0; c < n_mid; c += 64) {
-    const double w = (c + lane < n_mid) ? lane_weight(c + lane) : 0.0;
+  for (int c = 0; c < n_mid; c += kG) {
+    if (__builtin_amdgcn_ballot_w64(result == kNone) == 0) break;  // every group of the wave has its answer
+    const double w = (c + gl < n_mid) ? lane_weight(c + gl) : 0.0;
     if (__builtin_amdgcn_ballot_w64(w != 0.0) == 0) continue;
-    // the chunk's partial sums, in lane order: lane 0 runs the chain (quotients read back from LDS) and leaves partial
-    // sum j at cbuf[j]; then every lane compares its own with the uniform and the first hit is the answer
-    wbuf[lane] = w / sum;
+    // the chunk's partial sums, in lane order: the group's first lane runs the chain (quotients read back from LDS) and
+    // leaves partial sum j at cbuf[j]; then every lane compares its own with the uniform and the first hit is the answer
+    // (a group whose weights are all zero here leaves its running sum as it is: sixteen times + 0)
+    d.wbuf[gl] = w / sum;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-      const double2* b2 = reinterpret_cast<const double2*>(wbuf);
-      double2* c2 = reinterpret_cast<double2*>(cbuf);
+    if (gl == 0) {
+      const double2* b2 = reinterpret_cast<const double2*>(d.wbuf);
+      double2* c2 = reinterpret_cast<double2*>(d.cbuf);
       double run = cum;
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {
+      for (int j = 0; j < kG / 2; ++j) {
         const double2 v = b2[j];
         double2 o;
         run += v.x;
@@ -133,19 +150,21 @@ __device__ int wave_draw(int n_dense, const double* pre, int n_pre, int n_mid, F
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const double mine = cbuf[lane];
-    cum = cbuf[63];  // (lanes beyond the chunk added zeros)
-    const int m = min(64, n_mid - c);
-    const unsigned long long hit = __builtin_amdgcn_ballot_w64(lane < m && mine >= p);
+    const double mine = d.cbuf[gl];
+    cum = d.cbuf[kG - 1];  // (lanes beyond the chunk added zeros)
+    const int m = min(kG, n_mid - c);
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(result == kNone && gl < m && mine >= p);
+    const unsigned mine_hits = (unsigned)(hit >> shift) & ((1u << kG) - 1u);
     __builtin_amdgcn_wave_barrier();
-    if (hit != 0) return n_pre + c + (int)__builtin_ctzll(hit);
+    if (result == kNone && mine_hits != 0) result = n_pre + c + (int)__builtin_ctz(mine_hits);
   }
   pos = n_pre + n_mid;
+#pragma unroll
   for (int a = 0; a < n_post; ++a, ++pos) {
     cum += post[a] / sum;
-    if (cum >= p) return pos;
+    if (result == kNone && cum >= p) result = pos;
   }
-  return kPastEnd;
+  return result == kNone ? kPastEnd : result;
 }
 
 // What a dense junction state is: kind (0 left-gene state, 1 NTI, 2 right-gene germline state), its gene (left
@@ -171,34 +190,35 @@ __device__ inline Succ classify(const DevSampleJunction& J, int dense) {
 
 // One backward step: draws the state of junction row i given its successor (row i + 1, or the gene of the region
 // right of the junction for i = W - 1).  fwd_row: the row's compact forward entries [left nL | nti nR x 4 |
-// right nR].  Returns the dense index drawn.  Everything but the lane-parallel weights is wave-uniform.
+// right nR].  Returns the dense index drawn.  The successor -- and with it every table entry read here -- is a per-lane
+// value, the same across a sample's group; nothing branches on it.
 __device__ int draw_row(const DevSampleJunction& J, int i, const Succ& sc, const double* __restrict__ fwd_row, Draw& d) {
   const int nL = J.n_left, nR = J.n_right;
   const double* fL = fwd_row;
   const double* fN = fwd_row + nL;
   const double* fR = fwd_row + nL + 4 * (size_t)nR;
+  // kind 0 -- the successor is a left gene's state: its only predecessor is the gene's state on the row before, the
+  // distribution has one non-zero weight (the host still draws: the uniform may be 0, or the weight's quotient below it),
+  // and a state that does not belong to row i + 1 has no predecessor with a forward entry on row i.  r1 indexes the LEFT
+  // genes then, the RIGHT genes otherwise.
+  const bool single = sc.kind == 0;
   const int r1 = sc.gene;
-  if (sc.kind == 0) {
-    // the only predecessor of a left gene's state is the gene's state on the row before: the distribution has one
-    // non-zero weight, but the host still draws (and the uniform may be 0, or the weight's quotient below it)
-    // (a state that does not belong to row i + 1 has no predecessor with a forward entry on row i)
-    const double w = sc.row == i + 1 ? J.left_trans[(size_t)(i + 1) * nL + r1] * fL[r1] : 0.0;
-    const int pos = wave_draw(J.n_states, &w, 1, 0, [](int) { return 0.0; }, nullptr, 0, d);
-    return pos == kFirst ? 0 : pos == kPastEnd ? J.n_states - 1 : J.left_dense[r1] + i;
-  }
+  const int rr = single ? 0 : r1;  // a valid right-gene index for the table reads the single-weight case does not use
+  const double w_single = (single && sc.row == i + 1) ? J.left_trans[(size_t)(i + 1) * nL + r1] * fL[r1] : 0.0;
   // coefficient of the left genes' block: T(state of left gene l on row i -> succ) = (landing_out * gene_prob) * x
-  const double gp = J.gp[r1];
+  const double gp = J.gp[rr];
   double x, exitp = 1.0;
   if (sc.kind == 1)
-    x = J.nli[(size_t)r1 * 4 + sc.base];
+    x = J.nli[(size_t)rr * 4 + sc.base];
   else if (sc.kind == 2)
-    x = sc.row == i + 1 ? J.li[(size_t)sc.row * nR + r1] : 0.0;  // left states reach it from the row before its own only
+    x = sc.row == i + 1 ? J.li[(size_t)sc.row * nR + rr] : 0.0;  // left states reach it from the row before its own only
   else {
-    x = J.exit_li[r1];
-    exitp = J.prod[r1];
+    x = J.exit_li[rr];
+    exitp = J.prod[rr];
   }
   const bool exiting = sc.kind == 3;
   auto left_weight = [&](int l) -> double {
+    if (single) return l == r1 ? w_single : 0.0;
     if (i >= J.left_rows[l]) return 0.0;  // the gene has no state on this row
     double t = (J.left_lo[(size_t)i * nL + l] * gp) * x;
     if (exiting) t *= exitp;
@@ -206,34 +226,46 @@ __device__ int draw_row(const DevSampleJunction& J, int i, const Succ& sc, const
   };
   // the successor's own gene: its four NTI states, then its germline state of this row
   double own[5];
+  const int srow = sc.kind == 2 ? sc.row : 0;  // (a valid row for the reads below)
+  // NOT to be unrolled.  Unrolled (hipcc 7.2 does so from -O2 on) the three-way choice of the table folds into a choice
+  // between ADDRESSES followed by one wide load, and the kernel that comes out forms a wild address on some lanes: memory
+  // faults at 0xfffff000 / 0x100000000 on the first launch of a 9-tip family.  The same source is correct at -O1, with
+  // -fno-unroll-loops (which leaves exactly this loop alone: -Rpass=loop-unroll) and with every read address-checked -- a
+  // code-generation fault, found by bisecting the optimisation flags (round 4); tests/test_host_gpu.py's device = host
+  // sampler tests are the guard.
+#pragma unroll 1
   for (int a = 0; a < 4; ++a) {
     double t;
     if (sc.kind == 1)
-      t = J.ntt[(size_t)r1 * 16 + a * 4 + sc.base];
+      t = J.ntt[(size_t)rr * 16 + a * 4 + sc.base];
     else if (sc.kind == 2)
-      t = J.nlo[((size_t)sc.row * nR + r1) * 4 + a];  // NTI states live on every row: into the state's own position
+      t = J.nlo[((size_t)srow * nR + rr) * 4 + a];  // NTI states live on every row: into the state's own position
     else
-      t = J.exit_nlo[(size_t)r1 * 4 + a];
-    own[a] = t * fN[(size_t)r1 * 4 + a];
+      t = J.exit_nlo[(size_t)rr * 4 + a];
+    own[a] = single ? 0.0 : t * fN[(size_t)rr * 4 + a];
   }
   own[4] = 0.0;
-  const int first = J.right_first[r1];
-  if (i >= first && sc.kind == 2 && sc.row == i + 1) own[4] = J.rtrans[(size_t)sc.row * nR + r1] * fR[r1];
-  if (i >= first && sc.kind == 3) own[4] = J.exit_trans[r1] * fR[r1];
+  const int first = J.right_first[rr];
+  if (i >= first && sc.kind == 2 && sc.row == i + 1) own[4] = J.rtrans[(size_t)sc.row * nR + rr] * fR[rr];
+  if (i >= first && sc.kind == 3) own[4] = J.exit_trans[rr] * fR[rr];
   const bool rf = J.right_first_block != 0;
-  const int pos = wave_draw(J.n_states, own, rf ? 5 : 0, nL, left_weight, own, rf ? 0 : 5, d);
+  const int pos = rf ? group_draw<5, 0>(J.n_states, own, nL, left_weight, d) : group_draw<0, 5>(J.n_states, own, nL, left_weight, d);
   if (pos == kFirst) return 0;
   if (pos == kPastEnd) return J.n_states - 1;
   const int a = rf ? pos : pos - nL;  // position within the own-gene entries
-  if (a >= 0 && a < 5) return J.right_dense[r1] + (a < 4 ? a : 4 + (i - first));
+  if (a >= 0 && a < 5) return J.right_dense[rr] + (a < 4 ? a : 4 + (i - first));
   return J.left_dense[rf ? pos - 5 : pos] + i;
 }
 
 // SampleGermlineState: the gene of the germline region LEFT of junction J, given the junction's row-0 state
 __device__ int draw_left_region(const DevSampleJunction& J, int dense0, const double* __restrict__ germ_fwd, Draw& d) {
   const Succ sc = classify(J, dense0);
-  const int pos = wave_draw(
-      J.n_left, nullptr, 0, J.n_left,
+  const int rg = sc.kind == 0 ? 0 : sc.gene;  // (a valid right-gene index)
+  const double x = sc.kind == 1 ? J.nli[(size_t)rg * 4 + sc.base] : J.li[rg];  // row 0 of li
+  const double gpx = J.gp[rg];
+  const double none[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  const int pos = group_draw<0, 0>(
+      J.n_left, none, J.n_left,
       [&](int g) -> double {
         double t;
         if (sc.kind == 0) {
@@ -241,26 +273,25 @@ __device__ int draw_left_region(const DevSampleJunction& J, int dense0, const do
           t = J.left_trans[g];  // row 0 of left_trans: the transition out of the germline region
         } else {
           if (sc.kind == 2 && sc.row != 0) return 0.0;
-          const double x = sc.kind == 1 ? J.nli[(size_t)sc.gene * 4 + sc.base] : J.li[sc.gene];  // row 0 of li
-          t = (J.enter_lo[g] * J.gp[sc.gene]) * x;
+          t = (J.enter_lo[g] * gpx) * x;
         }
         return t * germ_fwd[g];
       },
-      nullptr, 0, d);
+      d);
   return pos == kFirst ? 0 : pos == kPastEnd ? J.n_left - 1 : pos;
 }
 
 // Samples junction J backwards: states[i] for i = W-1 .. 0, given gene `right_gene` of the region right of it.
 // Returns the row-0 state.
 __device__ int sample_junction(const DevSampleJunction& J, int right_gene, const double* __restrict__ fwd_rows,
-                                Draw& d, int32_t* __restrict__ states) {
+                                Draw& d, int32_t* __restrict__ states, bool writer) {
   const int W = J.n_rows;
   const size_t stride = (size_t)J.n_left + 5 * (size_t)J.n_right;
   Succ sc{3, right_gene, 0, -1};
   int row0 = 0;
   for (int i = W - 1; i >= 0; --i) {
     const int s = draw_row(J, i, sc, fwd_rows + (size_t)i * stride, d);
-    if ((threadIdx.x & 63) == 0) states[i] = s;
+    if (writer) states[i] = s;
     sc = classify(J, s);
     row0 = s;
   }
@@ -271,16 +302,21 @@ __device__ int sample_junction(const DevSampleJunction& J, int right_gene, const
 
 // states[n][1 + W_dj + 1 + W_vd + 1] (igh) / [1 + W_vd + 1] (light chains):
 //   J gene | D-J junction rows 0..W-1 | D gene | V-D junction rows | V gene      (dense indices, as the host keeps them)
-constexpr int kSampleWaves = 4;  // samples per workgroup
+constexpr int kSampleWaves = 4;            // waves per workgroup
+constexpr int kPerWave = 64 / kG;          // samples per wave
 __global__ void __launch_bounds__(64 * kSampleWaves)
-    sample_kernel(const DevSampler smp, int n, const double* __restrict__ fwd_all, size_t forward_size,
+    sample_kernel(const DevSampler* __restrict__ smp_dev, int n, const double* __restrict__ fwd_all, size_t forward_size,
                   const uint32_t* __restrict__ words_all, int words_per_sample, int32_t* __restrict__ states_all) {
-  const int s = __builtin_amdgcn_readfirstlane(blockIdx.x * kSampleWaves + (int)(threadIdx.x >> 6));
-  if (s >= n) return;
-  const bool writer = (threadIdx.x & 63) == 0;
+  const DevSampler& smp = *smp_dev;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane / kG;
+  const int s_raw = (blockIdx.x * kSampleWaves + wave) * kPerWave + grp;
+  // (a group past the end of the batch walks the last sample along with the others and writes nothing: every lane of the
+  // wave takes part in every ballot and barrier)
+  const int s = min(s_raw, n - 1);
+  const bool writer = (lane % kG) == 0 && s_raw < n;
   const double* fwd = fwd_all + (size_t)s * forward_size;
-  __shared__ double wave_lds[kSampleWaves][128];
-  Draw d{words_all + (size_t)s * words_per_sample, 0, wave_lds[threadIdx.x >> 6]};
+  __shared__ double wave_lds[kSampleWaves][kPerWave][2 * kG];
+  Draw d{words_all + (size_t)s * words_per_sample, 0, wave_lds[wave][grp], wave_lds[wave][grp] + kG, lane % kG};
   const DevSampleJunction& VD = smp.vd;
   const DevSampleJunction& DJ = smp.dj;
   const int nV = smp.n_v, nD = smp.n_d, nJ = smp.n_j;
@@ -293,30 +329,33 @@ __global__ void __launch_bounds__(64 * kSampleWaves)
   const double* f_j = f_dj + dj_size;
   int32_t* out = states_all + (size_t)s * smp.states_per_sample;
   // SampleInitialState
-  int jg = wave_draw(nJ, nullptr, 0, nJ, [&](int g) -> double { return f_j[g]; }, nullptr, 0, d);
+  const double none[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  int jg = group_draw<0, 0>(nJ, none, nJ, [&](int g) -> double { return f_j[g]; }, d);
   jg = jg == kFirst ? 0 : jg == kPastEnd ? nJ - 1 : jg;
   int o = 0;
   if (writer) out[o] = jg;
   ++o;
   int row0;
   if (smp.has_d) {
-    row0 = sample_junction(DJ, jg, f_dj, d, out + o);
+    row0 = sample_junction(DJ, jg, f_dj, d, out + o, writer);
     const int dg = draw_left_region(DJ, row0, f_d, d);
     o += DJ.n_rows;
     if (writer) out[o] = dg;
     ++o;
-    row0 = sample_junction(VD, dg, f_vd, d, out + o);
+    row0 = sample_junction(VD, dg, f_vd, d, out + o, writer);
   } else {
-    row0 = sample_junction(VD, jg, f_vd, d, out + o);
+    row0 = sample_junction(VD, jg, f_vd, d, out + o, writer);
   }
   const int vg = draw_left_region(VD, row0, f_v, d);
   o += VD.n_rows;
   if (writer) out[o] = vg;
 }
 
-void launch_sample(const DevSampler& smp, int n, const double* fwd, size_t forward_size, const uint32_t* words,
-                   int words_per_sample, int32_t* states, hipStream_t stream) {
-  hipLaunchKernelGGL(sample_kernel, dim3((n + kSampleWaves - 1) / kSampleWaves), dim3(64 * kSampleWaves), 0, stream, smp, n,
+void launch_sample(const DevSampler& smp, const DevSampler* smp_dev, int n, const double* fwd, size_t forward_size,
+                   const uint32_t* words, int words_per_sample, int32_t* states, hipStream_t stream) {
+  (void)smp;
+  const int per_block = kSampleWaves * kPerWave;
+  hipLaunchKernelGGL(sample_kernel, dim3((n + per_block - 1) / per_block), dim3(64 * kSampleWaves), 0, stream, smp_dev, n,
                      fwd, forward_size, words, words_per_sample, states);
 }
 
