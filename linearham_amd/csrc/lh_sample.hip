@@ -31,6 +31,8 @@
 // test its predecessor failed.  The quotients weight / sum of the second pass are one division per lane.
 // (First version: one thread per sample, 5 ms for 2048 samples.)
 // No fused multiply-adds in here: the host rounds after every operation.
+#include <algorithm>
+
 #include "lh_device.h"
 
 namespace lh {
@@ -39,7 +41,7 @@ namespace {
 
 #pragma clang fp contract(off)
 
-constexpr int kG = 16;  // lanes per sample
+constexpr int kG = 16;  // lanes per sample (measured: 8 -> 4.88 M pipeline rows/s, 16 -> 5.07-5.10 M, 32 -> 4.77 M; profiles/r04_pipeline.txt)
 
 struct Draw {  // this sample's slice of the engine's output stream, and its group's two 16-slot areas of the wave's LDS
   const uint32_t* words;
@@ -47,6 +49,7 @@ struct Draw {  // this sample's slice of the engine's output stream, and its gro
   double* wbuf;  // [16] weights or quotients of the group's current chunk
   double* cbuf;  // [16] partial sums
   int gl;        // lane within the group
+  double* wsave; // [cap] every weight of the group's current draw (nullptr: the family's draws do not fit; recompute them)
 };
 
 // std::generate_canonical<double, 53>(std::mt19937&) (bits/random.tcc): two 32-bit outputs
@@ -92,6 +95,11 @@ __device__ inline double add_in_group_order(double acc, double mine, const Draw&
 
 // (the successor's own five weights come by value and their place -- before or behind the left genes' block -- as a template
 // argument: with a pointer and run-time counts the array was indexed dynamically, and the build at -O3 faulted on it)
+// Three phases per draw.  A: every lane forms the weights of its genes (one per 16-gene chunk) and parks them in the group's
+// LDS row -- no arithmetic depends on a load of another chunk, so all of a row's table and forward reads are in flight
+// together (the chunk-by-chunk form of the first 16-lane version paid a memory round trip per chunk and pass: 26 per V-D
+// row).  B: the sum, in dense-vector order, from LDS.  C: quotients and partial sums, from LDS.  `nz` remembers which chunks
+// hold a non-zero weight in any group of the wave; the others change no sum and cannot be drawn.
 template <int kPre, int kPost, typename F>
 __device__ int group_draw(int n_dense, const double (&own)[5], int n_mid, F&& lane_weight, Draw& d) {
   constexpr int n_pre = kPre, n_post = kPost;
@@ -100,13 +108,36 @@ __device__ int group_draw(int n_dense, const double (&own)[5], int n_mid, F&& la
   if (n_dense < 2) return kFirst;
   const int gl = d.gl;
   const int shift = (threadIdx.x & 63) & ~(kG - 1);  // first lane of this group within the wave
+  const bool saved = d.wsave != nullptr;
+  unsigned long long nz = 0;  // bit c / 16: chunk c has a non-zero weight somewhere in the wave (first 64 chunks)
+  if (saved) {
+    for (int c = 0; c < n_mid; c += kG) {
+      const double w = (c + gl < n_mid) ? lane_weight(c + gl) : 0.0;
+      d.wsave[c + gl] = w;
+      if (__builtin_amdgcn_ballot_w64(w != 0.0) != 0) nz |= 1ull << ((c / kG) & 63);
+    }
+    if (n_mid > 64 * kG) nz = ~0ull;  // (more chunks than bits: none is skipped)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
   double sum = 0.0;
 #pragma unroll
   for (int a = 0; a < n_pre; ++a) sum += pre[a];
   for (int c = 0; c < n_mid; c += kG) {
-    const double w = (c + gl < n_mid) ? lane_weight(c + gl) : 0.0;
-    if (__builtin_amdgcn_ballot_w64(w != 0.0) == 0) continue;  // (no group of the wave has a weight here)
-    sum = add_in_group_order(sum, w, d);
+    if (saved) {
+      if (!((nz >> ((c / kG) & 63)) & 1)) continue;
+      const double2* b2 = reinterpret_cast<const double2*>(d.wsave + c);
+#pragma unroll
+      for (int j = 0; j < kG / 2; ++j) {
+        const double2 v = b2[j];
+        sum += v.x;
+        sum += v.y;
+      }
+    } else {
+      const double w = (c + gl < n_mid) ? lane_weight(c + gl) : 0.0;
+      if (__builtin_amdgcn_ballot_w64(w != 0.0) == 0) continue;  // (no group of the wave has a weight here)
+      sum = add_in_group_order(sum, w, d);
+    }
   }
 #pragma unroll
   for (int a = 0; a < n_post; ++a) sum += post[a];
@@ -123,6 +154,38 @@ __device__ int group_draw(int n_dense, const double (&own)[5], int n_mid, F&& la
     cum += pre[a] / sum;
     if (result == kNone && cum >= p) result = pos;
   }
+  if (saved) {
+    // quotients in place (a lane its own elements), then every lane of the group runs the partial sums over them on
+    // broadcast reads.  Weights are >= 0 (or the sum is NaN, which was settled above), so the partial sums never fall and
+    // the element lower_bound picks is the number of leading elements whose partial sum is not >= the uniform -- one
+    // compare and one add-with-carry per element, no round trip through LDS between chunks.
+    for (int c = 0; c < n_mid; c += kG)
+      if ((nz >> ((c / kG) & 63)) & 1) d.wsave[c + gl] = d.wsave[c + gl] / sum;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int below = 0;  // leading elements of the block whose partial sum is below the uniform
+    for (int c = 0; c < n_mid; c += kG) {
+      if (__builtin_amdgcn_ballot_w64(result == kNone) == 0) break;  // every group of the wave has its answer
+      if (!((nz >> ((c / kG) & 63)) & 1)) {  // zeros: the partial sums stand still
+        if (result == kNone) below = min(c + kG, n_mid);
+        continue;
+      }
+      const double2* b2 = reinterpret_cast<const double2*>(d.wsave + c);
+      int cnt = 0;
+#pragma unroll
+      for (int j = 0; j < kG / 2; ++j) {
+        const double2 v = b2[j];
+        cum += v.x;
+        cnt += !(cum >= p) ? 1 : 0;
+        cum += v.y;
+        cnt += !(cum >= p) ? 1 : 0;
+      }
+      if (result == kNone) {
+        below = c + cnt;  // (every element before this chunk was below: the chunk is reached with result == kNone only then)
+        if (cnt < kG && below < n_mid) result = n_pre + below;
+      }
+    }
+  } else {
   for (int c = 0; c < n_mid; c += kG) {
     if (__builtin_amdgcn_ballot_w64(result == kNone) == 0) break;  // every group of the wave has its answer
     const double w = (c + gl < n_mid) ? lane_weight(c + gl) : 0.0;
@@ -154,9 +217,10 @@ __device__ int group_draw(int n_dense, const double (&own)[5], int n_mid, F&& la
     cum = d.cbuf[kG - 1];  // (lanes beyond the chunk added zeros)
     const int m = min(kG, n_mid - c);
     const unsigned long long hit = __builtin_amdgcn_ballot_w64(result == kNone && gl < m && mine >= p);
-    const unsigned mine_hits = (unsigned)(hit >> shift) & ((1u << kG) - 1u);
+    const unsigned mine_hits = (unsigned)(hit >> shift) & (kG >= 32 ? 0xffffffffu : ((1u << (kG & 31)) - 1u));
     __builtin_amdgcn_wave_barrier();
     if (result == kNone && mine_hits != 0) result = n_pre + c + (int)__builtin_ctz(mine_hits);
+  }
   }
   pos = n_pre + n_mid;
 #pragma unroll
@@ -306,7 +370,7 @@ constexpr int kSampleWaves = 4;            // waves per workgroup
 constexpr int kPerWave = 64 / kG;          // samples per wave
 __global__ void __launch_bounds__(64 * kSampleWaves)
     sample_kernel(const DevSampler* __restrict__ smp_dev, int n, const double* __restrict__ fwd_all, size_t forward_size,
-                  const uint32_t* __restrict__ words_all, int words_per_sample, int32_t* __restrict__ states_all) {
+                  const uint32_t* __restrict__ words_all, int words_per_sample, int32_t* __restrict__ states_all, int save_cap) {
   const DevSampler& smp = *smp_dev;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane / kG;
   const int s_raw = (blockIdx.x * kSampleWaves + wave) * kPerWave + grp;
@@ -316,7 +380,9 @@ __global__ void __launch_bounds__(64 * kSampleWaves)
   const bool writer = (lane % kG) == 0 && s_raw < n;
   const double* fwd = fwd_all + (size_t)s * forward_size;
   __shared__ double wave_lds[kSampleWaves][kPerWave][2 * kG];
-  Draw d{words_all + (size_t)s * words_per_sample, 0, wave_lds[wave][grp], wave_lds[wave][grp] + kG, lane % kG};
+  extern __shared__ double2 sample_dyn[];  // [kSampleWaves][kPerWave][save_cap] doubles: a draw's weights (save_cap == 0: none)
+  double* wsave = save_cap > 0 ? reinterpret_cast<double*>(sample_dyn) + (size_t)(wave * kPerWave + grp) * save_cap : nullptr;
+  Draw d{words_all + (size_t)s * words_per_sample, 0, wave_lds[wave][grp], wave_lds[wave][grp] + kG, lane % kG, wsave};
   const DevSampleJunction& VD = smp.vd;
   const DevSampleJunction& DJ = smp.dj;
   const int nV = smp.n_v, nD = smp.n_d, nJ = smp.n_j;
@@ -353,10 +419,15 @@ __global__ void __launch_bounds__(64 * kSampleWaves)
 
 void launch_sample(const DevSampler& smp, const DevSampler* smp_dev, int n, const double* fwd, size_t forward_size,
                    const uint32_t* words, int words_per_sample, int32_t* states, hipStream_t stream) {
-  (void)smp;
   const int per_block = kSampleWaves * kPerWave;
-  hipLaunchKernelGGL(sample_kernel, dim3((n + per_block - 1) / per_block), dim3(64 * kSampleWaves), 0, stream, smp_dev, n,
-                     fwd, forward_size, words, words_per_sample, states);
+  // a draw's weights are kept in LDS between its passes when the widest draw of the family fits 2 KB per sample (32 KB
+  // per workgroup): 256 genes; wider families form them again in each pass
+  int widest = std::max(std::max(smp.n_v, smp.n_j), std::max(smp.vd.n_left, smp.has_d ? std::max(smp.n_d, smp.dj.n_left) : 0));
+  widest = (widest + kG - 1) / kG * kG;
+  const int save_cap = widest <= 256 ? widest : 0;
+  const size_t dyn = (size_t)per_block * save_cap * sizeof(double);
+  hipLaunchKernelGGL(sample_kernel, dim3((n + per_block - 1) / per_block), dim3(64 * kSampleWaves), dyn, stream, smp_dev, n,
+                     fwd, forward_size, words, words_per_sample, states, save_cap);
 }
 
 }  // namespace lh
