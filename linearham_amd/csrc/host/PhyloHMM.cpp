@@ -172,21 +172,24 @@ void PhyloHMM::CreateFamily() {
     sd.vd = svd.c();
     device_sampler_ = lh_family_set_sampler(family_, &sd) == 0 && lh_sample_words(family_) == RawDrawsPerSample();
     timer.Mark("lh_family_set_sampler");
-    // the other devices' handles: the same descriptors, uploaded with that device current
-    for (std::size_t k = 1; k < devices_.size(); ++k) {
+    // the other devices' handles: the same descriptors, uploaded with that device current (only when the rows will be
+    // sampled on the devices: nothing else shards)
+    for (std::size_t k = 1; device_sampler_ && k < devices_.size(); ++k) {
       CheckHip(lh_set_device(devices_[k]), "lh_set_device");
       lh_family* f = nullptr;
       CheckHip(lh_family_create(&d, &f), "lh_family_create");
       more_families_.push_back(f);
       if (device_sampler_ && lh_family_set_sampler(f, &sd) != 0) throw std::runtime_error(lh_last_error());
     }
-  } else {
-    for (std::size_t k = 1; k < devices_.size(); ++k) {
-      CheckHip(lh_set_device(devices_[k]), "lh_set_device");
-      lh_family* f = nullptr;
-      CheckHip(lh_family_create(&d, &f), "lh_family_create");
-      more_families_.push_back(f);
-    }
+  }
+  // Only RunPipeline's device-sampling branch deals rows to several handles.  A family that keeps the host sampler
+  // (LH_HOST_SAMPLING, or genes that do not form two blocks of a junction's state vector) evaluates everything on the
+  // first listed device: say so instead of building handles nobody uses.
+  if (devices_.size() > 1 && !device_sampler_) {
+    std::fprintf(stderr, "linearham: --devices lists %zu devices, but this run samples on the host: all rows are evaluated on "
+                 "device %d\n", devices_.size(), devices_[0]);
+    for (lh_family* f : more_families_) lh_family_destroy(f);
+    more_families_.clear();
   }
   if (devices_.size() > 1) CheckHip(lh_set_device(devices_[0]), "lh_set_device");
 }

@@ -70,8 +70,28 @@ int main(int argc, char** argv) {
     const std::string hmm_param_dir = a.one("hmm-param-dir");
     const int seed = std::stoi(a.opt("seed", "0"));
     const int num_rates = std::stoi(a.opt("num-rates", "1"));
-    // the HIP runtime and the device context come up on a side thread while the parameter files are read
-    std::thread warmup([] { (void)lh_warmup(); });
+    // not in the reference: --devices a,b,... -- the GPUs --pipeline deals the table's rows to (row i -> device i mod N);
+    // every other subcommand evaluates on the first one
+    std::vector<int> device_list;
+    {
+      const std::string devs = a.opt("devices", "");
+      std::size_t pos = 0;
+      while (!devs.empty() && pos <= devs.size()) {
+        const std::size_t comma = std::min(devs.find(',', pos), devs.size());
+        device_list.push_back(std::stoi(devs.substr(pos, comma - pos)));
+        pos = comma + 1;
+      }
+      if (device_list.size() > 1 && subcmd != "--pipeline")
+        std::fprintf(stderr, "linearham: %s evaluates on one device; of --devices only device %d is used\n", subcmd.c_str(),
+                     device_list[0]);
+    }
+    // the HIP runtime and the context of the device the run evaluates on come up on a side thread while the parameter
+    // files are read
+    const int first_device = device_list.empty() ? -1 : device_list[0];
+    std::thread warmup([first_device] {
+      if (first_device >= 0 && first_device < lh_device_count()) (void)lh_set_device(first_device);
+      (void)lh_warmup();
+    });
     struct Join {
       std::thread& t;
       ~Join() {
@@ -82,19 +102,9 @@ int main(int argc, char** argv) {
         std::make_shared<linearham::PhyloHMM>(yaml_path, cluster_ind, hmm_param_dir, seed);
     warmup.join();
     if (timing) std::fprintf(stderr, "[main] family object + HIP context ready at %.3f s\n", since_start());
-    // not in the reference: --devices a,b,... -- the GPUs --pipeline deals the table's rows to (row i -> device i mod N)
-    {
-      const std::string devs = a.opt("devices", "");
-      if (!devs.empty()) {
-        std::vector<int> list;
-        std::size_t pos = 0;
-        while (pos <= devs.size()) {
-          const std::size_t comma = std::min(devs.find(',', pos), devs.size());
-          list.push_back(std::stoi(devs.substr(pos, comma - pos)));
-          pos = comma + 1;
-        }
-        phylo_hmm_ptr->SetDevices(list);
-      }
+    if (!device_list.empty()) {
+      if (subcmd != "--pipeline") device_list.resize(1);
+      phylo_hmm_ptr->SetDevices(device_list);
     }
     // not in the reference: finite log-likelihoods where its scaling over/underflows (include/linearham_amd.h)
     if (std::stoi(a.opt("extended-range", "0")) != 0) phylo_hmm_ptr->SetExtendedRange(true);

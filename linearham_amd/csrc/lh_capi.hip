@@ -26,6 +26,7 @@ const DebugOptions& debug_options() {
     o.k1_tile_cap = num("LH_K1_TILE_CAP", 0);
     o.k1_cxx_walk = set("LH_K1_CXX_WALK");
     o.k1_tables = set("LH_K1_TABLES");
+    o.k1_stack = set("LH_K1_STACK");
     o.k1_no_tables = set("LH_K1_NO_TABLES");
     o.k1_segments = set("LH_K1_SEGMENTS");
     o.k1_seg_waves = num("LH_K1_SEG_WAVES", o.k1_seg_waves);

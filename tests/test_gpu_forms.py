@@ -20,7 +20,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "forms_worker.py")
-HOOKS = ("LH_K1_TABLES", "LH_K1_NO_TABLES", "LH_K1_CXX_WALK", "LH_K1_NO_FUSE", "LH_K1_SEGMENTS", "LH_K1_SEG_WAVES",
+HOOKS = ("LH_K1_TABLES", "LH_K1_STACK", "LH_K1_NO_TABLES", "LH_K1_CXX_WALK", "LH_K1_NO_FUSE", "LH_K1_SEGMENTS", "LH_K1_SEG_WAVES",
          "LH_K1_TILE_CAP")
 
 
@@ -44,7 +44,8 @@ def _expect(report, family, pattern, **conds):
 # kernel<depth, N-aware, fused, assembly>    cherry-table form: ct6 / ct5 / ct4
 def test_default_forms_without_n():
     rep = _run({}, ["small_igh", "mid60x400", "balanced64", "wide100x600", "wide100x600_r8"])
-    _expect(rep, "small_igh", r"w[456]<[34],false>")                      # one one-site wave per rate, fused
+    # at most 128 patterns (one wave per rate): the assembly walk over cherry tables, the few patterns in a two-site wave
+    _expect(rep, "small_igh", r"ct[456]<4,false,true,true>", n_patterns=("le", 128))
     _expect(rep, "mid60x400", r"w[456]<[34],false>", n_patterns=("gt", 128))            # two-site waves, fused (configs[2]'s form)
     # a perfectly balanced 64-leaf tree: five pending siblings, i.e. slots beyond the register slot live in scratch memory
     _expect(rep, "balanced64", r"ct[456]<16,false,true,true>", max_depth=("ge", 5))
@@ -71,6 +72,8 @@ def test_default_forms_with_n_inside_columns():
 
 
 @pytest.mark.parametrize("hook,expect", [
+    # the register-stack form on a small family (one one-site wave per rate), which by itself takes the cherry-table form
+    ({"LH_K1_STACK": "1"}, {"small_igh": r"w[456]<[34],false>"}),
     # the cherry-table form where the register-stack form would run: fused, assembly walk (two-site waves) / N-aware C++ walk
     ({"LH_K1_TABLES": "1"}, {"small_igh": r"ct[456]<4,false,true,true>", "mid60x400": r"ct[456]<4,false,true,true>",
                              "mixed_small": r"ct[456]<4,true,true,false>", "mixed_60x400": r"ct[456]<4,true,\w+,false>"}),
@@ -89,7 +92,7 @@ def test_default_forms_with_n_inside_columns():
     ({"LH_K1_SEGMENTS": "1", "LH_K1_SEG_WAVES": "5"}, {"mid60x400": r"seg5<4,false>", "mixed_60x400": r"seg5<4,true>"}),
     # several site tiles per (sample, rate)
     ({"LH_K1_TILE_CAP": "64"}, {"mid60x400": r"\w+<.*>", "mixed_60x400": r"\w+<.*,true.*>"}),
-], ids=["tables", "tables_cxx", "no_tables", "no_fuse", "segments", "segments5", "tiles"])
+], ids=["stack", "tables", "tables_cxx", "no_tables", "no_fuse", "segments", "segments5", "tiles"])
 def test_hooked_forms(hook, expect):
     rep = _run(hook, list(expect))
     for fam, pattern in expect.items():

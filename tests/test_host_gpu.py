@@ -351,6 +351,14 @@ def test_pipeline_with_several_handles_writes_the_same_table(tmp_path, devices):
     bad = subprocess.run([_exe(), "--pipeline"] + common + ["--devices", "0,7", "--output-path", os.path.join(out, "x.tsv")],
                          capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "no such device" in bad.stderr      # a device the box does not have
+    # a run that samples on the host does not shard: it says so (instead of building handles nobody uses) and writes the
+    # same table on the first listed device
+    o = os.path.join(out, "hostsampling.tsv")
+    r = subprocess.run([_exe(), "--pipeline"] + common + ["--devices", devices, "--output-path", o], capture_output=True,
+                       text=True, timeout=600, env=dict(os.environ, LH_HOST_SAMPLING="1"))
+    assert r.returncode == 0, r.stderr
+    assert "samples on the host" in r.stderr, r.stderr
+    assert open(o).read() == tables["one"]
 
 
 @pytest.mark.parametrize("locus", ["igh", "igk", "many_alleles", "many_alleles_igk"])
