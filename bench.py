@@ -43,7 +43,7 @@ WORKLOADS = {
     "config2_ragged": "the configs[2] family with ragged reads: every sequence N-padded by 0-30 sites at either end, i.e. N "
                       "inside alignment columns (not the headline workload; its rate is the extra key mixed_n_evals_per_s)",
 }
-PMC_PROFILE = {"config2": "r03_bench_pmc_per_launch.json", "config4": "r03_config4_pmc_per_launch.json"}
+PMC_PROFILE = {"config2": "r04_bench_pmc_per_launch.json", "config4": "r03_config4_pmc_per_launch.json"}
 GEN_VERSION = 2                # bump when tools/synth_family.py changes what it writes
 
 
@@ -52,6 +52,7 @@ def log(*a):
 
 
 BRLEN_MEAN = None              # --brlen-mean (development runs on families with fewer site patterns)
+LIVE_TRAFFIC = (None, None)    # (bytes per K1 launch, note) from live_k1_traffic(), collected before the GPU is touched
 
 
 def preset_spec(preset, batch):
@@ -336,6 +337,50 @@ def mixed_n_rate(args, lib, T, R, n, dev, stream):
     return res
 
 
+def live_k1_traffic(args):
+    """HBM-side bytes of one K1 launch, measured NOW on this box: FETCH_SIZE and WRITE_SIZE of the pruning kernel from two short
+    child runs of this script under `rocprofv3 --pmc` (counters cannot be collected inside the measuring process, and the two
+    do not fit one pass: MI355X_MICROARCH.md, rocprofv3 PMC slots).  Runs BEFORE this process touches the GPU.  Returns
+    (bytes per launch with the gfx950 factor 2 x FETCH + WRITE, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    per_launch = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="lh_pmc_")
+        cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "run", "--", sys.executable, os.path.abspath(__file__),
+               "--preset", args.preset, "--batch", str(args.batch), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+               "--no-check", "--no-extras", "--no-forward-rate", "--no-live-pmc"]
+        if BRLEN_MEAN is not None:
+            cmd += ["--brlen-mean", repr(BRLEN_MEAN)]
+        try:
+            r = subprocess.run(cmd, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()),
+                               capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (ctr, r.returncode)
+            vals = []
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if "prune_kernel" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "no prune_kernel dispatch in the %s pass" % ctr
+            per_launch[ctr] = sum(vals) / len(vals)
+        except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+            return None, "rocprofv3 --pmc %s: %s" % (ctr, e)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    total = (2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]) * 1024.0
+    return total, ("measured in this run: two child passes of `rocprofv3 --pmc` over 3 launches of the same workload "
+                   "(FETCH_SIZE %.0f KiB, WRITE_SIZE %.0f KiB per launch as reported; bytes = 2 x FETCH + WRITE, the gfx950 "
+                   "correction of MI355X_MICROARCH.md)" % (per_launch["FETCH_SIZE"], per_launch["WRITE_SIZE"]))
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -357,6 +402,9 @@ def parse_args():
                     help="evaluations of the CPU baseline sample (also the rows the parity check covers)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys measured outside the `value` region (pipeline_rows_per_s, asr_tree_samples_per_s)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not spawn the two short `rocprofv3 --pmc` child runs that measure K1's HBM traffic for roofline.traffic "
+                         "(the figure then comes from the committed profile and says so)")
     ap.add_argument("--no-mixed-n", action="store_true",
                     help="skip the extra key mixed_n_evals_per_s (the configs[2] family with ragged reads, outside `value`)")
     ap.add_argument("--timeout-s", type=float, default=1500.0,
@@ -525,15 +573,18 @@ def worker(args, rank, local_rank, world):
         k1_tflops = k1_flops / (prune_ms * 1e-3) / 1e12
         # HBM traffic of one K1 launch from the committed PMC passes of this same command (counters need
         # their own rocprofv3 runs; gfx950 correction: FETCH_SIZE counts wide coalesced reads at half).
-        traffic = None
+        traffic, traffic_note = LIVE_TRAFFIC if world == 1 and per_launch == args.batch else (None, None)
         pmc_file = os.path.join(ROOT, "profiles", PMC_PROFILE.get(args.preset, "-"))
-        if world == 1 and per_launch == args.batch and os.path.exists(pmc_file) and BRLEN_MEAN is None:
+        if traffic is None and world == 1 and per_launch == args.batch and os.path.exists(pmc_file) and BRLEN_MEAN is None:
             with open(pmc_file) as f:
                 pmc = json.load(f)
             if pmc.get("_evals_per_launch", per_launch) == per_launch:
                 k1 = next((v for k, v in pmc.items() if "prune_kernel" in k), {})
                 if "FETCH_SIZE" in k1 and "WRITE_SIZE" in k1:
                     traffic = (2.0 * k1["FETCH_SIZE"] + k1["WRITE_SIZE"]) * 1024.0
+                    traffic_note = ("NOT measured by this run (%s): profiles/%s, HBM-side bytes per K1 launch from separate "
+                                    "rocprofv3 --pmc passes of this same command (2 x FETCH_SIZE + WRITE_SIZE)"
+                                    % (traffic_note or "live counters off", PMC_PROFILE.get(args.preset)))
         model_bytes_per_eval = Cx * (2 * (T - 2) * R * 32 + T + 8)   # CLV-streaming model
         out = {
             "metric": "phylo-HMM log-likelihood evals/sec (100-leaf x 400-site family)",
@@ -556,11 +607,8 @@ def worker(args, rank, local_rank, world):
                          "achieved": k1_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": k1_tflops / FP64_VALU_PEAK_TFLOPS,
                          "traffic": traffic,
-                         "traffic_source": ("profiles/%s: HBM-side bytes per K1 launch from separate rocprofv3 --pmc passes of this "
-                                            "same command (2 x FETCH_SIZE + WRITE_SIZE); counters cannot be collected inside "
-                                            "this run, so this one figure is NOT measured by it" % PMC_PROFILE.get(args.preset))
-                         if traffic else None,
-                         "hbm_gbs_from_profile": (traffic / (prune_ms * 1e-3) / 1e9) if traffic else None,
+                         "traffic_source": traffic_note if traffic else None,
+                         "hbm_gbs": (traffic / (prune_ms * 1e-3) / 1e9) if traffic else None,
                          "flop_per_launch": k1_flops, "evals_per_launch": per_launch, "avg_launch_ms": prune_ms,
                          "peak_source": "half the 157.3 TFLOP/s FP32 vector peak of MI355X_MICROARCH.md (FP64 FMAs "
                                         "issue at half rate; the guide lists no FP64 figure)",
@@ -631,6 +679,12 @@ def main():
             return launcher(args)
         env = (0, 0, 1)
     rank, local_rank, world = env
+    global LIVE_TRAFFIC
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if world == 1 and not args.no_live_pmc and not under_profiler and args.preset in ("config2", "config4"):
+        t0 = time.time()
+        LIVE_TRAFFIC = live_k1_traffic(args)
+        log("[bench] K1 HBM traffic from live rocprofv3 passes: %s (%.0f s)" % (LIVE_TRAFFIC, time.time() - t0))
     if world != args.gpus:
         log("warning: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     return worker(args, rank, local_rank, world)
