@@ -80,6 +80,8 @@ for seed in range(first, first + n):
                 print("seed", seed, t.LAST_RUN["form"], "FAILED", " ".join(str(e2).split())[:300], flush=True)
     finally:
         shutil.rmtree(out, ignore_errors=True)
+    if (seed - first + 1) % 50 == 0:
+        print("... %d seeds done" % (seed - first + 1), flush=True)
 print("sweep of %d seeds from %d: %d failures, %d beyond the relative tolerance on tiny entries only, %d with reference overflow rows"
       % (n, first, bad, soft, skipped), flush=True)
 print("forms reached:", dict(sorted(forms.items())), flush=True)
