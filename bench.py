@@ -62,7 +62,7 @@ def preset_spec(preset, batch):
     if preset == "config2":     # the batch is drawn from >= batch distinct tree samples
         return sf.Spec(n_samples=max(batch, 256))
     if preset == "config2_ragged":   # (2048 distinct tree samples, cycled through the batch)
-        return sf.Spec(n_samples=2048, ragged=30)
+        return sf.Spec(n_samples=2048, ragged=30, **({} if BRLEN_MEAN is None else {"brlen_mean": BRLEN_MEAN}))
     if preset == "config3":
         return sf.Spec(n_samples=10000)
     if preset == "config4":

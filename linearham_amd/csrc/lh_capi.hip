@@ -613,16 +613,22 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
       pat_of_site_all = pat_of_site;
       rc = rc || upload(f, pmsa.data(), pmsa.size(), &h.msa);
       h.msa_planes = nullptr;
-      if (!h.msa_mixed_n && h.n_prune > 0) {  // (every state is 0..3: two bits)
-        const size_t np = h.n_prune, nb = (np + 127) / 128;
-        std::vector<uint64_t> planes(N * nb * 4, 0);
+      if (h.n_prune > 0) {
+        // two state bits per pattern, and for alignments that mix N with bases a third plane flagging N (state bits 0 there)
+        const size_t np = h.n_prune, nb = (np + 127) / 128, nm = h.msa_mixed_n ? 3 : 2;
+        std::vector<uint64_t> planes(N * nb * 2 * nm, 0);
         for (size_t i = 0; i < N; ++i)
           for (size_t b = 0; b < nb; ++b)
             for (size_t s2 = 0; s2 < 2; ++s2)
               for (size_t l = 0; l < 64; ++l) {
                 const uint8_t st = pmsa[i * np + std::min(128 * b + 64 * s2 + l, np - 1)];
-                planes[(i * nb + b) * 4 + 2 * s2] |= (uint64_t)(st & 1) << l;
-                planes[(i * nb + b) * 4 + 2 * s2 + 1] |= (uint64_t)((st >> 1) & 1) << l;
+                uint64_t* m = &planes[((i * nb + b) * 2 + s2) * nm];
+                if (st < 4) {
+                  m[0] |= (uint64_t)(st & 1) << l;
+                  m[1] |= (uint64_t)((st >> 1) & 1) << l;
+                } else {
+                  m[2] |= (uint64_t)1 << l;  // (reached only when msa_mixed_n: a clean alignment holds no 4)
+                }
               }
         rc = rc || upload(f, planes.data(), planes.size(), &h.msa_planes);
       }

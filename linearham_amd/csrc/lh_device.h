@@ -106,10 +106,10 @@ struct DevFamily {
   int32_t idx_byte_offsets;                // 1: the segment index chunks hold byte offsets (index * 8),
                                            // possible when (n_ucol + 1) * 8 fits 16 bits
   const uint8_t* msa;                      // [n_seqs][n_prune]
-  // alignments without N inside a column (msa_mixed_n == 0): the same states 2 bits each as BIT PLANES for K1's assembly
-  // walk -- [n_seqs][ceil(n_prune / 128)][2 site sets][2 bits] 64-bit masks: bit l of plane (row i, block b, set s, bit q) is
-  // bit q of the state of row i at pattern 128 b + 64 s + l (patterns past the last one repeat it).  A wave fetches the
-  // 32 bytes of (row, its block) with one scalar load; nullptr otherwise.
+  // the same states as BIT PLANES for K1's assembly walk -- [n_seqs][ceil(n_prune / 128)][2 site sets][2 or 3] 64-bit masks:
+  // bit l of plane (row i, block b, set s, bit q) is bit q of the state of row i at pattern 128 b + 64 s + l (patterns past
+  // the last one repeat it); alignments that mix N with bases (msa_mixed_n) carry a third plane per set flagging N (state
+  // bits 0 there).  A wave fetches the 32 / 48 bytes of (row, its block) with one / two scalar loads.
   const uint64_t* msa_planes;
   const int32_t* site_pat;                 // [n_sites] pattern of alignment site j (n_prune = the all-N pattern)
   const int32_t* u_pat;                    // [n_ucol] pattern of u-column u

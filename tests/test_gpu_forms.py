@@ -58,35 +58,37 @@ def test_default_forms_without_n():
 
 def test_default_forms_with_n_inside_columns():
     """Ragged reads and scattered ambiguous bases (tools/synth_family.py ragged / ambiguous): the kN = true instantiations
-    -- tip columns with row sums formed on the spot, 25-entry cherry tables, the C++ cherry-table walk (the assembly walk is
-    for alignments without N)."""
+    -- N tips reading the vector of ones, 25-entry cherry tables, the N-aware assembly walk (a third state plane), the
+    N-aware register-stack and segmented kernels."""
     rep = _run({}, ["mixed_small", "mixed_igk", "mixed_120", "mixed_60x400", "mixed_balanced64", "mixed_500"])
     for fam in rep:
         assert rep[fam]["mixed_columns"] > 0, fam
-    _expect(rep, "mixed_small", r"w[456]<[34],true>")
-    _expect(rep, "mixed_igk", r"w[456]<[34],true>")
+    _expect(rep, "mixed_small", r"ct[456]<4,true,true,true>", n_patterns=("le", 128))    # small family: N-aware assembly walk
+    _expect(rep, "mixed_igk", r"ct[456]<4,true,true,true>", n_patterns=("le", 128))
     _expect(rep, "mixed_120", r"seg4<4,true>")                                            # 121 tips: segmented tip table
     _expect(rep, "mixed_60x400", r"w[456]<[34],true>", n_patterns=("gt", 256))          # twelve waves per workgroup
-    _expect(rep, "mixed_balanced64", r"ct[456]<16,true,true,false>", max_depth=("ge", 5))
+    _expect(rep, "mixed_balanced64", r"ct[456]<16,true,true,true>", max_depth=("ge", 5))
     _expect(rep, "mixed_500", r"seg4<4,true>")                                            # 11 segments
 
 
 @pytest.mark.parametrize("hook,expect", [
     # the register-stack form on a small family (one one-site wave per rate), which by itself takes the cherry-table form
-    ({"LH_K1_STACK": "1"}, {"small_igh": r"w[456]<[34],false>"}),
+    ({"LH_K1_STACK": "1"}, {"small_igh": r"w[456]<[34],false>", "mixed_small": r"w[456]<[34],true>"}),
     # the cherry-table form where the register-stack form would run: fused, assembly walk (two-site waves) / N-aware C++ walk
     ({"LH_K1_TABLES": "1"}, {"small_igh": r"ct[456]<4,false,true,true>", "mid60x400": r"ct[456]<4,false,true,true>",
-                             "mixed_small": r"ct[456]<4,true,true,false>", "mixed_60x400": r"ct[456]<4,true,\w+,false>"}),
+                             "mixed_small": r"ct[456]<4,true,true,true>", "mixed_60x400": r"ct[456]<4,true,true,true>"}),
     # its C++ walk instead of the assembly one
     ({"LH_K1_TABLES": "1", "LH_K1_CXX_WALK": "1"}, {"small_igh": r"ct[456]<4,false,true,false>",
+                                                   "mixed_small": r"ct[456]<4,true,true,false>",
+                                                   "mixed_60x400": r"ct[456]<4,true,true,false>",
                                                    "mid60x400": r"ct[456]<4,false,true,false>",
                                                    "wide100x600_r8": r"ct[456]<4,false,false,false>"}),
     # the same kernels walking the schedule without tables (every cherry its own op)
     ({"LH_K1_NO_TABLES": "1"}, {"small_igh": r"ct[456]<4,false,true,true>", "mid60x400": r"ct[456]<4,false,true,true>",
-                                "mixed_small": r"ct[456]<4,true,true,false>"}),
+                                "mixed_small": r"ct[456]<4,true,true,true>"}),
     # one workgroup per (sample, rate), K2a mixing the rates
     ({"LH_K1_NO_FUSE": "1"}, {"small_igh": r"ct[456]<4,false,false,true>", "mid60x400": r"ct[456]<4,false,false,true>",
-                              "mixed_small": r"ct[456]<4,true,false,false>", "mixed_60x400": r"ct[456]<4,true,false,false>"}),
+                              "mixed_small": r"ct[456]<4,true,false,true>", "mixed_60x400": r"ct[456]<4,true,false,true>"}),
     # the large-tree form (tip table a schedule segment at a time) on small trees, both register budgets
     ({"LH_K1_SEGMENTS": "1"}, {"small_igh": r"seg4<4,false>", "mid60x400": r"seg4<4,false>", "mixed_small": r"seg4<4,true>"}),
     ({"LH_K1_SEGMENTS": "1", "LH_K1_SEG_WAVES": "5"}, {"mid60x400": r"seg5<4,false>", "mixed_60x400": r"seg5<4,true>"}),

@@ -122,11 +122,13 @@ def test_generated_assembly_walk_is_reproducible():
     import os
     from tools import gen_walk_asm as g
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    body, clob, _ = g.render(2)
     csrc = os.path.join(root, "linearham_amd", "csrc")
-    assert open(os.path.join(csrc, "lh_prune_walk_asm_s2.inc")).read() == body
-    assert open(os.path.join(csrc, "lh_prune_walk_clobbers_s2.inc")).read() == clob
-    assert sorted(f for f in os.listdir(csrc) if f.endswith(".inc")) == ["lh_prune_walk_asm_s2.inc", "lh_prune_walk_clobbers_s2.inc"]
+    for n_aware, name in ((False, "lh_prune_walk_asm_s2.inc"), (True, "lh_prune_walk_asm_s2n.inc")):
+        body, clob, _ = g.render(2, n_aware)
+        assert open(os.path.join(csrc, name)).read() == body, name
+        assert open(os.path.join(csrc, "lh_prune_walk_clobbers_s2.inc")).read() == clob
+    assert sorted(f for f in os.listdir(csrc) if f.endswith(".inc")) == ["lh_prune_walk_asm_s2.inc", "lh_prune_walk_asm_s2n.inc",
+                                                                        "lh_prune_walk_clobbers_s2.inc"]
     from linearham_amd import build
     import inspect
     assert ".inc" in inspect.getsource(build.build_hip)

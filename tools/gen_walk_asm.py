@@ -44,6 +44,11 @@ import re
 OPTS = set(os.environ.get("LH_ASM_OPTS", "").split(","))   # timing experiments (variants are built into lib_exp/, never the product)
 P = 36
 SA, SB, SC = 8, 16, 24       # first SGPR of the state planes of the op's tips A, B, C (eight registers each; s32 is the stack pointer)
+# N-aware walk (alignments that mix N with bases): a third plane per site set says "this lane's state is N" (the two state
+# bits are 0 there), 12 registers per tip: A in s[8:19], B in s[20:31]; tip C of a table-x-tip op is fetched into A's
+# registers once the table look-up has consumed them.  An N tip reads the four ones behind the tip table(s) instead of a
+# column (lh_prune.hip tip_column); a cherry table has 5 x 5 entries.
+NSA, NSB = 8, 20
 
 
 class Regs:
@@ -97,9 +102,12 @@ PREFETCH = [                                       # the descriptor two ops ahea
 
 
 class Gen:
-    def __init__(self, S=2):
+    def __init__(self, S=2, n_aware=False):
         self.r = Regs(S)
         self.S = S
+        self.n_aware = n_aware
+        self.sa, self.sb = (NSA, NSB) if n_aware else (SA, SB)
+        self.sc = NSA if n_aware else SC
 
     def matvec(self, dst):
         """dst <- P a for all sites, rows interleaved (4 S independent chains), in the order of lh::matvec:
@@ -123,10 +131,11 @@ class Gen:
                     "s_load_dwordx16 s[52:67], s[74:75], s92 offset:0x40"]
         return ["s_load_dwordx16 s[36:51], s[74:75], s77 offset:0x0", "s_load_dwordx16 s[52:67], s[74:75], s77 offset:0x40"]
 
-    @staticmethod
-    def plane(st, s, bit):
-        """The 64-bit mask of bit `bit` of site set s in the state planes that start at SGPR `st`."""
-        return "s[%d:%d]" % (st + 4 * s + 2 * bit, st + 4 * s + 2 * bit + 1)
+    def plane(self, st, s, bit):
+        """The 64-bit mask of bit `bit` (2: the N flag of the N-aware walk) of site set s in the state planes that start at
+        SGPR `st`."""
+        per_set = 6 if self.n_aware else 4
+        return "s[%d:%d]" % (st + per_set * s + 2 * bit, st + per_set * s + 2 * bit + 1)
 
     def tip_column(self, dst, st, tip_expr):
         """dst <- tip-table columns of the tip whose number `tip_expr` leaves in s87, for the states in the planes s<st>..:
@@ -137,40 +146,60 @@ class Gen:
             out += ["v_cndmask_b32_e64 v%d, 0, 32, %s" % (r.tmp + s, self.plane(st, s, 0)),
                     "v_cndmask_b32_e64 v%d, 0, 64, %s" % (r.t2 + s, self.plane(st, s, 1)),
                     "v_add3_u32 v%d, v%d, v%d, s87" % (r.tmp + s, r.tmp + s, r.t2 + s)]
+            if self.n_aware:   # state N: the vector of ones (its LDS address in v<usite>)
+                out += ["v_cndmask_b32_e64 v%d, v%d, v%d, %s" % (r.tmp + s, r.tmp + s, r.usite, self.plane(st, s, 2))]
         for s in range(self.S):   # s81 = LDS address of the tip table
             out += ["ds_read_b128 v[%d:%d], v%d" % (dst + 8 * s, dst + 8 * s + 3, self.r.tmp + s),
                     "ds_read_b128 v[%d:%d], v%d offset:16" % (dst + 8 * s + 4, dst + 8 * s + 7, self.r.tmp + s)]
         return out
 
     def table_entry(self, dst):
-        """dst <- entry (sa, sb) of the next cherry table (global memory, written by this workgroup's prologue)."""
+        """dst <- entry (state A, state B) of the next cherry table (global memory, written by this workgroup's prologue)."""
         toff = "%[ctoff]" if "tabhit" in OPTS else "s76"   # tabhit: every look-up in table 0 (results wrong)
         r = self.r
         out = []
-        for s in range(self.S):   # byte offset = table + 128 state A + 32 state B
-            out += ["v_cndmask_b32_e64 v%d, 0, 32, %s" % (r.tmp + s, self.plane(SB, s, 0)),
-                    "v_cndmask_b32_e64 v%d, 0, 64, %s" % (r.t2 + s, self.plane(SB, s, 1)),
-                    "v_add3_u32 v%d, v%d, v%d, %s" % (r.tmp + s, r.tmp + s, r.t2 + s, toff),
-                    "v_cndmask_b32_e64 v%d, 0, v%d, %s" % (r.t2 + s, r.c128, self.plane(SA, s, 0)),
-                    "v_cndmask_b32_e64 v%d, 0, v%d, %s" % (r.t3 + s, r.c256, self.plane(SA, s, 1)),
-                    "v_add3_u32 v%d, v%d, v%d, v%d" % (r.tmp + s, r.tmp + s, r.t2 + s, r.t3 + s)]
         pol = " nt" if "tabnt" in OPTS else " sc1" if "tabsc1" in OPTS else " sc0 sc1" if "tabsc" in OPTS else ""   # cache-policy experiments
+        for s in range(self.S):
+            if self.n_aware:   # 5 x 5 entries: byte offset = table + 160 state A + 32 state B, N = 4 (s92 holds 160)
+                out += ["v_cndmask_b32_e64 v%d, 0, 32, %s" % (r.tmp + s, self.plane(self.sb, s, 0)),
+                        "v_cndmask_b32_e64 v%d, 0, 64, %s" % (r.t2 + s, self.plane(self.sb, s, 1)),
+                        "v_add3_u32 v%d, v%d, v%d, %s" % (r.tmp + s, r.tmp + s, r.t2 + s, toff),
+                        "v_cndmask_b32_e64 v%d, 0, 1, %s" % (r.t2 + s, self.plane(self.sb, s, 2)),
+                        "v_lshl_add_u32 v%d, v%d, 7, v%d" % (r.tmp + s, r.t2 + s, r.tmp + s),
+                        "v_cndmask_b32_e64 v%d, 0, 1, %s" % (r.t2 + s, self.plane(self.sa, s, 0)),
+                        "v_cndmask_b32_e64 v%d, 0, 2, %s" % (r.t3 + s, self.plane(self.sa, s, 1)),
+                        "v_or_b32_e32 v%d, v%d, v%d" % (r.t2 + s, r.t2 + s, r.t3 + s),
+                        "v_cndmask_b32_e64 v%d, v%d, 4, %s" % (r.t2 + s, r.t2 + s, self.plane(self.sa, s, 2)),
+                        "v_mad_u32_u24 v%d, v%d, s92, v%d" % (r.tmp + s, r.t2 + s, r.tmp + s)]
+            else:              # byte offset = table + 128 state A + 32 state B
+                out += ["v_cndmask_b32_e64 v%d, 0, 32, %s" % (r.tmp + s, self.plane(self.sb, s, 0)),
+                        "v_cndmask_b32_e64 v%d, 0, 64, %s" % (r.t2 + s, self.plane(self.sb, s, 1)),
+                        "v_add3_u32 v%d, v%d, v%d, %s" % (r.tmp + s, r.tmp + s, r.t2 + s, toff),
+                        "v_cndmask_b32_e64 v%d, 0, v%d, %s" % (r.t2 + s, r.c128, self.plane(self.sa, s, 0)),
+                        "v_cndmask_b32_e64 v%d, 0, v%d, %s" % (r.t3 + s, r.c256, self.plane(self.sa, s, 1)),
+                        "v_add3_u32 v%d, v%d, v%d, v%d" % (r.tmp + s, r.tmp + s, r.t2 + s, r.t3 + s)]
         for s in range(self.S):
             out += ["global_load_dwordx4 v[%d:%d], v%d, s[74:75]%s" % (dst + 8 * s, dst + 8 * s + 3, r.tmp + s, pol),
                     "global_load_dwordx4 v[%d:%d], v%d, s[74:75] offset:16%s" % (dst + 8 * s + 4, dst + 8 * s + 7, r.tmp + s, pol)]
-        return out + ["s_add_i32 s76, s76, 0x200"]
+        return out + ["s_add_i32 s76, s76, %s" % ("0x320" if self.n_aware else "0x200")]
+
+    def plane_load(self, dst):
+        """The planes of the tip whose number is in s87 into s<dst>.. (s80: bytes per tip)."""
+        o = ["s_mul_i32 s87, s87, s80", "s_load_dwordx8 s[%d:%d], s[78:79], s87" % (dst, dst + 7)]
+        if self.n_aware:
+            o += ["s_load_dwordx4 s[%d:%d], s[78:79], s87 offset:0x20" % (dst + 8, dst + 11)]
+        return o
 
     def states(self, dx, dy, split=False):
         """Tip states of the op whose descriptor is s<dx>, s<dy>, as bit planes into s[8:31]: tip A always, B and C on
-        their flags.  Scalar loads: they are complete behind the s_waitcnt lgkmcnt(0) at the top of the next op."""
+        their flags (the N-aware walk fetches C later: table_x_tip).  Scalar loads: they are complete behind the
+        s_waitcnt lgkmcnt(0) at the top of the next op."""
         if "nostate" in OPTS:   # no state traffic at all (the planes keep what they hold; results wrong)
             return ([], []) if split else []
-
-        def load(dst):
-            return ["s_mul_i32 s87, s87, s80", "s_load_dwordx8 s[%d:%d], s[78:79], s87" % (dst, dst + 7)]
-        part_a = ["s_lshr_b32 s87, s%d, 16" % dx] + load(SA)
-        part_bc = (["s_bitcmp1_b32 s%d, 13" % dx, "s_cbranch_scc0 1f", "s_and_b32 s87, s%d, 0xffff" % dy] + load(SB) +
-                   ["1:", "s_bitcmp1_b32 s%d, 14" % dx, "s_cbranch_scc0 2f", "s_lshr_b32 s87, s%d, 16" % dy] + load(SC) + ["2:"])
+        part_a = ["s_lshr_b32 s87, s%d, 16" % dx] + self.plane_load(self.sa)
+        part_bc = ["s_bitcmp1_b32 s%d, 13" % dx, "s_cbranch_scc0 1f", "s_and_b32 s87, s%d, 0xffff" % dy] + self.plane_load(self.sb) + ["1:"]
+        if not self.n_aware:
+            part_bc += ["s_bitcmp1_b32 s%d, 14" % dx, "s_cbranch_scc0 2f", "s_lshr_b32 s87, s%d, 16" % dy] + self.plane_load(self.sc) + ["2:"]
         if split:
             return part_a, part_bc
         return part_a + part_bc
@@ -203,6 +232,8 @@ class Gen:
              "s_mov_b32 s96, 0x2ff00000", "s_movk_i32 s97, 0x100"])
         add(["v_mov_b32_e32 v%d, 0" % (r.scal + i) for i in range((S + 1) // 2)])
         add(["v_mov_b32_e32 v%d, 0x80" % r.c128, "v_mov_b32_e32 v%d, 0x100" % r.c256])
+        if self.n_aware:
+            add(["v_mov_b32_e32 v%d, %%[ones]" % r.usite, "s_movk_i32 s92, 0xa0"])
         for i in range(4 * S):
             add(["v_mov_b32_e32 v%d, 0" % (A + 2 * i), "v_mov_b32_e32 v%d, 0x3ff00000" % (A + 2 * i + 1)])
         add(["s_cmp_lt_i32 s83, 1", "s_cbranch_scc1 lh_walk_end",
@@ -216,7 +247,7 @@ class Gen:
              "s_cmp_eq_u32 s87, 1", "s_cbranch_scc1 lh_walk_tip", "s_cmp_eq_u32 s87, 4", "s_cbranch_scc1 lh_walk_ctab",
              "s_cmp_eq_u32 s87, 2", "s_cbranch_scc1 lh_walk_pop", "s_cmp_eq_u32 s87, 3", "s_cbranch_scc1 lh_walk_ctip"])
         # cherry: a = tipcol_A * tipcol_B (the accumulator pushed first if the op says so)
-        cherry = self.tip_column(U, SA, tip_a) + self.tip_column(X, SB, tip_b)
+        cherry = self.tip_column(U, self.sa, tip_a) + self.tip_column(X, self.sb, tip_b)
         add(["; cherry", "s_bfe_u32 s88, s68, 0x50004", "s_cmp_eq_u32 s88, 0", "s_cbranch_scc1 lh_walk_cherry_np"])
         add(self.push_block("lh_walk_cherry"))
         tipwait = "s_waitcnt lgkmcnt(0)"
@@ -224,7 +255,9 @@ class Gen:
         add(["lh_walk_cherry_np:"] + cherry + [tipwait] + ROTATE + PREFETCH + self.product(U, X) + self.states(70, 71) +
             ["s_branch lh_walk_tail"])
         # cherry table x tip column
-        ctip = self.table_entry(U) + self.tip_column(X, SC, tip_c)
+        # (N-aware: tip C's planes into tip A's registers, which the look-up has consumed)
+        late_c = (["s_lshr_b32 s87, s69, 16"] + self.plane_load(self.sc) + ["s_waitcnt lgkmcnt(0)"]) if self.n_aware else []
+        ctip = self.table_entry(U) + late_c + self.tip_column(X, self.sc, tip_c)
         add(["; cherry table x tip column", "lh_walk_ctip:", "s_bfe_u32 s88, s68, 0x50004", "s_cmp_eq_u32 s88, 0",
              "s_cbranch_scc1 lh_walk_ctip_np"])
         add(self.push_block("lh_walk_ctip"))
@@ -235,7 +268,7 @@ class Gen:
         st_a, st_bc = self.states(70, 71, split=True)
         mv = self.matvec(X)
         half = len(mv) // 2
-        add(["; tip into accumulator", "lh_walk_tip:"] + self.p_load() + self.tip_column(U, SA, tip_a) + ["s_waitcnt lgkmcnt(0)"] +
+        add(["; tip into accumulator", "lh_walk_tip:"] + self.p_load() + self.tip_column(U, self.sa, tip_a) + ["s_waitcnt lgkmcnt(0)"] +
             ROTATE + weave(mv[:half], P_ADV + PREFETCH + st_a) + st_bc + mv[half:] +
             self.product(U, X) + ["s_branch lh_walk_tail"])
         # cherry table into accumulator: a = table * (P a)
@@ -275,12 +308,13 @@ class Gen:
         return L
 
 
-def render(S=2):
-    """(text of lh_prune_walk_asm_s<S>.inc, text of lh_prune_walk_clobbers_s<S>.inc, summary line)"""
-    g = Gen(S)
+def render(S=2, n_aware=False):
+    """(text of lh_prune_walk_asm_s<S>[n].inc, text of lh_prune_walk_clobbers_s<S>.inc, summary line)"""
+    g = Gen(S, n_aware)
     lines = g.generate()
     body = ["// GENERATED by tools/gen_walk_asm.py (register map and rationale there) -- do not edit by hand.\n",
-            "// gfx950 assembly of K1's schedule walk, %d sites per lane, alignments without N: the body of one asm statement.\n" % S,
+            "// gfx950 assembly of K1's schedule walk, %d sites per lane, alignments %s: the body of one asm statement.\n" % (
+                S, "that mix N with bases" if n_aware else "without N"),
             "// Vector registers v5 .. v%d (lh_prune_walk_clobbers_s%d.inc lists them for the statement).\n" % (g.r.last, S)]
     for ln in lines:
         ln = ln.replace("%%", "%")
@@ -297,13 +331,14 @@ def render(S=2):
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outdir = os.environ.get("LH_ASM_OUT") or os.path.join(root, "linearham_amd", "csrc")
-    body, clob, summary = render(2)
-    out = os.path.join(outdir, "lh_prune_walk_asm_s2.inc")
-    with open(out, "w") as f:
-        f.write(body)
-    with open(os.path.join(outdir, "lh_prune_walk_clobbers_s2.inc"), "w") as f:
-        f.write(clob)
-    print("wrote %s: %s" % (out, summary))
+    for n_aware in (False, True):
+        body, clob, summary = render(2, n_aware)
+        out = os.path.join(outdir, "lh_prune_walk_asm_s2%s.inc" % ("n" if n_aware else ""))
+        with open(out, "w") as f:
+            f.write(body)
+        with open(os.path.join(outdir, "lh_prune_walk_clobbers_s2.inc"), "w") as f:   # (the same registers in both)
+            f.write(clob)
+        print("wrote %s: %s" % (out, summary))
 
 
 if __name__ == "__main__":
