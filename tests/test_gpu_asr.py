@@ -131,6 +131,24 @@ def test_asr_error_paths(hip, data_dir):
     fam.close()
 
 
+def test_asr_rejected_device_schedule_gets_the_sentinel():
+    """lh_asr_batch_device on a batch whose DEVICE-resident schedules hold one malformed sample (a pop from the wrong stack
+    slot: every field in range): that sample's anc and rate_choice rows come back as 0xff in every byte -- states are bytes
+    and have no NaN --, lh_family_status reports it, the other samples keep the draws of the clean batch.  (Its own
+    process: the device buffers are torch tensors, and torch brings its own HIP runtime, which has to come up first.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "asr_device_worker.py")], capture_output=True, text=True,
+                       timeout=300, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["clean_status"] == "" and res["clean_max_state"] <= 3
+    assert "malformed schedule" in res["bad_status"]
+    assert res["victim_all_ff"] and res["others_unchanged"]
+
+
 def test_asr_committed_vectors(hip, data_dir):
     """The HIP path against the committed oracle-derived vectors (tests/golden/asr_goldens.json)."""
     import json

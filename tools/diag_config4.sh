@@ -1,7 +1,9 @@
 #!/bin/bash
 # Counter sets of K1 on the configs[4] shape for a list of environment settings (one rocprofv3 --pmc pass per counter
 # group and setting, no tracing); per-launch averages of the prune kernels go to gpurun_out/diag_config4_<label>.txt.
-# usage (GPU box, repo root): bash tools/diag_config4.sh "seg4:" "ctseg:LH_K1_CT_SEGMENTS=1"
+# usage (GPU box, repo root): bash tools/diag_config4.sh "seg4:" ["label:VAR=1 ..."]
+# (profiles/r04_config4_pmc_*.txt were made with `"seg4:" "ctseg:LH_K1_CT_SEGMENTS=1"` on the round-3 build 0b72f3b; the
+# segment-wise assembly form that switch selected left the source in round 4.)
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
