@@ -612,8 +612,11 @@ def worker(args, rank, local_rank, world):
                          "flop_per_launch": k1_flops, "evals_per_launch": per_launch, "avg_launch_ms": prune_ms,
                          "peak_source": "half the 157.3 TFLOP/s FP32 vector peak of MI355X_MICROARCH.md (FP64 FMAs "
                                         "issue at half rate; the guide lists no FP64 figure)",
-                         "note": "strict flop count (mul/add 1, FMA 2) of the arithmetic in lh_prune.hip per (site "
-                                 "pattern, rate); the kernel keeps CLVs in registers, so HBM is not its bound: "
+                         "note": "strict flop count (mul/add 1, FMA 2) of the pruning arithmetic per (site pattern, rate) as the "
+                                 "schedule states it (lh_prune.hip's register-stack walk executes exactly these; the cherry-table "
+                                 "form that fused shapes run since round 4 folds a quarter of the ops into table look-ups and executes "
+                                 "fewer: `achieved` prices the ALGORITHM's flops against the launch time); the kernel keeps CLVs in "
+                                 "registers, so HBM is not its bound: "
                                  "SURVEY 8(d)'s CLV-streaming model (%d B per evaluation) would need %.0f GB/s at "
                                  "this launch time -- a statement about the model, not about the kernel"
                                  % (model_bytes_per_eval, model_bytes_per_eval * per_launch / (prune_ms * 1e-3) / 1e9)},

@@ -46,11 +46,11 @@ def test_default_forms_without_n():
     rep = _run({}, ["small_igh", "mid60x400", "balanced64", "wide100x600", "wide100x600_r8"])
     # at most 128 patterns (one wave per rate): the assembly walk over cherry tables, the few patterns in a two-site wave
     _expect(rep, "small_igh", r"ct[456]<4,false,true,true>", n_patterns=("le", 128))
-    _expect(rep, "mid60x400", r"w[456]<[34],false>", n_patterns=("gt", 128))            # two-site waves, fused (configs[2]'s form)
+    _expect(rep, "mid60x400", r"ct[456]<4,false,true,true>", n_patterns=("gt", 128))    # two waves per rate, fused (configs[2]'s form)
     # a perfectly balanced 64-leaf tree: five pending siblings, i.e. slots beyond the register slot live in scratch memory
     _expect(rep, "balanced64", r"ct[456]<16,false,true,true>", max_depth=("ge", 5))
     # more than 256 patterns: three two-site waves per rate, all four rates in one workgroup of twelve waves
-    _expect(rep, "wide100x600", r"w[456]<[34],false>", n_patterns=("gt", 256))
+    _expect(rep, "wide100x600", r"ct[456]<4,false,true,true>", n_patterns=("gt", 256))
     # the same family with eight rate categories: 24 waves do not fit one workgroup -- a workgroup per (sample, rate), the
     # assembly walk over cherry tables, K2a mixing the rates
     _expect(rep, "wide100x600_r8", r"ct[456]<4,false,false,true>", n_patterns=("gt", 256))
@@ -66,14 +66,17 @@ def test_default_forms_with_n_inside_columns():
     _expect(rep, "mixed_small", r"ct[456]<4,true,true,true>", n_patterns=("le", 128))    # small family: N-aware assembly walk
     _expect(rep, "mixed_igk", r"ct[456]<4,true,true,true>", n_patterns=("le", 128))
     _expect(rep, "mixed_120", r"seg4<4,true>")                                            # 121 tips: segmented tip table
-    _expect(rep, "mixed_60x400", r"w[456]<[34],true>", n_patterns=("gt", 256))          # twelve waves per workgroup
+    _expect(rep, "mixed_60x400", r"ct[456]<4,true,true,true>", n_patterns=("gt", 256))   # twelve waves per workgroup
     _expect(rep, "mixed_balanced64", r"ct[456]<16,true,true,true>", max_depth=("ge", 5))
     _expect(rep, "mixed_500", r"seg4<4,true>")                                            # 11 segments
 
 
 @pytest.mark.parametrize("hook,expect", [
-    # the register-stack form on a small family (one one-site wave per rate), which by itself takes the cherry-table form
-    ({"LH_K1_STACK": "1"}, {"small_igh": r"w[456]<[34],false>", "mixed_small": r"w[456]<[34],true>"}),
+    # the register-stack form on fused shapes (which by themselves take the cherry-table form): one one-site wave per rate,
+    # two two-site waves, twelve waves per workgroup, with and without N
+    ({"LH_K1_STACK": "1"}, {"small_igh": r"w[456]<[34],false>", "mixed_small": r"w[456]<[34],true>",
+                            "mid60x400": r"w[456]<[34],false>", "wide100x600": r"w[456]<[34],false>",
+                            "mixed_60x400": r"w[456]<[34],true>"}),
     # the cherry-table form where the register-stack form would run: fused, assembly walk (two-site waves) / N-aware C++ walk
     ({"LH_K1_TABLES": "1"}, {"small_igh": r"ct[456]<4,false,true,true>", "mid60x400": r"ct[456]<4,false,true,true>",
                              "mixed_small": r"ct[456]<4,true,true,true>", "mixed_60x400": r"ct[456]<4,true,true,true>"}),

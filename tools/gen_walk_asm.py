@@ -281,9 +281,16 @@ class Gen:
             self.matvec(X) + ["s_waitcnt vmcnt(0)"] + self.product(U, X) + self.states(70, 71) +
             ["s_branch lh_walk_tail", "lh_walk_pop0:", "s_waitcnt lgkmcnt(0)"] + ROTATE + weave(mv[:half], P_ADV + PREFETCH + st_a) + st_bc +
             mv[half:] + self.product(ST0, X))
-        # tail: 2^256 rescaling test on the high words (libpll's per-site scalers), next op
+        # tail: 2^256 rescaling test on the high words (libpll's per-site scalers), next op.
+        # The test runs after every FOURTH op and after the last one, and rescales until the largest entry is back above
+        # 2^-256: multiplying by 2^256 is exact, an op lowers the largest entry by 2^-73 at worst (two tip columns across
+        # 1e-6 branches at the slowest rate), so four ops stay 400 binades clear of the subnormals and the final (value,
+        # count) pair is the one the test after every op leaves -- libpll's per-node scaling reaches the same pair
+        # (round 4: six of ~65 vector instructions per op were this test).
         add(["; ---- rescaling test, next op ------------------------------------------------------------------------",
-             "lh_walk_tail:"])
+             "lh_walk_tail:", "s_add_i32 s87, s82, 1", "s_cmp_ge_i32 s87, s83", "s_cbranch_scc1 lh_walk_test",
+             "s_and_b32 s87, s82, 3", "s_cmp_eq_u32 s87, 3", "s_cbranch_scc0 lh_walk_back",
+             "lh_walk_test:"])
         for s in range(S):
             h = [A + 8 * s + 2 * i + 1 for i in range(4)]
             add(["v_max_u32_e32 v%d, v%d, v%d" % (r.tmp + s, h[0], h[1]),
@@ -296,9 +303,18 @@ class Gen:
              "s_cbranch_scc1 lh_walk_top", "s_branch lh_walk_end",
              "lh_walk_rescale:"])
         for s in range(S):
+            # (an all-zero CLV -- impossible data -- is rescaled once and left: its high words stay 0, the loop would not end)
             add(["v_cmp_gt_u32_e32 vcc, s96, v%d" % (r.tmp + s), "s_nop 1", "s_and_saveexec_b64 s[94:95], vcc"])
             add(["v_ldexp_f64 %s, %s, s97" % (pair(A + 8 * s + 2 * i), pair(A + 8 * s + 2 * i)) for i in range(4)])
             add(["v_add_u32_e32 v%d, %s, v%d" % (r.scal + s // 2, "0x10000" if s & 1 else "1", r.scal + s // 2), "s_mov_b64 exec, s[94:95]"])
+        # again, unless nothing but zeros is left below the threshold (max high word 0)
+        for s in range(S):
+            h = [A + 8 * s + 2 * i + 1 for i in range(4)]
+            add(["v_max_u32_e32 v%d, v%d, v%d" % (r.tmp + s, h[0], h[1]),
+                 "v_max3_u32 v%d, v%d, v%d, v%d" % (r.tmp + s, h[2], h[3], r.tmp + s)])
+            add(["v_cmp_eq_u32_e32 vcc, 0, v%d" % (r.tmp + s), "v_cndmask_b32_e64 v%d, v%d, -1, vcc" % (r.tmp + s, r.tmp + s)])
+        add(["v_min_u32_e32 v%d, v%d, v%d" % (U, r.tmp, r.tmp + 1), "v_cmp_gt_u32_e32 vcc, s96, v%d" % U,
+             "s_cbranch_vccnz lh_walk_rescale"])
         add(["s_branch lh_walk_back",
              "; ---- results to the private array: a (32 S bytes), then the packed scaler counts ------------------",
              "lh_walk_end:", "s_waitcnt vmcnt(0) lgkmcnt(0)"])
