@@ -43,7 +43,7 @@ WORKLOADS = {
     "config2_ragged": "the configs[2] family with ragged reads: every sequence N-padded by 0-30 sites at either end, i.e. N "
                       "inside alignment columns (not the headline workload; its rate is the extra key mixed_n_evals_per_s)",
 }
-PMC_PROFILE = {"config2": "r04_bench_pmc_per_launch.json", "config4": "r03_config4_pmc_per_launch.json"}
+PMC_PROFILE = {"config2": "r04b_bench_pmc_per_launch.json", "config4": "r03_config4_pmc_per_launch.json"}
 GEN_VERSION = 2                # bump when tools/synth_family.py changes what it writes
 
 

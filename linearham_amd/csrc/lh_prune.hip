@@ -30,17 +30,17 @@
 //  * HBM traffic is therefore ~T bytes of tip states per site (L2-resident, shared by all samples)
 //    and 5 doubles out, instead of the 2*I*R*32 bytes per column of a CLV-streaming kernel.
 //
-// What is in this file (round 3):
-//  * prune_wave / prune_body / prune_kernel_w6,w5,w4 -- the register-stack form with all R rates in one workgroup and
-//    the rate mixture formed in the kernel: what configs[2]-like families run.  Its schedules are checked by
-//    schedule_ranks_kernel in front of it (fields and ranks; the verdict in hdr).
-//  * prune_kernel_seg / seg4 -- the same walk for large trees: the tip table built a schedule segment at a time
-//    (SegCtx); checked by schedule_fields_kernel.
-//  * K0c schedule_rewrite_kernel + prune_wave_ct / prune_wave_asm / prune_body_ct / prune_kernel_ct* -- the
+// What is in this file (round 4):
+//  * K0c schedule_rewrite_kernel + prune_wave_ct / prune_wave_asm / prune_body_ct / prune_kernel_ct6,ct5,ct4 -- the
 //    cherry-table form: schedules rewritten into walk ops (lh_device.h), cherries as tables in the scratch region, the
-//    walk in hand-written assembly (lh_prune_walk_asm_*.inc, generated by tools/gen_walk_asm.py).  Runs the shapes the
-//    first form cannot (rates that do not fit one workgroup, stack depth > 4, the ancestral-sequence step's unmixed
-//    planes); measured against it on configs[2] in DESIGN.md section 4 / profiles/r03_k1_walk_experiments.txt.
+//    walk in generated assembly (lh_prune_walk_asm_s2.inc, _s2n.inc for alignments with N; tools/gen_walk_asm.py), tip
+//    states as bit planes through the scalar path.  What configs[2] and every other family whose tip tables fit a
+//    workgroup's share of LDS run, and any stack depth up to 16 (profiles/r04_k1_programme.txt).
+//  * prune_wave / prune_body / prune_kernel_w6,w5,w4 -- the register-stack form with all R rates in one workgroup and
+//    the rate mixture formed in the kernel: round 3's default, now behind LH_K1_STACK=1 (a second implementation the
+//    parity tests hold against the oracle).  Its schedules are checked by schedule_stack_check_kernel in front of it.
+//  * prune_kernel_seg / seg4 -- the register-stack walk for large trees: the tip table built a schedule segment at a
+//    time (SegCtx); same check kernel.
 //  * launch_prune -- the choice between them, and the debug switches (lh::DebugOptions).
 #include <cstdlib>
 
