@@ -435,22 +435,25 @@ typedef __attribute__((address_space(3))) const char* lds_ptr;
 // fetches 32 bytes per tip and op with a scalar load.
 // kN: alignments that mix N with bases -- a third plane per site set flags the lanes whose state is N (6 masks per tip and
 // block instead of 4), and such a tip reads the four ones at `ones` (LDS) instead of a column; lh_prune_walk_asm_s2n.inc.
-template <int kDepth, bool kN>
-__device__ __forceinline__ void prune_wave_asm(int block128, const uint64_t* __restrict__ planes, int n_blocks, int n_w,
+template <int kDepth, bool kN, int S>
+__device__ __forceinline__ void prune_wave_asm(int block64, const uint64_t* __restrict__ planes, int n_blocks, int n_w,
                                                const WalkOp* __restrict__ wops, pmat_ptr pm, unsigned ctoff,
                                                const double* tiptab, const double* naive_tab, const double* ones,
-                                               const double* __restrict__ p4, double (&lik)[2][5], int (&scl)[2]) {
-  constexpr int S = 2;
+                                               const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
+  static_assert(S == 1 || S == 2, "one or two sites per lane");
   __attribute__((aligned(16))) double out_mem[4 * S + 2];                                   // a[S][4], then the packed scaler counts
   __attribute__((aligned(16))) double deep_mem[(kDepth > 1 ? kDepth - 1 : 1) * 4 * S];     // stack slots 1.. : [slot][site][4]
   // tip t (MSA row t - 1) of this wave's block at planes_w + t * pstride bytes; a wave wholly past the last pattern (its
-  // results are not stored) reads the last block
+  // results are not stored) reads the last block.  block64: the wave's first pattern / 64 -- a two-site wave starts a block
+  // of 128, a one-site wave (S = 1: a remainder of up to 64 patterns) takes the first or the second site set of its block:
+  // its loads start at that set's masks (and run over into the next block's, or the array's padding: never used).
   constexpr int kMasks = kN ? 6 : 4;  // 64-bit masks per (tip, block)
-  const int blk = min(block128, n_blocks - 1);
-  const uint64_t* planes_w = planes + ((ptrdiff_t)blk - (ptrdiff_t)n_blocks) * kMasks;
+  const int blk = min(block64 >> 1, n_blocks - 1);
+  const int set = S == 1 ? (block64 & 1) : 0;
+  const uint64_t* planes_w = planes + ((ptrdiff_t)blk - (ptrdiff_t)n_blocks) * kMasks + set * (kMasks / 2);
   const unsigned pstride = (unsigned)n_blocks * (unsigned)(kMasks * 8);
   const unsigned tip_lds = (unsigned)(size_t)(lds_ptr)tiptab;
-  if constexpr (kN) {
+  if constexpr (kN && S == 2) {
     const unsigned ones_lds = (unsigned)(size_t)(lds_ptr)ones;
     asm volatile(
 #include "lh_prune_walk_asm_s2n.inc"
@@ -460,7 +463,7 @@ __device__ __forceinline__ void prune_wave_asm(int block128, const uint64_t* __r
         : "memory", "vcc", "scc",
 #include "lh_prune_walk_clobbers_s2.inc"
     );
-  } else {
+  } else if constexpr (S == 2) {
     asm volatile(
 #include "lh_prune_walk_asm_s2.inc"
         :
@@ -468,6 +471,25 @@ __device__ __forceinline__ void prune_wave_asm(int block128, const uint64_t* __r
           [tip] "s"(tip_lds), [out] "v"((private_ptr)out_mem), [deep] "v"((private_ptr)deep_mem)
         : "memory", "vcc", "scc",
 #include "lh_prune_walk_clobbers_s2.inc"
+    );
+  } else if constexpr (kN) {
+    const unsigned ones_lds = (unsigned)(size_t)(lds_ptr)ones;
+    asm volatile(
+#include "lh_prune_walk_asm_s1n.inc"
+        :
+        : [nw] "s"(n_w), [wops] "s"(wops), [pm] "s"(pm), [ctoff] "s"(ctoff), [planes] "s"(planes_w), [pstride] "s"(pstride),
+          [tip] "s"(tip_lds), [ones] "v"(ones_lds), [out] "v"((private_ptr)out_mem), [deep] "v"((private_ptr)deep_mem)
+        : "memory", "vcc", "scc",
+#include "lh_prune_walk_clobbers_s1.inc"
+    );
+  } else {
+    asm volatile(
+#include "lh_prune_walk_asm_s1.inc"
+        :
+        : [nw] "s"(n_w), [wops] "s"(wops), [pm] "s"(pm), [ctoff] "s"(ctoff), [planes] "s"(planes_w), [pstride] "s"(pstride),
+          [tip] "s"(tip_lds), [out] "v"((private_ptr)out_mem), [deep] "v"((private_ptr)deep_mem)
+        : "memory", "vcc", "scc",
+#include "lh_prune_walk_clobbers_s1.inc"
     );
   }
   double a[S][4];
@@ -1157,11 +1179,12 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
   // Prologue, first half: the P-matrices of this (sample, rate), one thread per matrix (K0c left every matrix's
   // branch length in the order they are stored): the walk's inner-branch matrices to the scratch area, the tip
   // branches' into the LDS tip table (column by column, as the walk gathers them), the cherry branches' for the
-  // tables.  Without N a table's four state rows are built by the four lanes of a QUAD, and the quad's first lane
-  // computes the cherry branch's matrix here and keeps it in registers: it reaches the other three through DPP in the
-  // second half, not through memory (tables beyond nthr / 4, and all tables of alignments with N, take the path
-  // through the scratch area).
-  constexpr bool kQuad = !kN;
+  // tables.  A table's four base rows are built by the four lanes of a QUAD, and the quad's first lane computes the
+  // cherry branch's matrix here and keeps it in registers: it reaches the other three through DPP in the second half,
+  // not through memory (tables beyond nthr / 4 take the path through the scratch area).  With N in the alignment a
+  // table has a fifth row and column: the quad's lanes share the fifth row's entries (round 4; such tables all took
+  // the scratch path before).
+  constexpr bool kQuad = true;
   const int n_q = kQuad ? min(n_tab, nthr >> 2) : 0;
   const bool pc_lane = kQuad && (rtid & 3) == 0 && (rtid >> 2) < n_q;
   int4 tcell = make_int4(1, 1, 0, 0);
@@ -1243,7 +1266,24 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
       const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(pcq[i]), 0, 0xf, 0xf, true);
       pc[i] = __hiloint2double(hi, lo);
     }
-    if ((rtid >> 2) < n_q) build_rows(pc, rtid >> 2, rtid & 3, tcell.x, tcell.y);
+    if ((rtid >> 2) < n_q) {
+      build_rows(pc, rtid >> 2, rtid & 3, tcell.x, tcell.y);
+      if constexpr (kN) {
+        // the fifth row (first tip N: a vector of ones): its entries go to the quad's four lanes one each, the corner to
+        // the last lane -- the very operations build_rows performs for sy = 4
+        const int sz = rtid & 3;
+        double2* o = reinterpret_cast<double2*>(ctab) + ((size_t)(rtid >> 2) * E + 4 * SY) * 2;
+        for (int k = sz; k < SY; k += 4) {
+          double pz[4], pr[4], x[4];
+          tip_column<kN>(tiptab, tcell.y, k, pz, ones_off);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pr[i] = 1.0 * pz[i];
+          matvec_v(pc, pr, x);
+          o[2 * k] = make_double2(x[0], x[1]);
+          o[2 * k + 1] = make_double2(x[2], x[3]);
+        }
+      }
+    }
   }
   for (int it = rtid; it < (n_tab - n_q) * SY; it += nthr) {
     const int c = n_q + it / SY, sy = it - (it / SY) * SY;
@@ -1278,8 +1318,8 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
     site0 = tile0 + wave * (64 * kS) + lane;
     n_own = kS;
     if constexpr (kAsm)
-      prune_wave_asm<kDepth, kN>((tile0 + wave * (64 * kS)) >> 7, planes, (L + 127) >> 7, n_w, wops + (size_t)sample * n_ops, pm,
-                                 (unsigned)((T - 3 > 0 ? T - 3 : 0) * 128), tiptab, naive_tab, ones, p4, lik, scl);
+      prune_wave_asm<kDepth, kN, kS>((tile0 + wave * (64 * kS)) >> 6, planes, (L + 127) >> 7, n_w, wops + (size_t)sample * n_ops, pm,
+                                     (unsigned)((T - 3 > 0 ? T - 3 : 0) * 128), tiptab, naive_tab, ones, p4, lik, scl);
     else
       prune_wave_ct<kDepth, kS, kN>(site0, site_end, msa, L, n_w, desc, pm, tiptab, ctab, naive_tab, ones_off, p4, lik, scl);
   } else {
@@ -1287,7 +1327,12 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
     n_own = 1;
     double lik1[1][5];
     int scl1[1];
-    prune_wave_ct<kDepth, 1, kN>(site0, site_end, msa, L, n_w, desc, pm, tiptab, ctab, naive_tab, ones_off, p4, lik1, scl1);
+    if constexpr (kAsm)
+      prune_wave_asm<kDepth, kN, 1>((tile0 + n2 * (64 * kS) + (wave - n2) * 64) >> 6, planes, (L + 127) >> 7, n_w,
+                                    wops + (size_t)sample * n_ops, pm, (unsigned)((T - 3 > 0 ? T - 3 : 0) * 128), tiptab, naive_tab,
+                                    ones, p4, lik1, scl1);
+    else
+      prune_wave_ct<kDepth, 1, kN>(site0, site_end, msa, L, n_w, desc, pm, tiptab, ctab, naive_tab, ones_off, p4, lik1, scl1);
 #pragma unroll
     for (int b = 0; b < 5; ++b) lik[0][b] = lik1[0][b];
     scl[0] = scl1[0];
@@ -1488,14 +1533,8 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   const bool seg = big && max_depth <= 4;
   const size_t seg_bytes = (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) + ones_bytes;
   size_t lds = fused ? fused_lds : seg ? seg_bytes : tip_bytes + ones_bytes + tail_bytes;
-  // The assembly walk takes a remainder of up to 64 patterns as one more TWO-site wave (its second site set repeats the
-  // last pattern; nothing of it is stored) instead of leaving it to a one-site wave of the C++ walk, which would then be
-  // the workgroup's slowest: 57 patterns 4.75 -> 4.20 ms per 49 152 (profiles/r04_k1_small_families.txt).
-  if (!stack_fused && !seg && use_asm && n1 == 1) {
-    ++n2;
-    n1 = 0;
-    if (fused) lds = std::max((size_t)R * tip_bytes + ones_bytes + tail_bytes, (size_t)R * (size_t)n2 * 128 * (5 * sizeof(double) + sizeof(int)));
-  }
+  // (A remainder of up to 64 patterns rides in a ONE-site wave: the assembly walk has a one-site variant -- 45 vector
+  // registers, half the arithmetic per op; lh_prune_walk_asm_s1.inc.)
   if (lds > 160 * 1024) {
     snprintf(g_prune_error, sizeof(g_prune_error),
              "K1: a tree of %d tips with stack depth %d needs %zu bytes of LDS in the cherry-table form (160 KB per CU)", T, max_depth, lds);

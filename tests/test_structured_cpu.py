@@ -115,7 +115,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_generated_assembly_walk_is_reproducible():
-    """linearham_amd/csrc/lh_prune_walk_asm_s2.inc and its clobber list are GENERATED text (tools/gen_walk_asm.py): the
+    """linearham_amd/csrc/lh_prune_walk_asm_s{2,1}[n].inc and their clobber lists are GENERATED text (tools/gen_walk_asm.py): the
     committed files must be what the committed generator writes, byte for byte -- a walk edited by hand, or a generator
     edited without regenerating, would leave the product library out of step with its source (build.py lists the .inc
     files among the library's dependencies)."""
@@ -123,12 +123,16 @@ def test_generated_assembly_walk_is_reproducible():
     from tools import gen_walk_asm as g
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "linearham_amd", "csrc")
-    for n_aware, name in ((False, "lh_prune_walk_asm_s2.inc"), (True, "lh_prune_walk_asm_s2n.inc")):
-        body, clob, _ = g.render(2, n_aware)
-        assert open(os.path.join(csrc, name)).read() == body, name
-        assert open(os.path.join(csrc, "lh_prune_walk_clobbers_s2.inc")).read() == clob
-    assert sorted(f for f in os.listdir(csrc) if f.endswith(".inc")) == ["lh_prune_walk_asm_s2.inc", "lh_prune_walk_asm_s2n.inc",
-                                                                        "lh_prune_walk_clobbers_s2.inc"]
+    names = []
+    for S in (2, 1):
+        for n_aware in (False, True):
+            name = "lh_prune_walk_asm_s%d%s.inc" % (S, "n" if n_aware else "")
+            body, clob, _ = g.render(S, n_aware)
+            assert open(os.path.join(csrc, name)).read() == body, name
+            assert open(os.path.join(csrc, "lh_prune_walk_clobbers_s%d.inc" % S)).read() == clob
+            names.append(name)
+        names.append("lh_prune_walk_clobbers_s%d.inc" % S)
+    assert sorted(f for f in os.listdir(csrc) if f.endswith(".inc")) == sorted(names)
     from linearham_amd import build
     import inspect
     assert ".inc" in inspect.getsource(build.build_hip)

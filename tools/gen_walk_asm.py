@@ -45,8 +45,9 @@ OPTS = set(os.environ.get("LH_ASM_OPTS", "").split(","))   # timing experiments 
 P = 36
 SA, SB, SC = 8, 16, 24       # first SGPR of the state planes of the op's tips A, B, C (eight registers each; s32 is the stack pointer)
 # N-aware walk (alignments that mix N with bases): a third plane per site set says "this lane's state is N" (the two state
-# bits are 0 there), 12 registers per tip: A in s[8:19], B in s[20:31]; tip C of a table-x-tip op is fetched into A's
-# registers once the table look-up has consumed them.  An N tip reads the four ones behind the tip table(s) instead of a
+# bits are 0 there), 12 registers per tip: A in s[8:19], B in s[20:31]; tip C of a table-x-tip op is fetched into the
+# P-matrix registers s[36:47], which such an op no longer needs once a push (if any) is done: the load is in flight during
+# the table look-up's address arithmetic.  An N tip reads the four ones behind the tip table(s) instead of a
 # column (lh_prune.hip tip_column); a cherry table has 5 x 5 entries.
 NSA, NSB = 8, 20
 
@@ -67,7 +68,7 @@ class Regs:
         self.t3 = self.t2 + S
         self.c128 = self.t3 + S
         self.c256 = self.c128 + 1
-        self.tmp = self.c128 + S
+        self.tmp = self.c256 + 1
         self.last = self.tmp + S - 1
 
 
@@ -107,7 +108,7 @@ class Gen:
         self.S = S
         self.n_aware = n_aware
         self.sa, self.sb = (NSA, NSB) if n_aware else (SA, SB)
-        self.sc = NSA if n_aware else SC
+        self.sc = P if n_aware else SC
 
     def matvec(self, dst):
         """dst <- P a for all sites, rows interleaved (4 S independent chains), in the order of lh::matvec:
@@ -205,7 +206,7 @@ class Gen:
         return part_a + part_bc
 
     def deep_addr(self, slot_reg):
-        sh = {2: 6, 4: 7}[self.S]                         # a slot is 32 S bytes per lane
+        sh = {1: 5, 2: 6, 4: 7}[self.S]                   # a slot is 32 S bytes per lane
         return ["s_lshl_b32 s87, %s, %d" % (slot_reg, sh), "v_add_u32_e32 v%d, s87, %%[deep]" % self.r.tmp]
 
     def block_io(self, op, base):
@@ -255,9 +256,10 @@ class Gen:
         add(["lh_walk_cherry_np:"] + cherry + [tipwait] + ROTATE + PREFETCH + self.product(U, X) + self.states(70, 71) +
             ["s_branch lh_walk_tail"])
         # cherry table x tip column
-        # (N-aware: tip C's planes into tip A's registers, which the look-up has consumed)
-        late_c = (["s_lshr_b32 s87, s69, 16"] + self.plane_load(self.sc) + ["s_waitcnt lgkmcnt(0)"]) if self.n_aware else []
-        ctip = self.table_entry(U) + late_c + self.tip_column(X, self.sc, tip_c)
+        # (N-aware: tip C's planes into the P-matrix registers, free here; requested before the look-up, awaited behind it)
+        c_load = (["s_lshr_b32 s87, s69, 16"] + self.plane_load(self.sc)) if self.n_aware else []
+        c_wait = ["s_waitcnt lgkmcnt(0)"] if self.n_aware else []
+        ctip = c_load + self.table_entry(U) + c_wait + self.tip_column(X, self.sc, tip_c)
         add(["; cherry table x tip column", "lh_walk_ctip:", "s_bfe_u32 s88, s68, 0x50004", "s_cmp_eq_u32 s88, 0",
              "s_cbranch_scc1 lh_walk_ctip_np"])
         add(self.push_block("lh_walk_ctip"))
@@ -295,7 +297,7 @@ class Gen:
             h = [A + 8 * s + 2 * i + 1 for i in range(4)]
             add(["v_max_u32_e32 v%d, v%d, v%d" % (r.tmp + s, h[0], h[1]),
                  "v_max3_u32 v%d, v%d, v%d, v%d" % (r.tmp + s, h[2], h[3], r.tmp + s)])
-        add(["v_min_u32_e32 v%d, v%d, v%d" % (U, r.tmp, r.tmp + 1)])           # the u block is free here
+        add(["v_min_u32_e32 v%d, v%d, v%d" % (U, r.tmp, r.tmp + 1) if S > 1 else "v_mov_b32_e32 v%d, v%d" % (U, r.tmp)])   # the u block is free here
         if S == 4:
             add(["v_min3_u32 v%d, v%d, v%d, v%d" % (U, r.tmp + 2, r.tmp + 3, U)])
         add(["v_cmp_gt_u32_e32 vcc, s96, v%d" % U, "s_cbranch_vccnz lh_walk_rescale",
@@ -313,8 +315,8 @@ class Gen:
             add(["v_max_u32_e32 v%d, v%d, v%d" % (r.tmp + s, h[0], h[1]),
                  "v_max3_u32 v%d, v%d, v%d, v%d" % (r.tmp + s, h[2], h[3], r.tmp + s)])
             add(["v_cmp_eq_u32_e32 vcc, 0, v%d" % (r.tmp + s), "v_cndmask_b32_e64 v%d, v%d, -1, vcc" % (r.tmp + s, r.tmp + s)])
-        add(["v_min_u32_e32 v%d, v%d, v%d" % (U, r.tmp, r.tmp + 1), "v_cmp_gt_u32_e32 vcc, s96, v%d" % U,
-             "s_cbranch_vccnz lh_walk_rescale"])
+        add(["v_min_u32_e32 v%d, v%d, v%d" % (U, r.tmp, r.tmp + 1) if S > 1 else "v_mov_b32_e32 v%d, v%d" % (U, r.tmp),
+             "v_cmp_gt_u32_e32 vcc, s96, v%d" % U, "s_cbranch_vccnz lh_walk_rescale"])
         add(["s_branch lh_walk_back",
              "; ---- results to the private array: a (32 S bytes), then the packed scaler counts ------------------",
              "lh_walk_end:", "s_waitcnt vmcnt(0) lgkmcnt(0)"])
@@ -347,14 +349,15 @@ def render(S=2, n_aware=False):
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outdir = os.environ.get("LH_ASM_OUT") or os.path.join(root, "linearham_amd", "csrc")
-    for n_aware in (False, True):
-        body, clob, summary = render(2, n_aware)
-        out = os.path.join(outdir, "lh_prune_walk_asm_s2%s.inc" % ("n" if n_aware else ""))
-        with open(out, "w") as f:
-            f.write(body)
-        with open(os.path.join(outdir, "lh_prune_walk_clobbers_s2.inc"), "w") as f:   # (the same registers in both)
-            f.write(clob)
-        print("wrote %s: %s" % (out, summary))
+    for S in (2, 1):   # (one site per lane: the wave that carries a remainder of up to 64 patterns)
+        for n_aware in (False, True):
+            body, clob, summary = render(S, n_aware)
+            out = os.path.join(outdir, "lh_prune_walk_asm_s%d%s.inc" % (S, "n" if n_aware else ""))
+            with open(out, "w") as f:
+                f.write(body)
+            with open(os.path.join(outdir, "lh_prune_walk_clobbers_s%d.inc" % S), "w") as f:   # (the same registers in both)
+                f.write(clob)
+            print("wrote %s: %s" % (out, summary))
 
 
 if __name__ == "__main__":
