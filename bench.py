@@ -598,6 +598,7 @@ def worker(args, rank, local_rank, world):
                        "tree_samples_per_gpu_per_step": n, "distinct_tree_samples": min(flat["n_rows"], n_total),
                        "distinct_tree_samples_per_gpu": int(len(set(sharding.table_rows(ids, flat["n_rows"], world, n_total).tolist()))),
                        "n_tips": T, "n_sites": sizes["n_sites"], "xmsa_columns": Cx, "site_patterns": n_pat.value,
+                       "k1_form": lib.lib.lh_family_prune_form(C.c_void_p(fam_handle)).decode(),
                        "distinct_xmsa_columns": n_ucol.value, "S_vd": sizes["s_vd"],
                        "S_dj": sizes["s_dj"], "W_vd": sizes["w_vd"], "W_dj": sizes["w_dj"],
                        "G": sizes["g_total"], "backend": dist.get_backend() if world > 1 else None,

@@ -210,6 +210,8 @@ class Gen:
         return ["s_lshl_b32 s87, %s, %d" % (slot_reg, sh), "v_add_u32_e32 v%d, s87, %%[deep]" % self.r.tmp]
 
     def block_io(self, op, base):
+        if "nodeep" in OPTS:   # no traffic for stack slots beyond the first (results wrong): what those slots cost
+            return []
         t = self.r.tmp
         return ["%s v%d, v[%d:%d], off offset:%d" % (op, t, base + 4 * i, base + 4 * i + 3, 16 * i) if op.startswith("scratch_store")
                 else "%s v[%d:%d], v%d, off offset:%d" % (op, base + 4 * i, base + 4 * i + 3, t, 16 * i) for i in range(2 * self.S)]
