@@ -442,7 +442,7 @@ __device__ __forceinline__ void prune_wave_asm(int block64, const uint64_t* __re
                                                const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
   static_assert(S == 1 || S == 2, "one or two sites per lane");
   __attribute__((aligned(16))) double out_mem[4 * S + 2];                                   // a[S][4], then the packed scaler counts
-  __attribute__((aligned(16))) double deep_mem[(kDepth > 1 ? kDepth - 1 : 1) * 4 * S];     // stack slots 1.. : [slot][site][4]
+  __attribute__((aligned(16))) double deep_mem[(kDepth > 2 ? kDepth - 2 : 1) * 4 * S];     // stack slots 2.. : [slot][site][4] (0 and 1: registers)
   // tip t (MSA row t - 1) of this wave's block at planes_w + t * pstride bytes; a wave wholly past the last pattern (its
   // results are not stored) reads the last block.  block64: the wave's first pattern / 64 -- a two-site wave starts a block
   // of 128, a one-site wave (S = 1: a remainder of up to 64 patterns) takes the first or the second site set of its block:

@@ -10,15 +10,17 @@ after editing:    python tools/gen_walk_asm.py
 Why assembly: the compiler's loop carried ~145 instructions per op (copies at joins, flag juggling, spills) where
 ~85 are needed, and with four sites per lane it spilled 50 registers; here every register is placed by hand.
 
-Register map inside the statement, S sites per lane (clobbers v5 .. v<tmp+S-1>, s8-s31 and s36-s99):
-  (v5 .. v5+S-1 unused since round 4: the lanes' site numbers, which addressed the MSA bytes; the map below is unchanged)
-  scal   (S+1)/2 regs          scaler counts, two sites per register (16 bits each)
-  a      8S regs (even base)   running CLV: site s in 8 consecutive registers (four doubles)
+Register map inside the statement, S sites per lane (clobbers v5 .. v<last>, s8-s31 and s36-s99):
+  scal   1 reg (v5)            scaler counts, two sites per register (16 bits each)
+  c128 c256 (v6 v7)            the constants 128, 256 (table look-up of alignments without N); N-aware walk: v6 = LDS address of
+                               the four ones an N tip reads
+  a      8S regs (v8 ..)       running CLV: site s in 8 consecutive registers (four doubles)
   st0    8S                    pending sibling of stack slot 0 (already multiplied by its branch matrix)
-  x      8S                    P a, or a tip column
-  u      8S                    tip column / table entry / deep-slot sibling
-  t2 t3     S each             temporaries of the state -> address arithmetic;  c128 c256  the constants 128, 256
-  tmp  S                       temporaries (addresses, per-site maxima)
+  st1    8S                    ... of stack slot 1 (round 4; deeper slots live in scratch memory)
+  u      8S                    tip column / table entry / deep-slot sibling, both sites (their loads are in flight together)
+  x      8                     P a of ONE site: the sites' mat-vecs run one after the other, each followed by its product; between
+                               ops the block is free and serves as the temporaries of the address arithmetic and of the
+                               rescaling test (a memory instruction has read its address registers when it issues)
   s[8:15] s[16:23] s[24:31]    tip states of the op's tips A, B, C as BIT PLANES: per tip the wave's 128 sites take 32 bytes of
                                the family's 2-bit MSA (lh_family_create: planes[tip][block of 128 sites][site set s][bit]),
                                one s_load_dwordx8 per tip and op; lane l's state of site set s is bit l of the two 64-bit
@@ -28,8 +30,12 @@ Register map inside the statement, S sites per lane (clobbers v5 .. v<tmp+S-1>, 
   s[78:79] state planes of the wave's block, tip 0   s80 bytes per tip   s81 LDS address of the tip table   s82 op counter   s83 op count   s[84:85] descriptors
   s86 offset of the descriptor to prefetch   s98 offset of the last descriptor   s87..s93, s99 temporaries
   s[94:95] exec save   s96 0x2ff00000 (high word of 2^-256)   s97 256
-S = 2: v5-6 unused, scal v7, a v[8:23], st0 v[24:39], x v[40:55], u v[56:71], t2 v72-73, t3 v74-75, c128 v76, c256 v77,
-tmp v78-79 (80 registers: six waves per SIMD).
+S = 2: scal v5, c128 v6, c256 v7, a v[8:23], st0 v[24:39], st1 v[40:55], u v[56:71], x v[72:79] (80 registers: six waves per
+SIMD).  S = 1: a v[8:15], st0 v[16:23], st1 v[24:31], u v[32:39], x v[40:47].
+Two stack slots in registers (round 4): configs[2]-like trees push 8.2 times per walk at level 0, 4.5 times at level 1 and 0.3
+times deeper; with level 1 in scratch memory its 4 KB per wave and push went out to HBM and came back (tables and matrices
+stream through L2 in between): 9 % of K1's time and a quarter of its HBM-side traffic (profiles/r04_k1_programme.txt).  The
+sixteen registers come from computing one site's mat-vec at a time (x: 8 instead of 16) and from the temporaries moving into x.
 Round 4: the tip states come through the SCALAR memory path.  Round 3's walk fetched them with one global_load_ubyte per
 site and tip child; with them replaced by arithmetic the walk ran 12.5 % faster although it issued 9 % more vector
 instructions (profiles/r03_k1_state_loads.txt): the byte loads' issue through the CU's one vector-memory address unit,
@@ -55,21 +61,20 @@ NSA, NSB = 8, 20
 class Regs:
     def __init__(self, S):
         self.S = S
-        self.usite = 5
-        self.scal = 5 + S
-        n_scal = (S + 1) // 2
-        base = self.scal + n_scal
-        base += base & 1                       # 64-bit operands need even-aligned register pairs
-        self.A = base
+        self.scal = 5
+        self.c128 = 6
+        self.usite = 6                        # (N-aware walk: LDS address of the ones; that walk has no use for c128 / c256)
+        self.c256 = 7
+        self.A = 8
         self.ST0 = self.A + 8 * S
-        self.X = self.ST0 + 8 * S
-        self.U = self.X + 8 * S
-        self.t2 = self.U + 8 * S
-        self.t3 = self.t2 + S
-        self.c128 = self.t3 + S
-        self.c256 = self.c128 + 1
-        self.tmp = self.c256 + 1
-        self.last = self.tmp + S - 1
+        self.ST1 = self.ST0 + 8 * S
+        self.U = self.ST1 + 8 * S
+        self.X = self.U + 8 * S
+        # temporaries live in the x block while it holds no mat-vec result
+        self.tmp = self.X
+        self.t2 = self.X + 2
+        self.t3 = self.X + 4
+        self.last = self.X + 7
 
 
 def pair(r):
@@ -125,6 +130,21 @@ class Gen:
 
     def product(self, f1, f2):
         return ["v_mul_f64 %s, %s, %s" % (pair(self.r.A + 2 * i), pair(f1 + 2 * i), pair(f2 + 2 * i)) for i in range(4 * self.S)]
+
+    def mv_prod(self, f, wait=None):
+        """a <- f o (P a), one site after the other: x <- P a_s (four independent chains, the order of lh::matvec), then
+        a_s <- f_s o x.  wait: s_waitcnt placed before the product of each site (f's loads: site 0's were issued first)."""
+        X, A = self.r.X, self.r.A
+        out = []
+        for s in range(self.S):
+            for j in range(4):
+                for i in range(4):
+                    d, a, p = pair(X + 2 * i), pair(A + 8 * s + 2 * j), spair(P + 2 * (4 * i + j))
+                    out.append("v_mul_f64 %s, %s, %s" % (d, a, p) if j == 0 else "v_fmac_f64_e32 %s, %s, %s" % (d, p, a))
+            if wait:
+                out.append(wait[s])
+            out += ["v_mul_f64 %s, %s, %s" % (pair(A + 8 * s + 2 * i), pair(f + 8 * s + 2 * i), pair(X + 2 * i)) for i in range(4)]
+        return out
 
     def p_load(self):
         if "phit" in OPTS:   # every matrix from one of two hot lines (results wrong)
@@ -206,7 +226,7 @@ class Gen:
         return part_a + part_bc
 
     def deep_addr(self, slot_reg):
-        sh = {1: 5, 2: 6, 4: 7}[self.S]                   # a slot is 32 S bytes per lane
+        sh = {1: 5, 2: 6}[self.S]                         # a slot is 32 S bytes per lane
         return ["s_lshl_b32 s87, %s, %d" % (slot_reg, sh), "v_add_u32_e32 v%d, s87, %%[deep]" % self.r.tmp]
 
     def block_io(self, op, base):
@@ -217,15 +237,19 @@ class Gen:
                 else "%s v[%d:%d], v%d, off offset:%d" % (op, base + 4 * i, base + 4 * i + 3, t, 16 * i) for i in range(2 * self.S)]
 
     def push_block(self, label):
-        """The op sets the accumulator aside first (descriptor bits 8:4 = slot + 1, in s88): slot <- P a."""
+        """The op sets the accumulator aside first (descriptor bits 8:4 = level + 1, in s88): slot <- P a -- levels 0 and 1 are
+        register blocks, deeper ones scratch memory (through the u block, free at this point of the op)."""
+        r = self.r
         return self.p_load() + ["s_waitcnt lgkmcnt(0)"] + ROTATE + P_ADV + [
-            "s_cmp_eq_u32 s88, 1", "s_cbranch_scc0 %s_deep" % label] + self.matvec(self.r.ST0) + ["s_branch %s_pushed" % label,
-            "%s_deep:" % label] + self.matvec(self.r.X) + ["s_add_i32 s89, s88, -2"] + self.deep_addr("s89") + \
-            self.block_io("scratch_store_dwordx4", self.r.X) + ["s_waitcnt vmcnt(0)", "%s_pushed:" % label]
+            "s_cmp_eq_u32 s88, 1", "s_cbranch_scc0 %s_lvl1" % label] + self.matvec(r.ST0) + ["s_branch %s_pushed" % label,
+            "%s_lvl1:" % label, "s_cmp_eq_u32 s88, 2", "s_cbranch_scc0 %s_deep" % label] + self.matvec(r.ST1) + ["s_branch %s_pushed" % label,
+            "%s_deep:" % label] + self.matvec(r.U) + ["s_add_i32 s89, s88, -3"] + self.deep_addr("s89") + \
+            self.block_io("scratch_store_dwordx4", r.U) + ["s_waitcnt vmcnt(0)", "%s_pushed:" % label]
 
     def generate(self):
         r, S = self.r, self.S
-        A, ST0, X, U = r.A, r.ST0, r.X, r.U
+        assert S in (1, 2)
+        A, ST0, ST1, X, U = r.A, r.ST0, r.ST1, r.X, r.U
         tip_a, tip_b, tip_c = ["s_lshr_b32 s87, s68, 16"], ["s_and_b32 s87, s69, 0xffff"], ["s_lshr_b32 s87, s69, 16"]
         L = []
         add = L.extend
@@ -233,10 +257,11 @@ class Gen:
              "s_mov_b32 s83, %[nw]", "s_mov_b64 s[84:85], %[wops]", "s_mov_b64 s[74:75], %[pm]", "s_mov_b32 s76, %[ctoff]",
              "s_mov_b32 s77, 0", "s_mov_b64 s[78:79], %[planes]", "s_mov_b32 s80, %[pstride]", "s_mov_b32 s81, %[tip]",
              "s_mov_b32 s96, 0x2ff00000", "s_movk_i32 s97, 0x100"])
-        add(["v_mov_b32_e32 v%d, 0" % (r.scal + i) for i in range((S + 1) // 2)])
-        add(["v_mov_b32_e32 v%d, 0x80" % r.c128, "v_mov_b32_e32 v%d, 0x100" % r.c256])
+        add(["v_mov_b32_e32 v%d, 0" % r.scal])
         if self.n_aware:
             add(["v_mov_b32_e32 v%d, %%[ones]" % r.usite, "s_movk_i32 s92, 0xa0"])
+        else:
+            add(["v_mov_b32_e32 v%d, 0x80" % r.c128, "v_mov_b32_e32 v%d, 0x100" % r.c256])
         for i in range(4 * S):
             add(["v_mov_b32_e32 v%d, 0" % (A + 2 * i), "v_mov_b32_e32 v%d, 0x3ff00000" % (A + 2 * i + 1)])
         add(["s_cmp_lt_i32 s83, 1", "s_cbranch_scc1 lh_walk_end",
@@ -249,42 +274,47 @@ class Gen:
              "lh_walk_top:", "s_waitcnt lgkmcnt(0)", "s_and_b32 s87, s68, 7",
              "s_cmp_eq_u32 s87, 1", "s_cbranch_scc1 lh_walk_tip", "s_cmp_eq_u32 s87, 4", "s_cbranch_scc1 lh_walk_ctab",
              "s_cmp_eq_u32 s87, 2", "s_cbranch_scc1 lh_walk_pop", "s_cmp_eq_u32 s87, 3", "s_cbranch_scc1 lh_walk_ctip"])
-        # cherry: a = tipcol_A * tipcol_B (the accumulator pushed first if the op says so)
-        cherry = self.tip_column(U, self.sa, tip_a) + self.tip_column(X, self.sb, tip_b)
+        # cherry: a = tipcol_A * tipcol_B (the accumulator pushed first if the op says so); the second column lands in a itself
+        cherry = self.tip_column(U, self.sa, tip_a) + self.tip_column(A, self.sb, tip_b)
         add(["; cherry", "s_bfe_u32 s88, s68, 0x50004", "s_cmp_eq_u32 s88, 0", "s_cbranch_scc1 lh_walk_cherry_np"])
         add(self.push_block("lh_walk_cherry"))
         tipwait = "s_waitcnt lgkmcnt(0)"
-        add(cherry + [tipwait] + PREFETCH + self.product(U, X) + self.states(70, 71) + ["s_branch lh_walk_tail"])
-        add(["lh_walk_cherry_np:"] + cherry + [tipwait] + ROTATE + PREFETCH + self.product(U, X) + self.states(70, 71) +
+        add(cherry + [tipwait] + PREFETCH + self.product(U, A) + self.states(70, 71) + ["s_branch lh_walk_tail"])
+        add(["lh_walk_cherry_np:"] + cherry + [tipwait] + ROTATE + PREFETCH + self.product(U, A) + self.states(70, 71) +
             ["s_branch lh_walk_tail"])
-        # cherry table x tip column
+        # cherry table x tip column (the column lands in a: the old accumulator has been pushed or never was)
         # (N-aware: tip C's planes into the P-matrix registers, free here; requested before the look-up, awaited behind it)
         c_load = (["s_lshr_b32 s87, s69, 16"] + self.plane_load(self.sc)) if self.n_aware else []
         c_wait = ["s_waitcnt lgkmcnt(0)"] if self.n_aware else []
-        ctip = c_load + self.table_entry(U) + c_wait + self.tip_column(X, self.sc, tip_c)
+        ctip = c_load + self.table_entry(U) + c_wait + self.tip_column(A, self.sc, tip_c)
         add(["; cherry table x tip column", "lh_walk_ctip:", "s_bfe_u32 s88, s68, 0x50004", "s_cmp_eq_u32 s88, 0",
              "s_cbranch_scc1 lh_walk_ctip_np"])
         add(self.push_block("lh_walk_ctip"))
-        add(ctip + ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + PREFETCH + self.product(U, X) + self.states(70, 71) + ["s_branch lh_walk_tail"])
-        add(["lh_walk_ctip_np:"] + ctip + ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + ROTATE + PREFETCH + self.product(U, X) + self.states(70, 71) +
+        add(ctip + ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + PREFETCH + self.product(U, A) + self.states(70, 71) + ["s_branch lh_walk_tail"])
+        add(["lh_walk_ctip_np:"] + ctip + ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + ROTATE + PREFETCH + self.product(U, A) + self.states(70, 71) +
             ["s_branch lh_walk_tail"])
         # tip into accumulator: a = tipcol_A * (P a)
         st_a, st_bc = self.states(70, 71, split=True)
-        mv = self.matvec(X)
-        half = len(mv) // 2
+        half = 20 if S == 2 else 8
+        mvp = self.mv_prod(U)
         add(["; tip into accumulator", "lh_walk_tip:"] + self.p_load() + self.tip_column(U, self.sa, tip_a) + ["s_waitcnt lgkmcnt(0)"] +
-            ROTATE + weave(mv[:half], P_ADV + PREFETCH + st_a) + st_bc + mv[half:] +
-            self.product(U, X) + ["s_branch lh_walk_tail"])
-        # cherry table into accumulator: a = table * (P a)
+            ROTATE + weave(mvp[:half], P_ADV + PREFETCH + st_a) + st_bc + mvp[half:] + ["s_branch lh_walk_tail"])
+        # cherry table into accumulator: a = table * (P a); a site's entry is awaited in front of its product (site 0's two
+        # gathers were issued first: vmcnt counts the loads still out)
+        waits = ["s_waitcnt vmcnt(%d)" % (2 * (S - 1 - s)) for s in range(S)]
+        mvw = self.mv_prod(U, waits)
         add(["; cherry table into accumulator", "lh_walk_ctab:"] + self.p_load() + self.table_entry(U) + ["s_waitcnt lgkmcnt(0)"] + ROTATE +
-            weave(mv, P_ADV + PREFETCH, 4) + ["s_waitcnt vmcnt(0)"] + self.product(U, X) + self.states(70, 71) + ["s_branch lh_walk_tail"])
-        # pop: a = pending sibling * (P a)
+            weave(mvw, P_ADV + PREFETCH, 4) + self.states(70, 71) + ["s_branch lh_walk_tail"])
+        # pop: a = pending sibling * (P a); level 0 / 1 from their register blocks, deeper ones from scratch memory through u
+        mv0, mv1 = self.mv_prod(ST0), self.mv_prod(ST1)
         add(["; pop", "lh_walk_pop:"] + self.p_load() + ["s_bfe_u32 s88, s68, 0x40009", "s_cmp_eq_u32 s88, 0",
-                                                        "s_cbranch_scc1 lh_walk_pop0", "s_add_i32 s89, s88, -1"] +
+                                                        "s_cbranch_scc1 lh_walk_pop0", "s_cmp_eq_u32 s88, 1", "s_cbranch_scc1 lh_walk_pop1",
+                                                        "s_add_i32 s89, s88, -2"] +
             self.deep_addr("s89") + self.block_io("scratch_load_dwordx4", U) + ["s_waitcnt lgkmcnt(0)"] + ROTATE + P_ADV + PREFETCH +
-            self.matvec(X) + ["s_waitcnt vmcnt(0)"] + self.product(U, X) + self.states(70, 71) +
-            ["s_branch lh_walk_tail", "lh_walk_pop0:", "s_waitcnt lgkmcnt(0)"] + ROTATE + weave(mv[:half], P_ADV + PREFETCH + st_a) + st_bc +
-            mv[half:] + self.product(ST0, X))
+            self.mv_prod(U, waits) + self.states(70, 71) + ["s_branch lh_walk_tail"])
+        add(["lh_walk_pop1:", "s_waitcnt lgkmcnt(0)"] + ROTATE + weave(mv1[:half], P_ADV + PREFETCH + st_a) + st_bc + mv1[half:] +
+            ["s_branch lh_walk_tail"])
+        add(["lh_walk_pop0:", "s_waitcnt lgkmcnt(0)"] + ROTATE + weave(mv0[:half], P_ADV + PREFETCH + st_a) + st_bc + mv0[half:])
         # tail: 2^256 rescaling test on the high words (libpll's per-site scalers), next op.
         # The test runs after every FOURTH op and after the last one, and rescales until the largest entry is back above
         # 2^-256: multiplying by 2^256 is exact, an op lowers the largest entry by 2^-73 at worst (two tip columns across
@@ -300,8 +330,6 @@ class Gen:
             add(["v_max_u32_e32 v%d, v%d, v%d" % (r.tmp + s, h[0], h[1]),
                  "v_max3_u32 v%d, v%d, v%d, v%d" % (r.tmp + s, h[2], h[3], r.tmp + s)])
         add(["v_min_u32_e32 v%d, v%d, v%d" % (U, r.tmp, r.tmp + 1) if S > 1 else "v_mov_b32_e32 v%d, v%d" % (U, r.tmp)])   # the u block is free here
-        if S == 4:
-            add(["v_min3_u32 v%d, v%d, v%d, v%d" % (U, r.tmp + 2, r.tmp + 3, U)])
         add(["v_cmp_gt_u32_e32 vcc, s96, v%d" % U, "s_cbranch_vccnz lh_walk_rescale",
              "lh_walk_back:", "s_mov_b64 s[68:69], s[70:71]", "s_add_i32 s82, s82, 1", "s_cmp_lt_i32 s82, s83",
              "s_cbranch_scc1 lh_walk_top", "s_branch lh_walk_end",
@@ -323,7 +351,7 @@ class Gen:
              "; ---- results to the private array: a (32 S bytes), then the packed scaler counts ------------------",
              "lh_walk_end:", "s_waitcnt vmcnt(0) lgkmcnt(0)"])
         add(["scratch_store_dwordx4 %%[out], v[%d:%d], off offset:%d" % (A + 4 * i, A + 4 * i + 3, 16 * i) for i in range(2 * S)])
-        add(["scratch_store_dword %%[out], v%d, off offset:%d" % (r.scal + i, 32 * S + 4 * i) for i in range((S + 1) // 2)])
+        add(["scratch_store_dword %%[out], v%d, off offset:%d" % (r.scal, 32 * S)])
         add(["s_waitcnt vmcnt(0)"])
         return L
 
