@@ -1530,7 +1530,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   // r04_k1_programme.txt).  The register-stack kernels stay what large trees run (segmented tip table) and what the
   // LH_K1_STACK test hook selects for fused shapes.
   const bool stack_fused = fused && max_depth <= 4 && dbg.k1_stack && !tables_hook;
-  const bool seg = big && max_depth <= 4;
+  const bool seg = big && max_depth <= 4 && !tables_hook;
   const size_t seg_bytes = (size_t)(2 * kSegOps + 1) * 16 * sizeof(double) + ones_bytes;
   size_t lds = fused ? fused_lds : seg ? seg_bytes : tip_bytes + ones_bytes + tail_bytes;
   // (A remainder of up to 64 patterns rides in a ONE-site wave: the assembly walk has a one-site variant -- 45 vector
