@@ -44,10 +44,10 @@ def _expect(report, family, pattern, **conds):
 # kernel<depth, N-aware, fused, assembly>    cherry-table form: ct6 / ct5 / ct4
 def test_default_forms_without_n():
     rep = _run({}, ["small_igh", "mid60x400", "balanced64", "wide100x600", "wide100x600_r8"])
-    # at most 128 patterns (one wave per rate): the assembly walk over cherry tables, the few patterns in a two-site wave
+    # at most 128 patterns (one wave per rate): the assembly walk over cherry tables; up to 64 patterns in its one-site variant
     _expect(rep, "small_igh", r"ct[456]<4,false,true,true>", n_patterns=("le", 128))
     _expect(rep, "mid60x400", r"ct[456]<4,false,true,true>", n_patterns=("gt", 128))    # two waves per rate, fused (configs[2]'s form)
-    # a perfectly balanced 64-leaf tree: five pending siblings, i.e. slots beyond the register slot live in scratch memory
+    # a perfectly balanced 64-leaf tree: five pending siblings, i.e. slots beyond the two register slots live in scratch memory
     _expect(rep, "balanced64", r"ct[456]<16,false,true,true>", max_depth=("ge", 5))
     # more than 256 patterns: three two-site waves per rate, all four rates in one workgroup of twelve waves
     _expect(rep, "wide100x600", r"ct[456]<4,false,true,true>", n_patterns=("gt", 256))
@@ -77,9 +77,10 @@ def test_default_forms_with_n_inside_columns():
     ({"LH_K1_STACK": "1"}, {"small_igh": r"w[456]<[34],false>", "mixed_small": r"w[456]<[34],true>",
                             "mid60x400": r"w[456]<[34],false>", "wide100x600": r"w[456]<[34],false>",
                             "mixed_60x400": r"w[456]<[34],true>"}),
-    # the cherry-table form where the register-stack form would run: fused, assembly walk (two-site waves) / N-aware C++ walk
-    ({"LH_K1_TABLES": "1"}, {"small_igh": r"ct[456]<4,false,true,true>", "mid60x400": r"ct[456]<4,false,true,true>",
-                             "mixed_small": r"ct[456]<4,true,true,true>", "mixed_60x400": r"ct[456]<4,true,true,true>"}),
+    # the cherry-table form where the register-stack form would run: large trees (whole tip table in LDS, a workgroup per
+    # (sample, rate)); fused shapes take it by themselves
+    ({"LH_K1_TABLES": "1"}, {"mixed_120": r"ct[456]<4,true,false,true>", "mixed_500": r"ct[456]<4,true,false,true>",
+                             "mid60x400": r"ct[456]<4,false,true,true>"}),
     # its C++ walk instead of the assembly one
     ({"LH_K1_TABLES": "1", "LH_K1_CXX_WALK": "1"}, {"small_igh": r"ct[456]<4,false,true,false>",
                                                    "mixed_small": r"ct[456]<4,true,true,false>",

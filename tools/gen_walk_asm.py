@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Writes linearham_amd/csrc/lh_prune_walk_asm_s2.inc (+ its clobber list): the gfx950 assembly of K1's schedule walk for
-two sites per lane (alignments without N tips), used by prune_wave_asm through one inline-asm statement.  (Round 3 also
-generated a four-sites-per-lane walk, one with the tip columns gathered from the scratch region and one that walks a
-schedule segment per statement; all three were measured slower and left the product with round 4 -- git 0b72f3b has them.)
-tests/test_structured_cpu.py checks that this script reproduces the committed file byte for byte.  The text is generated because the 4x4 mat-vec and the element-wise products are the same row
-pattern over four register blocks and S sites; everything else is written out below once.  Run from the repo root
-after editing:    python tools/gen_walk_asm.py
+"""Writes linearham_amd/csrc/lh_prune_walk_asm_s2.inc, _s2n.inc, _s1.inc, _s1n.inc (+ the clobber lists _clobbers_s2.inc,
+_clobbers_s1.inc): the gfx950 assembly of K1's schedule walk for two sites per lane and for one (the wave that carries a
+remainder of up to 64 patterns), for alignments without N and (n) for alignments that mix N with bases, each used by
+prune_wave_asm through one inline-asm statement.  (Round 3 also generated a four-sites-per-lane walk, one with the tip
+columns gathered from the scratch region and one that walks a schedule segment per statement; all three were measured
+slower and left the product with round 4 -- git 0b72f3b has them.)  tests/test_structured_cpu.py checks that this script
+reproduces the committed files byte for byte.  The text is generated because the 4x4 mat-vec and the element-wise products
+are the same row pattern over four register blocks and S sites; everything else is written out below once.  Run from the
+repo root after editing:    python tools/gen_walk_asm.py
 
 Why assembly: the compiler's loop carried ~145 instructions per op (copies at joins, flag juggling, spills) where
 ~85 are needed, and with four sites per lane it spilled 50 registers; here every register is placed by hand.
