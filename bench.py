@@ -52,13 +52,14 @@ def log(*a):
 
 
 BRLEN_MEAN = None              # --brlen-mean (development runs on families with fewer site patterns)
+DEV_LEAVES = None              # --leaves (development runs on smaller trees; only together with --brlen-mean)
 LIVE_TRAFFIC = (None, None)    # (bytes per K1 launch, note) from live_k1_traffic(), collected before the GPU is touched
 
 
 def preset_spec(preset, batch):
     from tools import synth_family as sf
     if preset == "config2" and BRLEN_MEAN is not None:
-        return sf.Spec(n_samples=max(batch, 256), brlen_mean=BRLEN_MEAN)
+        return sf.Spec(n_samples=max(batch, 256), brlen_mean=BRLEN_MEAN, **({} if DEV_LEAVES is None else {"n_leaves": DEV_LEAVES}))
     if preset == "config2":     # the batch is drawn from >= batch distinct tree samples
         return sf.Spec(n_samples=max(batch, 256))
     if preset == "config2_ragged":   # (2048 distinct tree samples, cycled through the batch)
@@ -72,6 +73,8 @@ def preset_spec(preset, batch):
 
 def family_dir(preset, spec):
     tag = "" if spec.brlen_mean == 0.01 else "_bl%g" % spec.brlen_mean
+    if DEV_LEAVES is not None:
+        tag += "_l%d" % DEV_LEAVES
     return os.path.join(tempfile.gettempdir(), "lh_bench_%s_n%d_v%d%s" % (preset, spec.n_samples, GEN_VERSION, tag))
 
 
@@ -391,6 +394,8 @@ def parse_args():
     ap.add_argument("--brlen-mean", type=float, default=None,
                     help="development only (not the headline workload): mean branch length of the synthetic truth tree "
                          "(default 0.01: 253 site patterns for config2; 0.002 gives a family with ~100 patterns)")
+    ap.add_argument("--leaves", type=int, default=None,
+                    help="development only, with --brlen-mean: leaves of the synthetic tree (default 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true",
                     help="also time the host-pointer entry point (PCIe-inclusive rate; its launch groups are "
@@ -413,8 +418,9 @@ def parse_args():
                     help="collective backend; gloo (through host copies) only to rehearse the multi-rank path on "
                          "a box with fewer GPUs than ranks -- ranks then share devices (LOCAL_RANK modulo)")
     args = ap.parse_args()
-    global BRLEN_MEAN
+    global BRLEN_MEAN, DEV_LEAVES
     BRLEN_MEAN = args.brlen_mean
+    DEV_LEAVES = args.leaves if args.brlen_mean is not None else None
     if args.batch is None:
         args.batch = {"config2": DEFAULT_BATCH, "config2_ragged": DEFAULT_BATCH, "config3": 0, "config4": 6144, "small": 64}[args.preset]
     return args

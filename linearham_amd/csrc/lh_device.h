@@ -260,7 +260,7 @@ struct DebugOptions {
   bool sample_timing = false;  // LH_SAMPLE_TIMING: stage times of every lh_eval_sample_batch call on stderr
   int k1_tile_cap = 0;         // LH_K1_TILE_CAP=<sites>: small K1 tiles, so that small families run the multi-tile path
   bool k1_cxx_walk = false;    // LH_K1_CXX_WALK: the cherry-table form with its C++ walk instead of the assembly one
-  bool k1_tables = false;      // LH_K1_TABLES: the cherry-table form for the fused shapes too
+  bool k1_tables = false;      // LH_K1_TABLES: the cherry-table form for large trees too (which take the segmented register-stack form)
   bool k1_stack = false;       // LH_K1_STACK: the register-stack form for fused shapes (which take the cherry-table form by themselves)
   bool k1_no_tables = false;   // LH_K1_NO_TABLES: the cherry-table form's kernels without tables
   bool k1_segments = false;    // LH_K1_SEGMENTS: the segmented tip table (large trees) on small trees too

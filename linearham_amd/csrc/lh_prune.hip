@@ -1184,11 +1184,10 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
   // not through memory (tables beyond nthr / 4 take the path through the scratch area).  With N in the alignment a
   // table has a fifth row and column: the quad's lanes share the fifth row's entries (round 4; such tables all took
   // the scratch path before).
-  constexpr bool kQuad = true;
-  const int n_q = kQuad ? min(n_tab, nthr >> 2) : 0;
-  const bool pc_lane = kQuad && (rtid & 3) == 0 && (rtid >> 2) < n_q;
+  const int n_q = min(n_tab, nthr >> 2);
+  const bool pc_lane = (rtid & 3) == 0 && (rtid >> 2) < n_q;
   int4 tcell = make_int4(1, 1, 0, 0);
-  if (kQuad && (rtid >> 2) < n_q) tcell = tl[rtid >> 2];  // the quad's table: requested now, used after the barrier
+  if ((rtid >> 2) < n_q) tcell = tl[rtid >> 2];  // the quad's table: requested now, used after the barrier
   double pcq[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) pcq[i] = 0.0;
@@ -1257,7 +1256,7 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
       o[2 * sz + 1] = make_double2(x[2], x[3]);
     }
   };
-  if constexpr (kQuad) {
+  {
     // every lane of the wave takes part in the DPP moves (quad_perm [0,0,0,0]: the quad's first lane to all four)
     double pc[16];
 #pragma unroll
