@@ -1513,7 +1513,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   //     rates' planes unmixed.  (Round 4: 16 instead of 8 waves -- families with 257 .. 512 site patterns at R = 4, two
   //     workgroups of 12 or 16 waves per CU, used to fall to a workgroup per (sample, rate) at twice the time.)
   //  2. big: with a whole tip table in LDS fewer than five waves per SIMD would be resident -> segmented tip table.
-  //  3. the register-stack form (stack depth <= 4: slots in registers) for big shapes; the cherry-table form (one slot in
+  //  3. the register-stack form (stack depth <= 4: slots in registers) for big shapes; the cherry-table form (two slots in
   //     registers, deeper ones in scratch memory: any depth up to 16; the walk in assembly) for everything else.
   const bool fused = allow_fused && !dbg.k1_no_fuse && !dbg.k1_segments &&
                      ((R * wpr <= 8 && fused_lds <= 53 * 1024) ||    // three workgroups of up to eight waves per CU
