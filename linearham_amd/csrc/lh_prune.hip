@@ -1517,7 +1517,7 @@ int launch_prune(const DevFamily& fam, int n, int R, int T, int max_depth, const
   //     registers, deeper ones in scratch memory: any depth up to 16; the walk in assembly) for everything else.
   const bool fused = allow_fused && !dbg.k1_no_fuse && !dbg.k1_segments &&
                      ((R * wpr <= 8 && fused_lds <= 53 * 1024) ||    // three workgroups of up to eight waves per CU
-                      (R * wpr >= 10 && R * wpr <= 16 && fused_lds <= 80 * 1024));    // two of ten to sixteen
+                      (R * wpr > 8 && R * wpr <= 16 && fused_lds <= 80 * 1024));     // two of nine to sixteen
   const bool big = !fused && ((160 * 1024 / tip_bytes) * wpr / 4 < 5 || dbg.k1_segments);
   const bool tables_hook = dbg.k1_tables || dbg.k1_no_tables;
   const bool use_asm = !dbg.k1_cxx_walk;  // (both kinds of alignment: 2-bit state planes, or 2 bits + an N flag)
