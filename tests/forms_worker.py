@@ -23,6 +23,7 @@ def specs():
         "balanced64": sf.Spec.small(n_leaves=64, n_samples=3, seed=47, tree_shape="balanced", n_nni=0),   # stack depth >= 5
         "wide100x600": sf.Spec(n_leaves=100, n_sites=600, n_v=24, n_d=6, n_j=4, n_samples=3, seed=48, brlen_mean=0.02),
         "wide100x600_r8": sf.Spec(n_leaves=100, n_sites=600, n_v=24, n_d=6, n_j=4, n_samples=3, seed=48, brlen_mean=0.02),
+        "wide100x600_r3": sf.Spec(n_leaves=100, n_sites=600, n_v=24, n_d=6, n_j=4, n_samples=3, seed=48, brlen_mean=0.02),
         # ragged reads (N padding of unequal extent at both ends) and scattered ambiguous bases: libpll's N = 1111
         # (src/HMM.cpp:69-83, src/PhyloHMM.cpp:229-235,368-370)
         "mixed_small": sf.Spec.small(n_leaves=20, n_samples=3, seed=42, ragged=6, ambiguous=0.02),
@@ -42,7 +43,7 @@ def specs():
 # relative rounding); the second sample agrees to 1e-10.  Measured here: 4.8e-9 / 2.1e-8.  Log-likelihood 1e-10 and exact
 # ScaleMatrix counts hold as everywhere.
 TOLERANCE = {"mixed_500": dict(em_rtol=2e-8, fwd_rtol=1e-7)}
-NUM_RATES = {"wide100x600_r8": 8}     # (4 everywhere else)
+NUM_RATES = {"wide100x600_r8": 8, "wide100x600_r3": 3}     # (4 everywhere else)
 
 
 def main(argv):

@@ -43,7 +43,7 @@ def _expect(report, family, pattern, **conds):
 # kernel<depth, N-aware>                     register-stack form: w6 / w5 / w4 (all rates in one workgroup), seg4 / seg5
 # kernel<depth, N-aware, fused, assembly>    cherry-table form: ct6 / ct5 / ct4
 def test_default_forms_without_n():
-    rep = _run({}, ["small_igh", "mid60x400", "balanced64", "wide100x600", "wide100x600_r8"])
+    rep = _run({}, ["small_igh", "mid60x400", "balanced64", "wide100x600", "wide100x600_r8", "wide100x600_r3"])
     # at most 128 patterns (one wave per rate): the assembly walk over cherry tables; up to 64 patterns in its one-site variant
     _expect(rep, "small_igh", r"ct[456]<4,false,true,true>", n_patterns=("le", 128))
     _expect(rep, "mid60x400", r"ct[456]<4,false,true,true>", n_patterns=("gt", 128))    # two waves per rate, fused (configs[2]'s form)
@@ -54,6 +54,8 @@ def test_default_forms_without_n():
     # the same family with eight rate categories: 24 waves do not fit one workgroup -- a workgroup per (sample, rate), the
     # assembly walk over cherry tables, K2a mixing the rates
     _expect(rep, "wide100x600_r8", r"ct[456]<4,false,false,true>", n_patterns=("gt", 256))
+    # ... and with three: nine waves (a workgroup that is not a power of two in size), fused
+    _expect(rep, "wide100x600_r3", r"ct[456]<4,false,true,true>", n_patterns=("gt", 256))
 
 
 def test_default_forms_with_n_inside_columns():
