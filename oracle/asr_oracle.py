@@ -103,7 +103,7 @@ def asr_sample(children, root, brlen, T, msa, naive, er, pi, rates, seed, sample
     R = len(rates)
     pi = np.asarray(pi, dtype=float)
     tips = np.concatenate([naive[None, :], msa], axis=0)
-    P = orc.gtr_pmatrices(er, pi, rates, brlen)          # [2T-2, R, 4, 4]
+    P = orc.gtr_pmatrices(er, pi, rates, brlen, small_qt_form=True)          # [2T-2, R, 4, 4]
     sites = np.arange(L)
     per_rate = []
     loglik = np.zeros((R, L))
@@ -112,7 +112,8 @@ def asr_sample(children, root, brlen, T, msa, naive, er, pi, rates, seed, sample
         # close the naive branch: L = sum_i pi_i clv_root[i] (P_naive clv_naive)[i]
         down = np.einsum("ij,lj->li", P[0, k], clv[0])
         w_root = pi[None, :] * clv[root] * down
-        loglik[k] = np.log(w_root.sum(axis=1)) + logscale
+        with np.errstate(divide="ignore"):     # (a category under which a column is impossible: weight 0)
+            loglik[k] = np.log(w_root.sum(axis=1)) + logscale
         per_rate.append((clv, w_root, order))
     # 1-2: rate category per site (the division by naive.probs is common to the R weights)
     w = np.exp(loglik - loglik.max(axis=0, keepdims=True)).T          # [L, R]

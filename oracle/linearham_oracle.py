@@ -1011,9 +1011,15 @@ def gamma_rates_mean(alpha, R):
     return R * np.diff(cum)
 
 
-def gtr_pmatrices(er, pi, rates, brlens):
+def gtr_pmatrices(er, pi, rates, brlens, small_qt_form=False):
     """Per-branch, per-rate P = exp(Q t r) for GTR (Q_ij = er_ij pi_j, mean rate 1) [3P].
-    Returns array [len(brlens), R, 4, 4]."""
+    Returns array [len(brlens), R, 4, 4].
+    small_qt_form: the form for Q t -> 0 that libpll's published core_pmatrix.c describes (expm1 of the eigenvalues, the
+    identity added at the end; [3P]: that source is not in /root/reference) and K1's prologue uses (lh_device.h
+    compute_pmatrix), here with negative entries set to 0 -- with plain exp() an off-diagonal entry of size 1e-19 (a
+    1e-6 branch at a discrete-Gamma rate of 1e-13, alpha = 0.05) is rounding noise of either sign.  The log-likelihood
+    path does not need it (such a category contributes nothing to a mixture); the ancestral-sequence oracle, which
+    compares categories site by site, asks for it."""
     pi = np.asarray(pi, dtype=float)
     S = np.zeros((4, 4))
     k = 0
@@ -1033,8 +1039,10 @@ def gtr_pmatrices(er, pi, rates, brlens):
     Uinv = W.T * sq[None, :]
     brlens = np.asarray(brlens, dtype=float)
     rates = np.asarray(rates, dtype=float)
-    ex = np.exp(lam[None, None, :] * brlens[:, None, None] * rates[None, :, None])   # [B,R,4]
-    return np.einsum("ik,brk,kj->brij", U, ex, Uinv)
+    x = lam[None, None, :] * brlens[:, None, None] * rates[None, :, None]            # [B,R,4]
+    if small_qt_form:
+        return np.maximum(np.einsum("ik,brk,kj->brij", U, np.expm1(x), Uinv) + np.eye(4)[None, None], 0.0)
+    return np.einsum("ik,brk,kj->brij", U, np.exp(x), Uinv)
 
 
 def per_site_loglik(tree, label_to_row, tip_states, er, pi, rates):
