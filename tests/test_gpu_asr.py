@@ -81,6 +81,22 @@ def test_asr_matches_oracle(hip, tmp_path, preset):
     assert choice.max() < R
 
 
+def test_asr_at_the_alpha_floor(hip, tmp_path):
+    """alpha = 0.05 with eight categories: the lowest rates are 1e-17 .. 1e-11, a 1e-6 branch's off-diagonal P entries 1e-19 and
+    smaller.  The kernels form P = I + U expm1(lambda t r) U^-1 clamped at 0; the oracle's exp() form gave such entries either
+    sign and drew columns with mutations into category 0 (round 4, found by tests/dev_tools/random_sweep_asr.py) until it asked
+    for the same form.  Every draw must agree, and no column that varies may be drawn into the slowest category."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_leaves=14, n_samples=3, seed=9005, locus="igk", ambiguous=0.05, tree_shape="balanced"), out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = [dict(r, alpha=0.05) for r in sf.read_trees_tsv(os.path.join(out, "trees.tsv"))]
+    mism, total, anc, choice = _run(hip, h, rows, 8, seed=9005, first_sample=3, rng=np.random.default_rng(5))
+    assert mism == 0, (mism, total)
+    varies = np.array([len(set(h.msa[:, j][h.msa[:, j] < 4])) > 1 for j in range(h.msa.shape[1])])
+    assert varies.sum() >= 3 and (choice[:, varies] > 0).all(), (int(varies.sum()), choice[:, varies].min(axis=0).tolist())
+
+
 def test_asr_toy_family_and_determinism(hip, data_dir):
     """The reference's own toy family (data/phylo_hmm_input.yaml + newton.tree): smallest tree with an inner
     branch; same call twice -> identical output; different seed -> different output; sample numbering is
