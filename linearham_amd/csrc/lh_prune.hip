@@ -1193,48 +1193,62 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
   for (int i = 0; i < 16; ++i) pcq[i] = 0.0;
   {
     const double* __restrict__ e = eig + (size_t)sample * 36;
-    const double rt = rates[(size_t)sample * R + rate];
     const double* __restrict__ bl = brlen + (size_t)sample * (2 * (size_t)T - 2);
     const double* __restrict__ wl = wlen + (size_t)sample * n_ops;
-    double P[4][4];
     // One matrix per thread and round.  Round 0: a quad's first lane takes its cherry matrix, every other thread the
-    // item of its rank in the common list (walk matrices | cherry matrices n_q.. (scratch path) | tips); later rounds:
-    // the rest of the list, nthr items at a time.  A single compute_pmatrix per round, whatever the item's kind.
+    // item of its rank in the common list of its rate (walk matrices | cherry matrices n_q.. (scratch path) | tips).
+    // The rest of the lists -- with all rates in one workgroup -- is POOLED over the workgroup's threads (round 4: 71
+    // items per rate on configs[2], which kept both waves of every rate busy for a second round; pooled, 284 items keep
+    // five of the eight waves busy and three skip the round).  The pooled part runs FIRST: the quads' matrices (sixteen
+    // registers each) are then not live across another compute_pmatrix.
     const int n_rest = n_tab - n_q;
     const int n_list = n_mat + n_rest + T;
-    const int round1 = nthr - n_q;  // list items taken in round 0
-    const int n_rounds = 1 + (n_list > round1 ? (n_list - round1 + nthr - 1) / nthr : 0);
-    for (int round = 0; round < n_rounds; ++round) {
-      const bool is_pc = round == 0 && pc_lane;
-      const int it = round == 0 ? rtid - min(n_q, (rtid + 3) >> 2) : round1 + rtid + (round - 1) * nthr;
+    const int round1 = nthr - n_q;  // list items of a rate taken in round 0
+    auto item = [&](bool is_pc, int it, int rr, int quad) {
+      double P[4][4];
       const bool in_list = !is_pc && it < n_list;
       const bool inner = in_list && it < n_mat + n_rest;
       const int slot = it < n_mat ? it : it + n_q;  // matrix slot in the scratch area ([n_mat + c] for table c)
       const int j = it - (n_mat + n_rest);          // tip
       double t = 0.0;
-      if (is_pc) t = wl[n_mat + (rtid >> 2)];
+      if (is_pc) t = wl[n_mat + quad];
       else if (inner) t = wl[slot];
       else if (in_list) t = bl[j];
-      compute_pmatrix(e, t * rt, P);
+      compute_pmatrix(e, t * rates[(size_t)sample * R + rr], P);
       if (is_pc) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) pcq[i * 4 + q] = P[i][q];
       } else if (inner) {
-        double* o = pw + (size_t)slot * 16;
+        double* o = pmat_w + ((size_t)sample * R + rr) * rate_stride + (size_t)slot * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) o[i * 4 + q] = P[i][q];
       } else if (in_list) {
-        double* o = tiptab + j * 16;
+        double* o = reinterpret_cast<double*>(smem2) + (kFused ? (size_t)rr * T * 16 : 0) + j * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int st = 0; st < 4; ++st) o[st * 4 + i] = P[i][st];
       }
+    };
+    const int rem = n_list - round1;  // items of a rate beyond round 0
+    if (rem > 0) {
+      if constexpr (kFused) {
+        const float inv_rem = 1.0f / (float)rem;
+        for (int c = tid; c < R * rem; c += blockDim.x) {
+          int rr = min((int)(((float)c + 0.5f) * inv_rem), R - 1);  // c / rem
+          rr -= rr * rem > c ? 1 : 0;
+          rr += (rr + 1) * rem <= c ? 1 : 0;
+          item(false, round1 + c - rr * rem, rr, 0);
+        }
+      } else {
+        for (int it = round1 + rtid; it < n_list; it += nthr) item(false, it, rate, 0);
+      }
     }
+    item(pc_lane, rtid - min(n_q, (rtid + 3) >> 2), rate, rtid >> 2);
   }
   // the tip tables are complete (LDS); the scratch-area stores need to have landed only if a table goes that way
   if (n_tab > n_q) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
