@@ -1389,19 +1389,24 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
     const double w = 1.0 / R;
     double* lik_out = site_lik + ((size_t)sample * 5) * (size_t)L;
     int32_t* scal_out = site_scal + (size_t)sample * (size_t)L;
-    for (int j = tid; j < 5 * n_tile; j += blockDim.x) {
-      const int b = j / n_tile, p = j - b * n_tile;
+    // a thread per pattern, its five naive states together (round 4: a thread per (state, pattern) cost an integer division
+    // by the tile size per item and read the R scaler counts five times over -- ~250 vector instructions per wave against ~40)
+    for (int p = tid; p < n_tile; p += blockDim.x) {
       int smin = 0x7fffffff;
       for (int r = 0; r < R; ++r) smin = min(smin, SC[r * pad + p]);
-      double acc = 0.0;
+      double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
       for (int r = 0; r < R; ++r) {
-        double v = X[((size_t)r * 5 + b) * pad + p];
         const int d = SC[r * pad + p] - smin;
-        for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
-        acc += w * v;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          double v = X[((size_t)r * 5 + b) * pad + p];
+          for (int q = 0; q < d && v != 0.0; ++q) v *= kScaleThreshold;
+          acc[b] += w * v;
+        }
       }
-      lik_out[(size_t)b * L + tile0 + p] = acc;
-      if (b == 0) scal_out[tile0 + p] = smin;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) lik_out[(size_t)b * L + tile0 + p] = acc[b];
+      scal_out[tile0 + p] = smin;
     }
   }
 }
