@@ -616,8 +616,7 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
       if (h.n_prune > 0) {
         // two state bits per pattern, and for alignments that mix N with bases a third plane flagging N (state bits 0 there)
         const size_t np = h.n_prune, nb = (np + 127) / 128, nm = h.msa_mixed_n ? 3 : 2;
-        // (+ 8 words: a one-site wave of the second site set loads a block's worth of masks from the middle of its block)
-        std::vector<uint64_t> planes(N * nb * 2 * nm + 8, 0);
+        std::vector<uint64_t> planes(N * nb * 2 * nm, 0);
         for (size_t i = 0; i < N; ++i)
           for (size_t b = 0; b < nb; ++b)
             for (size_t s2 = 0; s2 < 2; ++s2)

@@ -426,9 +426,10 @@ __device__ __forceinline__ void close_naive_branch(const double (&a)[S][4], cons
 typedef __attribute__((address_space(5))) char* private_ptr;
 typedef __attribute__((address_space(3))) const char* lds_ptr;
 
-// The walk in assembly (two sites per lane, alignments without N; text and register map: tools/gen_walk_asm.py ->
-// lh_prune_walk_asm_s2.inc).  Same operations in the same order as the C++ walk below, which stays as the form for
-// everything else and as its reference (LH_K1_CXX_WALK=1 selects it; the results are bit-identical).
+// The walk in assembly (S = 2 sites per lane, or 1 for the wave that carries a remainder of up to 64 patterns; text and
+// register map: tools/gen_walk_asm.py -> lh_prune_walk_asm_s2.inc, _s1.inc and their N-aware twins _s2n.inc, _s1n.inc).
+// Same operations in the same order as the C++ walk below, which stays as its reference (LH_K1_CXX_WALK=1 selects it; the
+// results are bit-identical).
 // wops: the sample's descriptors in global memory; ctoff: byte offset of the cherry tables in the scratch region pm points
 // to; planes: the family's tip states as bit planes (DevFamily::msa_planes: [tip][block of 128 patterns][site set][bit]
 // 64-bit masks; patterns past the last one repeat it), of which the wave -- lane l carries patterns 128 block + l + 64 s --
@@ -436,7 +437,7 @@ typedef __attribute__((address_space(3))) const char* lds_ptr;
 // kN: alignments that mix N with bases -- a third plane per site set flags the lanes whose state is N (6 masks per tip and
 // block instead of 4), and such a tip reads the four ones at `ones` (LDS) instead of a column; lh_prune_walk_asm_s2n.inc.
 template <int kDepth, bool kN, int S>
-__device__ __forceinline__ void prune_wave_asm(int block64, const uint64_t* __restrict__ planes, int n_blocks, int n_w,
+__device__ __forceinline__ void prune_wave_asm(int block128, const uint64_t* __restrict__ planes, int n_blocks, int n_w,
                                                const WalkOp* __restrict__ wops, pmat_ptr pm, unsigned ctoff,
                                                const double* tiptab, const double* naive_tab, const double* ones,
                                                const double* __restrict__ p4, double (&lik)[S][5], int (&scl)[S]) {
@@ -444,13 +445,11 @@ __device__ __forceinline__ void prune_wave_asm(int block64, const uint64_t* __re
   __attribute__((aligned(16))) double out_mem[4 * S + 2];                                   // a[S][4], then the packed scaler counts
   __attribute__((aligned(16))) double deep_mem[(kDepth > 2 ? kDepth - 2 : 1) * 4 * S];     // stack slots 2.. : [slot][site][4] (0 and 1: registers)
   // tip t (MSA row t - 1) of this wave's block at planes_w + t * pstride bytes; a wave wholly past the last pattern (its
-  // results are not stored) reads the last block.  block64: the wave's first pattern / 64 -- a two-site wave starts a block
-  // of 128, a one-site wave (S = 1: a remainder of up to 64 patterns) takes the first or the second site set of its block:
-  // its loads start at that set's masks (and run over into the next block's, or the array's padding: never used).
+  // results are not stored) reads the last block.  Every wave starts a block of 128 patterns: the one-site wave (S = 1: a
+  // remainder of up to 64 patterns behind the tile's two-site waves) reads the block's first site set and ignores the second.
   constexpr int kMasks = kN ? 6 : 4;  // 64-bit masks per (tip, block)
-  const int blk = min(block64 >> 1, n_blocks - 1);
-  const int set = S == 1 ? (block64 & 1) : 0;
-  const uint64_t* planes_w = planes + ((ptrdiff_t)blk - (ptrdiff_t)n_blocks) * kMasks + set * (kMasks / 2);
+  const int blk = min(block128, n_blocks - 1);
+  const uint64_t* planes_w = planes + ((ptrdiff_t)blk - (ptrdiff_t)n_blocks) * kMasks;
   const unsigned pstride = (unsigned)n_blocks * (unsigned)(kMasks * 8);
   const unsigned tip_lds = (unsigned)(size_t)(lds_ptr)tiptab;
   if constexpr (kN && S == 2) {
@@ -1331,7 +1330,7 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
     site0 = tile0 + wave * (64 * kS) + lane;
     n_own = kS;
     if constexpr (kAsm)
-      prune_wave_asm<kDepth, kN, kS>((tile0 + wave * (64 * kS)) >> 6, planes, (L + 127) >> 7, n_w, wops + (size_t)sample * n_ops, pm,
+      prune_wave_asm<kDepth, kN, kS>((tile0 + wave * (64 * kS)) >> 7, planes, (L + 127) >> 7, n_w, wops + (size_t)sample * n_ops, pm,
                                      (unsigned)((T - 3 > 0 ? T - 3 : 0) * 128), tiptab, naive_tab, ones, p4, lik, scl);
     else
       prune_wave_ct<kDepth, kS, kN>(site0, site_end, msa, L, n_w, desc, pm, tiptab, ctab, naive_tab, ones_off, p4, lik, scl);
@@ -1341,7 +1340,7 @@ __device__ __forceinline__ void prune_body_ct(int n2, int tile, int R, int wpr, 
     double lik1[1][5];
     int scl1[1];
     if constexpr (kAsm)
-      prune_wave_asm<kDepth, kN, 1>((tile0 + n2 * (64 * kS) + (wave - n2) * 64) >> 6, planes, (L + 127) >> 7, n_w,
+      prune_wave_asm<kDepth, kN, 1>((tile0 + n2 * (64 * kS)) >> 7, planes, (L + 127) >> 7, n_w,   // (at most one such wave)
                                     wops + (size_t)sample * n_ops, pm, (unsigned)((T - 3 > 0 ? T - 3 : 0) * 128), tiptab, naive_tab,
                                     ones, p4, lik1, scl1);
     else
