@@ -288,6 +288,23 @@ def test_random_small_families(hip, tmp_path, seed):
         assert [bool(np.isfinite(x)) for x in ll] == [bool(np.isfinite(r["loglik"])) for r in ref]
 
 
+@pytest.mark.parametrize("n_leaves,R,kw", [
+    (2, 1, {}), (2, 4, dict(ragged=3, ambiguous=0.05)), (3, 2, {}), (2, 16, {}), (5, 16, dict(ambiguous=0.03)),
+    (4, 5, dict(locus="igk")), (9, 7, dict(locus="igl", ragged=4))])
+def test_smallest_trees_and_odd_rate_counts(hip, tmp_path, n_leaves, R, kw):
+    """The edges of the shape space: the smallest tree the path accepts (naive + two sequences: a single cherry op and
+    no inner-branch matrix), and rate-category counts that are neither 1 nor 4 -- 2, 5, 7 (workgroups of 2, 5, 7 waves
+    with all rates inside) and 16 (sixteen waves: the largest fused workgroup) -- with and without N in the alignment."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_leaves=n_leaves, n_samples=3, seed=100 + n_leaves + R, **kw), out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    desc, ll, res, ref = run_family(hip, h, rows, R)
+    assert all(np.isfinite(r["loglik"]) for r in ref)
+    compare(h, desc, ll, res, ref)
+
+
 def test_large_tree_family(hip, tmp_path):
     """BASELINE.json configs[4] shape: 500 leaves x 600 sites (LDS tip table > 64 KB, two site tiles,
     deeper schedule stack), reduced germline set so that the dense oracle stays fast."""
