@@ -14,8 +14,9 @@ The Felsenstein-pruning arithmetic of the reference lives in a third-party depen
 vendored in /root/reference (matsengrp/libptpll wrapping xflouris/libpll-2, version unpinned in the
 snapshot -- lib/libptpll is an empty submodule directory).  Its published algorithm is restated
 here (GTR with rates ordered AC,AG,AT,CG,CT,GT, Q normalised to mean rate 1, discrete-Gamma
-category MEANS with equal weights, N tips = all-ones CLV) and anchored on the reference's own
-golden vectors for the call sites src/PhyloHMM.cpp:224-226,360,368-370.
+category MEANS with equal weights, N tips = all-ones CLV; P-matrices as libpll's core_pmatrix.c forms
+them -- expm1 of the eigenvalues, the identity added at the end: gtr_pmatrices) and anchored on the
+reference's own golden vectors for the call sites src/PhyloHMM.cpp:224-226,360,368-370.
 """
 import math
 import os
@@ -1011,15 +1012,17 @@ def gamma_rates_mean(alpha, R):
     return R * np.diff(cum)
 
 
-def gtr_pmatrices(er, pi, rates, brlens, small_qt_form=False):
+def gtr_pmatrices(er, pi, rates, brlens, small_qt_form=False, plain_exp=False):
     """Per-branch, per-rate P = exp(Q t r) for GTR (Q_ij = er_ij pi_j, mean rate 1) [3P].
     Returns array [len(brlens), R, 4, 4].
-    small_qt_form: the form for Q t -> 0 that libpll's published core_pmatrix.c describes (expm1 of the eigenvalues, the
-    identity added at the end; [3P]: that source is not in /root/reference) and K1's prologue uses (lh_device.h
-    compute_pmatrix), here with negative entries set to 0 -- with plain exp() an off-diagonal entry of size 1e-19 (a
-    1e-6 branch at a discrete-Gamma rate of 1e-13, alpha = 0.05) is rounding noise of either sign.  The log-likelihood
-    path does not need it (such a category contributes nothing to a mixture); the ancestral-sequence oracle, which
-    compares categories site by site, asks for it."""
+    Formed as libpll's published core_pmatrix.c forms it ([3P]: that source is not in /root/reference): expm1 of the
+    eigenvalues, the identity added at the end ("in order to deal with numerical issues in cases when Qt -> 0").  With plain
+    exp() -- this oracle's form until round 4, `plain_exp=True` -- an off-diagonal entry of size 1e-19 (a 1e-6 branch at a
+    discrete-Gamma rate of 1e-13: alpha = 0.05) is rounding noise of either sign, and on a 100-leaf x 600-site family with
+    R = 2 that noise reached 1.5e-9 of the log-likelihood (tests/dev_tools/oracle_conditioning.py --wide 7477: the C
+    restatement and the kernels agreed to 1e-11 with each other and not with this one).
+    small_qt_form: additionally negative entries set to 0, as K1's prologue does (lh_device.h compute_pmatrix); the
+    ancestral-sequence oracle, which compares categories site by site, asks for it."""
     pi = np.asarray(pi, dtype=float)
     S = np.zeros((4, 4))
     k = 0
@@ -1040,9 +1043,10 @@ def gtr_pmatrices(er, pi, rates, brlens, small_qt_form=False):
     brlens = np.asarray(brlens, dtype=float)
     rates = np.asarray(rates, dtype=float)
     x = lam[None, None, :] * brlens[:, None, None] * rates[None, :, None]            # [B,R,4]
-    if small_qt_form:
-        return np.maximum(np.einsum("ik,brk,kj->brij", U, np.expm1(x), Uinv) + np.eye(4)[None, None], 0.0)
-    return np.einsum("ik,brk,kj->brij", U, np.exp(x), Uinv)
+    if plain_exp:
+        return np.einsum("ik,brk,kj->brij", U, np.exp(x), Uinv)
+    P = np.einsum("ik,brk,kj->brij", U, np.expm1(x), Uinv) + np.eye(4)[None, None]
+    return np.maximum(P, 0.0) if small_qt_form else P
 
 
 def per_site_loglik(tree, label_to_row, tip_states, er, pi, rates):

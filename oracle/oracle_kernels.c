@@ -235,11 +235,12 @@ static double eval_one(const oc_family* F, const int32_t* children, int root, co
   for (int v = 0; v < nodes; ++v)
     for (int r = 0; r < R; ++r) {
       double ex[4];
-      for (int k = 0; k < 4; ++k) ex[k] = exp(lam[k] * brlen[v] * rates[r]);
+      /* libpll's form for Qt -> 0 (core_pmatrix.c, [3P]): expm1 of the eigenvalues, the identity added at the end */
+      for (int k = 0; k < 4; ++k) ex[k] = expm1(lam[k] * brlen[v] * rates[r]);
       double* p = P + ((size_t)v * R + r) * 16;
       for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
-          double acc = 0;
+          double acc = (i == j) ? 1.0 : 0.0;
           for (int k = 0; k < 4; ++k) acc += U[i][k] * ex[k] * Ui[k][j];
           p[i * 4 + j] = acc;
         }

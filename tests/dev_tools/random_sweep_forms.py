@@ -1,7 +1,7 @@
 """Randomised parity sweep over K1's kernel forms (builder-run, not part of the pytest suite): families drawn with N inside
 alignment columns (ragged reads, ambiguous bases) or without, ladder-like or balanced trees, one or several waves per rate;
 every one compared with the numpy oracle (tests/test_gpu_parity.compare), the form each reached (lh_family_prune_form)
-tallied.  usage (GPU box, repo root): python tests/dev_tools/random_sweep_forms.py [first_seed] [n_seeds]"""
+tallied.  usage (GPU box, repo root): python tests/dev_tools/random_sweep_forms.py [first_seed] [n_seeds] [--wide]"""
 import collections
 import os
 import shutil
@@ -17,7 +17,9 @@ import tests.test_gpu_parity as t  # noqa: E402
 from oracle import linearham_oracle as orc  # noqa: E402
 from tools import synth_family as sf  # noqa: E402
 
-first, n = (int(sys.argv[1]) if len(sys.argv) > 1 else 5000), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
+wide = "--wide" in sys.argv      # 600-site families of 40-110 leaves: three to five waves per rate, R in {2, 3, 4, 5, 8}
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+first, n = (int(argv[0]) if len(argv) > 0 else 5000), (int(argv[1]) if len(argv) > 1 else 100)
 lib = linearham_amd.load_library()
 
 
@@ -37,13 +39,36 @@ def loose(h, desc, ll, res, ref):
 
 forms = collections.Counter()
 bad = soft = skipped = 0
+worst = {"loglik": 0.0, "emission": 0.0, "forward": 0.0}   # largest relative deviations from the oracle seen in the sweep
+
+
+def deviations(h, desc, ll, res, ref):
+    for i, r in enumerate(ref):
+        worst["loglik"] = max(worst["loglik"], abs(ll[i] - r["loglik"]) / abs(r["loglik"]))
+        e, g = np.asarray(r["xmsa_emission"]), np.asarray(res["xmsa_emission"][i])
+        m = e != 0
+        if m.any():
+            worst["emission"] = max(worst["emission"], float(np.max(np.abs(g[m] - e[m]) / e[m])))
+        ex = t.expand_forward(h, desc, res["forward"][i], res["scaler_counts"][i])
+        for k in ex:
+            if k.endswith("_forward"):
+                w, v = np.asarray(r[k], dtype=float), np.asarray(ex[k], dtype=float)
+                m = w != 0
+                if m.any():
+                    worst["forward"] = max(worst["forward"], float(np.max(np.abs(v[m] - w[m]) / np.abs(w[m]))))
 for seed in range(first, first + n):
     rng = np.random.default_rng(seed)
     locus = ["igh", "igh", "igk", "igl"][int(rng.integers(4))]
     kw = dict(locus=locus, seed=seed, n_samples=2, n_nni=int(rng.integers(0, 4)),
               ragged=int(rng.choice([0, 0, 4, 10])), ambiguous=float(rng.choice([0.0, 0.0, 0.01, 0.05])),
               tree_shape=str(rng.choice(["stepwise", "stepwise", "balanced"])))
-    if rng.random() < 0.35:      # several waves per rate: 240 sites, longer V
+    if wide:
+        kw.update(n_leaves=int(rng.integers(40, 110)), n_sites=600, n_v=int(rng.integers(4, 24)), n_d=int(rng.integers(1, 6)),
+                  n_j=int(rng.integers(1, 4)), brlen_mean=float(rng.choice([0.01, 0.02, 0.03])))
+        if locus != "igh":
+            kw.pop("n_d")
+        spec = sf.Spec(**kw)
+    elif rng.random() < 0.35:      # several waves per rate: 240 sites, longer V
         kw.update(n_leaves=int(rng.integers(20, 70)), n_sites=240, len_v=150, len_d=(8, 20), len_j=(30, 45),
                   n_v=int(rng.integers(2, 8)), n_j=int(rng.integers(1, 4)), v_ancestors=2, d_ancestors=2, j_ancestors=2,
                   divergence=0.1, brlen_mean=float(rng.choice([0.01, 0.03])))
@@ -61,13 +86,14 @@ for seed in range(first, first + n):
         sf.generate(spec, out)
         h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
         rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
-        R = int(rng.choice([1, 3, 4]))
+        R = int(rng.choice([2, 3, 4, 5, 8])) if wide else int(rng.choice([1, 3, 4]))
         desc, ll, res, ref = t.run_family(lib, h, rows, R)
         forms[t.LAST_RUN["form"]] += 1
         if not all(np.isfinite(r["loglik"]) for r in ref):   # the reference's own overflow rows: same mask on both sides
             assert [bool(np.isfinite(x)) for x in ll] == [bool(np.isfinite(r["loglik"])) for r in ref], seed
             skipped += 1
             continue
+        deviations(h, desc, ll, res, ref)
         try:
             t.compare(h, desc, ll, res, ref)
         except AssertionError as e:
@@ -80,9 +106,11 @@ for seed in range(first, first + n):
                 print("seed", seed, t.LAST_RUN["form"], "FAILED", " ".join(str(e2).split())[:300], flush=True)
     finally:
         shutil.rmtree(out, ignore_errors=True)
-    if (seed - first + 1) % 50 == 0:
+    if (seed - first + 1) % (5 if wide else 50) == 0:
         print("... %d seeds done" % (seed - first + 1), flush=True)
 print("sweep of %d seeds from %d: %d failures, %d beyond the relative tolerance on tiny entries only, %d with reference overflow rows"
       % (n, first, bad, soft, skipped), flush=True)
+print("largest relative deviations from the oracle: log-likelihood %.1e, xMSA emissions %.1e, forward entries %.1e"
+      % (worst["loglik"], worst["emission"], worst["forward"]), flush=True)
 print("forms reached:", dict(sorted(forms.items())), flush=True)
 sys.exit(1 if bad else 0)

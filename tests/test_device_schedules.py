@@ -20,10 +20,10 @@ def _run(mode, env_extra, n_leaves=12, repeat=1):
                        env=dict(os.environ, **env_extra))
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
-    if mode == "none":       # clean schedules: the kernel form's numbers against the oracle's (north star 1e-6; asserted 1e-10)
+    if mode == "none":       # clean schedules: the kernel form's numbers against the oracle's (north star 1e-6; asserted 1e-12)
         assert len(res["oracle"]) == len(res["ll"]) // repeat
         for got, want in zip(res["ll"], res["oracle"]):
-            assert got is not None and abs(got - want) <= 1e-10 * abs(want), (res["form"], got, want)
+            assert got is not None and abs(got - want) <= 1e-12 * abs(want), (res["form"], got, want)
     return res
 
 

@@ -4,7 +4,7 @@ K1 picks a kernel form from the family's shape (lh_prune.hip launch_prune: all r
 whole or a schedule segment at a time; register stack or cherry tables; N-aware tip gather or not; assembly or C++ walk;
 stack depth 3 / 4 / 16).  Each test below names the form it means to reach, runs a family that reaches it -- by its own
 shape, or pushed there by one of the launcher's test hooks (environment variables read once per process, hence the
-subprocess) -- compares log-likelihood (1e-10), rates, xMSA emissions and forward arrays (1e-8) and ScaleMatrix counts
+subprocess) -- compares log-likelihood (1e-12), rates, xMSA emissions (1e-10), forward arrays (1e-9) and ScaleMatrix counts
 (exact) with oracle/linearham_oracle.py, and asserts through lh_family_prune_form that the intended form is the one that ran.
 
 Reference behaviour covered: Partition::TraversalUpdate / LogLikelihood on any topology (src/PhyloHMM.cpp:224-226), N

@@ -115,10 +115,14 @@ def run_family(hip, h, samples, num_rates, extended=False):
     return desc, ll, res, ref
 
 
-def compare(h, desc, ll, res, ref, rtol=1e-10, em_rtol=1e-8, fwd_rtol=1e-8):
-    # Emissions and forward entries: 1e-8.  An emission dominated by off-diagonal P entries of a 1e-6
-    # branch (~1e-8 each, formed as 1 + U expm1 U^-1 with ~1e-17 absolute rounding) is only that well
-    # conditioned; a 60-seed sweep of random families stayed below 1.2e-9.
+def compare(h, desc, ll, res, ref, rtol=1e-12, em_rtol=1e-10, fwd_rtol=1e-9):
+    # Log-likelihood 1e-12, xMSA emissions 1e-10, forward entries (products of some 300 emissions) 1e-9 -- a hundred times
+    # inside the 1e-10 / 1e-8 the path is asked for.  Until the end of round 4 these bounds WERE 1e-10 / 1e-8 / 1e-8, and
+    # some twenty samples of the random sweeps needed even more: the oracles then formed P = U exp(lambda t r) U^-1, whose
+    # off-diagonal entries on 1e-6 branches (and at the rates of alpha = 0.05) carry rounding noise of 1e-10 relative and
+    # more; with libpll's published form (expm1, identity added at the end; linearham_oracle.gtr_pmatrices) both CPU
+    # restatements and the kernels agree: over 1300 random families (tests/dev_tools/random_sweep_forms.py) the largest
+    # deviations are 7.6e-14 / 1.2e-11 / 9.2e-11 (profiles/r04_sweep_forms.txt).
     for i, r in enumerate(ref):
         assert abs(ll[i] - r["loglik"]) <= rtol * abs(r["loglik"]), (i, ll[i], r["loglik"])
         np.testing.assert_allclose(res["rates"][i], r["rates"], rtol=1e-9)
@@ -254,13 +258,13 @@ def test_extended_range_equals_default_where_finite(hip, tmp_path, preset):
     desc, ll, res, ref = run_family(hip, h, rows, 4, extended=True)
     for i, r in enumerate(ref):
         assert abs(ll[i] - r["loglik"]) <= 1e-10 * abs(r["loglik"]), (i, ll[i], r["loglik"])
-        np.testing.assert_allclose(res["xmsa_emission"][i], r["xmsa_emission"], rtol=1e-8)
+        np.testing.assert_allclose(res["xmsa_emission"][i], r["xmsa_emission"], rtol=1e-10)
         ex = expand_forward(h, desc, res["forward"][i], res["scaler_counts"][i])
         got = np.log(ex["jgerm_forward"].sum()) - ex["jgerm_scaler_count"] * np.log(2.0 ** 256)
         assert abs(got - r["loglik"]) <= 1e-10 * abs(r["loglik"])
         big = r["jgerm_forward"] > r["jgerm_forward"].max() * 1e-100
         d = (ex["jgerm_scaler_count"] - r["jgerm_scaler_count"]) * 256
-        np.testing.assert_allclose(ex["jgerm_forward"][big], np.ldexp(r["jgerm_forward"][big], d), rtol=1e-8)
+        np.testing.assert_allclose(ex["jgerm_forward"][big], np.ldexp(r["jgerm_forward"][big], d), rtol=1e-9)
 
 
 @pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108])
@@ -495,7 +499,7 @@ def test_full_size_forward_arrays_match_dense_oracle(hip, tmp_path, preset):
     """What SampleNaiveSequence consumes (src/HMM.cpp:1222-1353, 1107-1177), at BASELINE.json's full sizes: the forward
     arrays and ScaleMatrix counts the two-samples-per-wave K2b kernels write for configs[2] (100 leaves x 400 sites,
     200 V / 30 D / 12 J) and configs[4] (500 leaves x 600 sites) against the dense reference algorithm in C
-    (oracle_kernels.c, oc_eval_batch_fwd): values 1e-8, counts exactly, on every row the reference evaluates finitely."""
+    (oracle_kernels.c, oc_eval_batch_fwd): values 1e-9, counts exactly, on every row the reference evaluates finitely."""
     import linearham_amd
     from oracle import oracle_c
     from tools import synth_family as sf
@@ -530,7 +534,7 @@ def test_full_size_forward_arrays_match_dense_oracle(hip, tmp_path, preset):
             if "scaler" in k:
                 assert np.array_equal(np.asarray(ex[k]), np.asarray(r[k])), (i, k, ex[k], r[k])
             else:
-                np.testing.assert_allclose(ex[k], r[k], rtol=1e-8, atol=0, err_msg="%d %s" % (i, k))
+                np.testing.assert_allclose(ex[k], r[k], rtol=1e-9, atol=0, err_msg="%d %s" % (i, k))
         checked += 1
     assert checked >= 3
 
