@@ -1,4 +1,7 @@
-"""How well conditioned is the reference algorithm on a sweep family?  Rebuilds the family tests/dev_tools/random_sweep_forms.py
+"""(History: this tool is what showed, at the end of round 4, that the "conditioning" it was written to measure was the
+oracles' own -- P-matrices formed with exp() instead of libpll's expm1 form; with that form the two restatements agree to
+1e-15 / 1e-11 on every former outlier.  It stays as the check that they do.)
+How well conditioned is the reference algorithm on a sweep family?  Rebuilds the family tests/dev_tools/random_sweep_forms.py
 draws for a seed and compares the two CPU restatements (numpy and C: the same operations in another summation order) on its
 forward arrays.  A seed on which they differ by more than the suite's 1e-8 is one where that bound says nothing about a third
 implementation.  CPU only.  usage: python tests/dev_tools/oracle_conditioning.py [--wide] seed [seed ...]"""
