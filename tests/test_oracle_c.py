@@ -71,3 +71,32 @@ def test_c_oracle_forward_arrays_match_the_numpy_oracle(tmp_path):
                     assert np.array_equal(np.asarray(v), np.asarray(want)), k
                 else:
                     np.testing.assert_allclose(v, want, rtol=1e-10, atol=0, err_msg=k)
+
+
+def test_pmatrix_form_on_tiny_qt():
+    """gtr_pmatrices forms P as libpll's core_pmatrix.c does (expm1 of the eigenvalues, identity added at the end).  On a 1e-6
+    branch at the slowest rate of alpha = 0.05 (Q t r ~ 1e-19) its off-diagonal entries are Q_ij t r to rounding; the plain
+    exp() form this oracle had until round 4 leaves rounding noise of size 1e-17 there -- two orders above the entries, of
+    either sign.  On ordinary branches the two forms agree to 1e-15 absolute."""
+    er, pi = [1.0, 2.5, 0.7, 1.3, 3.1, 0.9], np.array([0.17, 0.19, 0.25, 0.39])
+    rates = orc.gamma_rates_mean(0.05, 4)
+    assert rates[0] < 1e-11
+    t = np.array([1e-6, 0.01, 0.3])
+    P = orc.gtr_pmatrices(er, pi, rates, t)
+    P_exp = orc.gtr_pmatrices(er, pi, rates, t, plain_exp=True)
+    np.testing.assert_allclose(P.sum(axis=-1), 1.0, rtol=0, atol=4e-15)
+    # the generator, as gtr_pmatrices builds it
+    S = np.zeros((4, 4))
+    S[np.triu_indices(4, 1)] = er
+    S = S + S.T
+    Q = S * pi[None, :]
+    np.fill_diagonal(Q, 0.0)
+    np.fill_diagonal(Q, -Q.sum(axis=1))
+    Q /= -np.sum(pi * np.diag(Q))
+    off = ~np.eye(4, dtype=bool)
+    tiny = P[0, 0][off]                                   # 1e-6 branch, slowest rate
+    np.testing.assert_allclose(tiny, (Q * t[0] * rates[0])[off], rtol=1e-12)
+    assert (tiny > 0).all()
+    noise = np.abs(P_exp[0, 0][off] - tiny)
+    assert noise.max() > 10 * tiny.max()                  # the old form: noise, not signal, at this size
+    np.testing.assert_allclose(P[1:, 2:], P_exp[1:, 2:], rtol=0, atol=2e-15)
