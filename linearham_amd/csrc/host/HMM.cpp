@@ -904,12 +904,16 @@ int DrawDiscreteSparse(std::mt19937& rng, const int* idx, const double* weights,
   double sum = 0.0;
   for (int j = 0; j < k; ++j) sum += weights[j];
   const double p = std::generate_canonical<double, std::numeric_limits<double>::digits>(rng);
-  if (!(p > 0.0) || k == 0) return 0;  // (all weights zero: libstdc++'s table is all NaN, index 0 comes back)
+  // (all weights zero, or a NaN among them: libstdc++'s table is all NaN from its first element, index 0 comes back)
+  if (!(p > 0.0) || k == 0 || sum != sum) return 0;
   double cum = 0.0;
   for (int j = 0; j < k; ++j) {
     cum += weights[j] / sum;
     const double cp = (j == k - 1 && idx[j] == size - 1) ? 1.0 : cum;
-    if (cp >= p) return idx[j];
+    // lower_bound: the first element that is NOT below p.  Written as !(cp < p), not cp >= p: on a row the reference's
+    // 2^(256 d) equalisation has overflowed (src/PhyloHMM.cpp:190-192) weights are inf, their quotients by the sum NaN,
+    // every partial sum from the first of them on NaN, and lower_bound -- no NaN is below anything -- stops there.
+    if (!(cp < p)) return idx[j];
   }
   return size - 1;
 }

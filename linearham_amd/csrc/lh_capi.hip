@@ -337,10 +337,19 @@ int upload_vec(lh_family* f, const std::vector<T>& v, const T** out) {
 
 // `remap` translates xMSA column indices into positions of the compact junction-column list; -1 (the
 // state does not emit at this site) and padding become the zero sentinel at position n_jcols.
+// left_chunks / right_chunks: the 64-gene register chunks K2b's kernel template gives each side of THIS junction
+// (lh_forward.hip launch_forward: the V side 1 / 2 / 4 / 8 / 16 by the V alleles, every D or J side 1 / 2 / 4 by the LARGER of
+// the D and J sets).  The tables are padded to that width, not to the side's own gene count rounded up: a lane reads
+// entry lane + 64 q of a row for every q of its template (round 4: with 65 D and 30 J alleles the D-J junction's J side was
+// padded to 64 and read two chunks wide -- the second chunk was the NEXT row's entries, behind the last row whatever
+// followed the table; such lanes feed no result, but their values entered the row's ScaleMatrix key, and a tiny one
+// scaled the row's real entries to inf; found by tests/dev_tools/random_sweep_pipeline.py --many).
 int upload_junction(lh_family* f, const lh_junction& j, const std::vector<int32_t>& remap, int n_jcols,
-                    const int32_t* xmsa_site, const std::vector<int32_t>& pat_of_site, lh::DevJunction* d) {
+                    const int32_t* xmsa_site, const std::vector<int32_t>& pat_of_site, int left_chunks, int right_chunks,
+                    lh::DevJunction* d) {
   const size_t W = j.n_rows, nL = j.n_left, nR = j.n_right;
-  const size_t pL = (nL + 63) / 64 * 64, pR = (nR + 63) / 64 * 64;
+  const size_t pL = std::max<size_t>((nL + 63) / 64, (size_t)left_chunks) * 64,
+               pR = std::max<size_t>((nR + 63) / 64, (size_t)right_chunks) * 64;
   d->n_rows = j.n_rows;
   d->n_left = j.n_left;
   d->n_right = j.n_right;
@@ -683,11 +692,19 @@ int lh_family_create(const lh_family_desc* desc, lh_family** out) {
     h.n_jcols = (int32_t)jcols.size();
     rc = upload(f, jcols.data(), jcols.size(), &h.jcols);
   }
-  rc = rc || upload_junction(f, desc->vd, remap, h.n_jcols, seg_site, pat_of_site_all, &h.vd);
+  // the chunk counts of K2b's templates (launch_forward): GA for the V side, GB for every D / J side
+  auto round_to = [](int c, std::initializer_list<int> steps) {
+    for (int s : steps)
+      if (c <= s) return s;
+    return c;
+  };
+  const int ga_t = round_to(((int)nV + 63) / 64, {1, 2, 4, 8, 16});
+  const int gb_t = round_to((std::max((int)desc->dgerm.n_genes * (h.has_d ? 1 : 0), (int)nJ) + 63) / 64, {1, 2, 4});
+  rc = rc || upload_junction(f, desc->vd, remap, h.n_jcols, seg_site, pat_of_site_all, ga_t, gb_t, &h.vd);
   if (!rc && desc->vd.n_left != (int)nV) rc = fail("lh_family_create: vd.n_left != number of V genes");
   if (h.has_d) {
     rc = rc || upload_segments(f, desc->dgerm, desc->n_xmsa, ucol, h.n_ucol, seg_site, &h.dgerm);
-    rc = rc || upload_junction(f, desc->dj, remap, h.n_jcols, seg_site, pat_of_site_all, &h.dj);
+    rc = rc || upload_junction(f, desc->dj, remap, h.n_jcols, seg_site, pat_of_site_all, gb_t, gb_t, &h.dj);
     if (!rc && (desc->vd.n_right != desc->dgerm.n_genes || desc->dj.n_left != desc->dgerm.n_genes ||
                 desc->dj.n_right != (int)nJ))
       rc = fail("lh_family_create: junction gene counts do not match the germline regions");

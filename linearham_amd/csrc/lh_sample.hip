@@ -152,13 +152,14 @@ __device__ int group_draw(int n_dense, const double (&own)[5], int n_mid, F&& la
 #pragma unroll
   for (int a = 0; a < n_pre; ++a, ++pos) {
     cum += pre[a] / sum;
-    if (result == kNone && cum >= p) result = pos;
+    if (result == kNone && !(cum < p)) result = pos;
   }
   if (saved) {
     // quotients in place (a lane its own elements), then every lane of the group runs the partial sums over them on
-    // broadcast reads.  Weights are >= 0 (or the sum is NaN, which was settled above), so the partial sums never fall and
-    // the element lower_bound picks is the number of leading elements whose partial sum is not >= the uniform -- one
-    // compare and one add-with-carry per element, no round trip through LDS between chunks.
+    // broadcast reads.  Weights are >= 0 (or the sum is NaN, which was settled above), so the partial sums never fall --
+    // or, from an inf weight on (a row the reference's 2^(256 d) equalisation has overflowed), are NaN to the end -- and
+    // the element lower_bound picks is the number of leading elements whose partial sum is BELOW the uniform (no NaN is):
+    // one compare and one add-with-carry per element, no round trip through LDS between chunks.
     for (int c = 0; c < n_mid; c += kG)
       if ((nz >> ((c / kG) & 63)) & 1) d.wsave[c + gl] = d.wsave[c + gl] / sum;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -176,9 +177,9 @@ __device__ int group_draw(int n_dense, const double (&own)[5], int n_mid, F&& la
       for (int j = 0; j < kG / 2; ++j) {
         const double2 v = b2[j];
         cum += v.x;
-        cnt += !(cum >= p) ? 1 : 0;
+        cnt += cum < p ? 1 : 0;
         cum += v.y;
-        cnt += !(cum >= p) ? 1 : 0;
+        cnt += cum < p ? 1 : 0;
       }
       if (result == kNone) {
         below = c + cnt;  // (every element before this chunk was below: the chunk is reached with result == kNone only then)
@@ -216,7 +217,7 @@ __device__ int group_draw(int n_dense, const double (&own)[5], int n_mid, F&& la
     const double mine = d.cbuf[gl];
     cum = d.cbuf[kG - 1];  // (lanes beyond the chunk added zeros)
     const int m = min(kG, n_mid - c);
-    const unsigned long long hit = __builtin_amdgcn_ballot_w64(result == kNone && gl < m && mine >= p);
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(result == kNone && gl < m && !(mine < p));
     const unsigned mine_hits = (unsigned)(hit >> shift) & (kG >= 32 ? 0xffffffffu : ((1u << (kG & 31)) - 1u));
     __builtin_amdgcn_wave_barrier();
     if (result == kNone && mine_hits != 0) result = n_pre + c + (int)__builtin_ctz(mine_hits);
@@ -226,7 +227,7 @@ __device__ int group_draw(int n_dense, const double (&own)[5], int n_mid, F&& la
 #pragma unroll
   for (int a = 0; a < n_post; ++a, ++pos) {
     cum += post[a] / sum;
-    if (result == kNone && cum >= p) result = pos;
+    if (result == kNone && !(cum < p)) result = pos;
   }
   return result == kNone ? kPastEnd : result;
 }

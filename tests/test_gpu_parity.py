@@ -309,6 +309,27 @@ def test_smallest_trees_and_odd_rate_counts(hip, tmp_path, n_leaves, R, kw):
     compare(h, desc, ll, res, ref)
 
 
+@pytest.mark.parametrize("kw", [dict(n_v=289, n_d=65, n_j=30, n_leaves=7, ragged=10, ambiguous=0.05, divergence=0.3, seed=13358),
+                                dict(n_v=70, n_d=65, n_j=30, seed=61), dict(n_v=70, n_d=20, n_j=70, seed=62),
+                                dict(n_v=130, n_d=140, n_j=10, seed=63), dict(n_v=40, n_d=3, n_j=200, seed=64)],
+                         ids=["sweep13358", "d65_j30", "d20_j70", "d140_j10", "d3_j200"])
+def test_junction_sides_of_unequal_chunk_counts(hip, tmp_path, kw):
+    """K2b gives every D or J side of a junction the register chunks of the LARGER of the two sets (64 genes a chunk), so a
+    junction table whose own side is the smaller one is read wider than its gene count rounded up: 65 D with 30 J alleles
+    (the D-J junction's J side two chunks wide), 20 D with 70 J (its D side), and so on.  Until the end of round 4 the tables
+    were padded to their own width: the second chunk was the next row's entries -- on the J side harmless to every value
+    but not to the row's ScaleMatrix key (the first case, found by tests/dev_tools/random_sweep_pipeline.py --many, came back
+    inf where the reference is finite), on the D side summed into the rank-one term."""
+    from tools import synth_family as sf
+    out = str(tmp_path / "fam")
+    sf.generate(sf.Spec.small(n_samples=3, **kw), out)
+    h = orc.PhyloHMM(os.path.join(out, "cluster.yaml"), 0, os.path.join(out, "hmm_params"), 0)
+    rows = sf.read_trees_tsv(os.path.join(out, "trees.tsv"))
+    desc, ll, res, ref = run_family(hip, h, rows, 3)
+    assert all(np.isfinite(r["loglik"]) for r in ref)
+    compare(h, desc, ll, res, ref)
+
+
 def test_large_tree_family(hip, tmp_path):
     """BASELINE.json configs[4] shape: 500 leaves x 600 sites (LDS tip table > 64 KB, two site tiles,
     deeper schedule stack), reduced germline set so that the dense oracle stays fast."""
