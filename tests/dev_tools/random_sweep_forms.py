@@ -1,7 +1,7 @@
 """Randomised parity sweep over K1's kernel forms (builder-run, not part of the pytest suite): families drawn with N inside
 alignment columns (ragged reads, ambiguous bases) or without, ladder-like or balanced trees, one or several waves per rate;
 every one compared with the numpy oracle (tests/test_gpu_parity.compare), the form each reached (lh_family_prune_form)
-tallied.  usage (GPU box, repo root): python tests/dev_tools/random_sweep_forms.py [first_seed] [n_seeds] [--wide | --many]"""
+tallied.  usage (GPU box, repo root): python tests/dev_tools/random_sweep_forms.py [first_seed] [n_seeds] [--wide | --many | --huge | --large]"""
 import collections
 import os
 import shutil
@@ -63,7 +63,12 @@ for seed in range(first, first + n):
     kw = dict(locus=locus, seed=seed, n_samples=2, n_nni=int(rng.integers(0, 4)),
               ragged=int(rng.choice([0, 0, 4, 10])), ambiguous=float(rng.choice([0.0, 0.0, 0.01, 0.05])),
               tree_shape=str(rng.choice(["stepwise", "stepwise", "balanced"])))
-    if many:
+    if "--large" in sys.argv:        # 120-400 leaves (tip tables beyond a workgroup's share of LDS: the segmented kernels by shape)
+        kw.update(n_leaves=int(rng.integers(120, 400)), n_v=int(rng.integers(1, 9)), n_j=int(rng.integers(1, 6)))
+        if locus == "igh":
+            kw["n_d"] = int(rng.integers(1, 6))
+        spec = sf.Spec.small(**kw)
+    elif many:
         huge = "--huge" in sys.argv      # up to the ABI's limits: 1024 V, 256 D, 256 J alleles (sixteen / four register chunks)
         kw.update(n_leaves=int(rng.integers(3, 10)), n_v=int(rng.integers(500, 1025) if huge else rng.integers(30, 320)),
                   n_j=int(rng.integers(100, 257) if huge else rng.integers(1, 140)), divergence=float(rng.choice([0.0, 0.05, 0.3])))
@@ -114,7 +119,7 @@ for seed in range(first, first + n):
                 print("seed", seed, t.LAST_RUN["form"], "FAILED", " ".join(str(e2).split())[:300], flush=True)
     finally:
         shutil.rmtree(out, ignore_errors=True)
-    if (seed - first + 1) % (5 if wide or many else 50) == 0:
+    if (seed - first + 1) % (5 if wide or many or '--large' in sys.argv else 50) == 0:
         print("... %d seeds done" % (seed - first + 1), flush=True)
 print("sweep of %d seeds from %d: %d failures, %d beyond the relative tolerance on tiny entries only, %d with reference overflow rows"
       % (n, first, bad, soft, skipped), flush=True)
