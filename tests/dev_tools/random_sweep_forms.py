@@ -1,7 +1,7 @@
 """Randomised parity sweep over K1's kernel forms (builder-run, not part of the pytest suite): families drawn with N inside
 alignment columns (ragged reads, ambiguous bases) or without, ladder-like or balanced trees, one or several waves per rate;
 every one compared with the numpy oracle (tests/test_gpu_parity.compare), the form each reached (lh_family_prune_form)
-tallied.  usage (GPU box, repo root): python tests/dev_tools/random_sweep_forms.py [first_seed] [n_seeds] [--wide | --many | --huge | --large]"""
+tallied.  usage (GPU box, repo root): python tests/dev_tools/random_sweep_forms.py [first_seed] [n_seeds] [--wide | --many | --huge | --large] [--ext]"""
 import collections
 import os
 import shutil
@@ -107,6 +107,12 @@ for seed in range(first, first + n):
             skipped += 1
             continue
         deviations(h, desc, ll, res, ref)
+        if "--ext" in sys.argv:      # the same family in the extended-range mode: the same log-likelihood wherever the reference is finite
+            _, ll_x, _, _ = t.run_family(lib, h, rows, R, extended=True)
+            for i, r in enumerate(ref):
+                if np.isfinite(r["loglik"]) and not abs(ll_x[i] - r["loglik"]) <= 1e-12 * abs(r["loglik"]):
+                    bad += 1
+                    print("seed", seed, "extended-range mode FAILED", i, ll_x[i], r["loglik"], flush=True)
         try:
             t.compare(h, desc, ll, res, ref)
         except AssertionError as e:
