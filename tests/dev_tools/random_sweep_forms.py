@@ -1,7 +1,7 @@
 """Randomised parity sweep over K1's kernel forms (builder-run, not part of the pytest suite): families drawn with N inside
 alignment columns (ragged reads, ambiguous bases) or without, ladder-like or balanced trees, one or several waves per rate;
 every one compared with the numpy oracle (tests/test_gpu_parity.compare), the form each reached (lh_family_prune_form)
-tallied.  usage (GPU box, repo root): python tests/dev_tools/random_sweep_forms.py [first_seed] [n_seeds] [--wide | --many | --huge | --large] [--ext]"""
+tallied.  usage (GPU box, repo root): python tests/dev_tools/random_sweep_forms.py [first_seed] [n_seeds] [--wide | --many | --huge | --large | --long] [--ext]"""
 import collections
 import os
 import shutil
@@ -63,7 +63,13 @@ for seed in range(first, first + n):
     kw = dict(locus=locus, seed=seed, n_samples=2, n_nni=int(rng.integers(0, 4)),
               ragged=int(rng.choice([0, 0, 4, 10])), ambiguous=float(rng.choice([0.0, 0.0, 0.01, 0.05])),
               tree_shape=str(rng.choice(["stepwise", "stepwise", "balanced"])))
-    if "--large" in sys.argv:        # 120-400 leaves (tip tables beyond a workgroup's share of LDS: the segmented kernels by shape)
+    if "--long" in sys.argv:         # 1500-3000 sites, 40-80 leaves: more than 1024 patterns -- several site tiles per (sample, rate) by shape
+        kw.update(n_leaves=int(rng.integers(40, 80)), n_sites=int(rng.integers(1500, 3000)), len_v=int(rng.integers(1300, 1400)),
+                  n_v=int(rng.integers(2, 6)), n_j=int(rng.integers(1, 3)), brlen_mean=float(rng.choice([0.02, 0.04])))
+        if locus == "igh":
+            kw["n_d"] = int(rng.integers(1, 3))
+        spec = sf.Spec(**kw)
+    elif "--large" in sys.argv:        # 120-400 leaves (tip tables beyond a workgroup's share of LDS: the segmented kernels by shape)
         kw.update(n_leaves=int(rng.integers(120, 400)), n_v=int(rng.integers(1, 9)), n_j=int(rng.integers(1, 6)))
         if locus == "igh":
             kw["n_d"] = int(rng.integers(1, 6))
@@ -102,6 +108,7 @@ for seed in range(first, first + n):
         R = int(rng.choice([2, 3, 4, 5, 8])) if wide else int(rng.choice([1, 3, 4]))
         desc, ll, res, ref = t.run_family(lib, h, rows, R)
         forms[t.LAST_RUN["form"]] += 1
+        worst["patterns"] = max(worst.get("patterns", 0), t.LAST_RUN["n_patterns"])
         if not all(np.isfinite(r["loglik"]) for r in ref):   # the reference's own overflow rows: same mask on both sides
             assert [bool(np.isfinite(x)) for x in ll] == [bool(np.isfinite(r["loglik"])) for r in ref], seed
             skipped += 1
@@ -125,11 +132,12 @@ for seed in range(first, first + n):
                 print("seed", seed, t.LAST_RUN["form"], "FAILED", " ".join(str(e2).split())[:300], flush=True)
     finally:
         shutil.rmtree(out, ignore_errors=True)
-    if (seed - first + 1) % (5 if wide or many or '--large' in sys.argv else 50) == 0:
+    if (seed - first + 1) % (5 if wide or many or '--large' in sys.argv or '--long' in sys.argv else 50) == 0:
         print("... %d seeds done" % (seed - first + 1), flush=True)
 print("sweep of %d seeds from %d: %d failures, %d beyond the relative tolerance on tiny entries only, %d with reference overflow rows"
       % (n, first, bad, soft, skipped), flush=True)
 print("largest relative deviations from the oracle: log-likelihood %.1e, xMSA emissions %.1e, forward entries %.1e"
       % (worst["loglik"], worst["emission"], worst["forward"]), flush=True)
+print("most site patterns in a family:", worst.get("patterns", 0), flush=True)
 print("forms reached:", dict(sorted(forms.items())), flush=True)
 sys.exit(1 if bad else 0)
