@@ -2,7 +2,7 @@
 suite): random small families -- igh / igk / igl, with and without N inside alignment columns, 1-8 alleles per segment -- through
 the C++ host (host.PhyloHMM.run_pipeline, device sampler), every row's NaiveSequence and LogLikelihood against
 oracle/linearham_oracle.py (same std::mt19937 stream; src/HMM.cpp:358-431, src/PhyloHMM.cpp RunPipeline).
-usage (GPU box, repo root): python tests/dev_tools/random_sweep_pipeline.py [first_seed] [n_seeds] [--many]"""
+usage (GPU box, repo root): python tests/dev_tools/random_sweep_pipeline.py [first_seed] [n_seeds] [--many] [--indels]"""
 import os
 import shutil
 import sys
@@ -34,6 +34,8 @@ for seed in range(first, first + n):
             kw["n_d"] = int(rng.integers(10, 80))
     R = int(rng.choice([1, 3, 4]))
     rng_seed = int(rng.integers(0, 1000))
+    if "--indels" in sys.argv:      # some sequences flagged has_shm_indels: read from indel_reversed_seqs (src/HMM.cpp:74-79)
+        kw["shm_indels"] = int(rng.integers(1, 4))
     out = tempfile.mkdtemp(prefix="lh_sweepp_")
     try:
         sf.generate(sf.Spec.small(**kw), out)
