@@ -1,7 +1,7 @@
 """Randomised sweep of the ancestral-sequence sampling step (K3 on K1's unmixed planes; builder-run, not part of the pytest
 suite): random small families -- with and without N inside alignment columns, ladder-like and balanced trees, R in {1, 3, 4,
 8} -- each tree sample's draws against oracle/asr_oracle.py (tests/test_gpu_asr._run; that oracle's parity is UNPINNED: the
-reference holds no fixture for the step).  usage (GPU box, repo root): python tests/dev_tools/random_sweep_asr.py [first_seed] [n_seeds]"""
+reference holds no fixture for the step).  usage (GPU box, repo root): python tests/dev_tools/random_sweep_asr.py [first_seed] [n_seeds] [--large]"""
 import os
 import shutil
 import sys
@@ -16,7 +16,8 @@ import tests.test_gpu_asr as ta  # noqa: E402
 from oracle import linearham_oracle as orc  # noqa: E402
 from tools import synth_family as sf  # noqa: E402
 
-first, n = (int(sys.argv[1]) if len(sys.argv) > 1 else 9000), (int(sys.argv[2]) if len(sys.argv) > 2 else 100)
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+first, n = (int(argv[0]) if len(argv) > 0 else 9000), (int(argv[1]) if len(argv) > 1 else 100)
 lib = linearham_amd.load_library()
 total_mism = total_sites = bad = 0
 for seed in range(first, first + n):
@@ -27,6 +28,8 @@ for seed in range(first, first + n):
               tree_shape=str(rng.choice(["stepwise", "stepwise", "balanced"])), n_nni=int(rng.integers(0, 4)))
     if locus == "igh":
         kw["n_d"] = int(rng.integers(1, 4))
+    if "--large" in sys.argv:      # 100-400 leaves: K1's unfused kernels on deep / wide trees, K3's larger LDS tables
+        kw["n_leaves"] = int(rng.integers(100, 400))
     out = tempfile.mkdtemp(prefix="lh_sweepa_")
     try:
         sf.generate(sf.Spec.small(**kw), out)
